@@ -1,0 +1,184 @@
+/*
+ * nbody3d_hip.h -- C ABI of the MI355X direct N-body engine (libnbody3d_hip.so)
+ *
+ * This is the drop-in boundary for the ONE hot path of huj31415/nbody3d-webgpu:
+ * the tiled O(N^2) force accumulation + leapfrog update that the reference runs
+ * as a single WGSL compute pass.  The reference has no FFI/plugin interface for
+ * it: the path sits behind the WebGPU object protocol inside nbody3d.js.  Each
+ * entry point below names the piece of that protocol it replaces (file:line
+ * relative to /root/reference).  INTEGRATION.md shows the N-API / ctypes binding.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types.
+ *   - Every call returns an nb_status (0 = ok).  Nothing throws or aborts across
+ *     the boundary; nb_last_error() gives the message for the last failure.
+ *   - Host arrays use the reference's packed layout (nbody3d.js:49,132):
+ *       bodies[4*i..] = x, y, z, mass     vel[4*i..] = vx, vy, vz, 0
+ *       accel [4*i..] = ax, ay, az, 0     (acceleration of the previous step)
+ *     element type float for NB_F32 sims, double for NB_F64 sims.
+ *   - The engine never keeps a host pointer past the call (the reference's
+ *     writeBuffer copies, nbody3d.js:186,193); it owns all device memory unless
+ *     nb_config.ext_bodies is given.  nb_download fills caller-owned arrays
+ *     (util.js:163-178 returns a fresh copy).
+ *   - One host thread per handle at a time; distinct handles are independent.
+ *   - nb_step enqueues on the engine's HIP stream and returns (the reference's
+ *     queue.submit is asynchronous, nbody3d.js:490); nb_download / nb_sync block.
+ */
+#ifndef NBODY3D_HIP_H
+#define NBODY3D_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(__GNUC__)
+#pragma GCC visibility push(default) /* the library is built -fvisibility=hidden */
+#endif
+
+#define NB_ABI_VERSION 1u
+
+typedef struct nb_sim nb_sim; /* opaque */
+
+typedef enum nb_status {
+    NB_OK = 0,
+    NB_ERR_INVALID = 1,   /* bad argument / bad config                       */
+    NB_ERR_NO_DEVICE = 2, /* no usable HIP device (reference: nbody3d.js:151) */
+    NB_ERR_HIP = 3,       /* a HIP runtime call failed                       */
+    NB_ERR_STATE = 4,     /* call out of order (e.g. step before upload)     */
+    NB_ERR_NOMEM = 5,
+    NB_ERR_COMM = 6       /* the exchange hook / collective failed           */
+} nb_status;
+
+typedef enum nb_precision { NB_F32 = 0, NB_F64 = 1 } nb_precision;
+
+/* nb_config.flags */
+#define NB_FLAG_EXT_STREAM 1u /* ext_stream is meaningful even when NULL (the
+                                 HIP null stream, e.g. torch's default stream) */
+
+/* nb_array: selector for nb_device_ptr */
+typedef enum nb_array { NB_BODIES = 0, NB_VEL = 1, NB_ACCEL = 2 } nb_array;
+
+/*
+ * Engine configuration.  Replaces: buffer creation (nbody3d.js:179-204), the
+ * constants TILE_SIZE (:4) and the hard-coded softening 1e-4 (:234).
+ * Zero-initialise, set struct_size = sizeof(nb_config), then fill what you need;
+ * zero fields take the defaults noted.
+ */
+typedef struct nb_config {
+    uint32_t struct_size;  /* sizeof(nb_config), for ABI evolution             */
+    uint32_t n;            /* total bodies N (any N >= 1; reference is only
+                              defined for N % 256 == 0)        */
+    uint32_t precision;    /* nb_precision; default NB_F32                     */
+    uint32_t tile;         /* j-tile staged in LDS; 0 -> 256 (nbody3d.js:4)    */
+    double eps2;           /* Plummer softening; 0 -> 1e-4 (nbody3d.js:234).
+                              Must be > 0 (the self term relies on it)         */
+    int32_t device;        /* HIP device ordinal; -1 -> current device         */
+    /* i-shard owned by this handle.  The handle integrates
+     * bodies [shard_begin, shard_begin+shard_count) against ALL n bodies and
+     * keeps vel/accel only for its shard.  shard_count == 0 -> whole system.   */
+    uint32_t shard_begin;
+    uint32_t shard_count;
+    /* Optional: run on a caller-owned hipStream_t (e.g. torch's current
+     * stream) instead of a private one.  Used when non-NULL or when
+     * NB_FLAG_EXT_STREAM is set.                                               */
+    void *ext_stream;
+    /* Optional: caller-owned DEVICE buffer of 4*n elements used as the
+     * replicated bodies array (so a host framework can run its collective
+     * directly on it).  NULL -> engine allocates.                              */
+    void *ext_bodies;
+    /* Force-kernel launch shape overrides for tuning; 0 -> engine heuristics.  */
+    uint32_t force_variant; /* see nb_variant_name()                            */
+    uint32_t jsplit;        /* number of j-partitions (grid.y)                  */
+    uint32_t flags;         /* NB_FLAG_*                                        */
+    uint32_t reserved[5];
+} nb_config;
+
+/* Library / ABI version; callable with no device. */
+uint32_t nb_abi_version(void);
+
+/* Number of visible HIP devices (0 when there is none; never fails). */
+int nb_device_count(void);
+
+/* create: nbody3d.js:179-204 (three 16*N-byte buffers + uniform block) and
+ * :296-311 (pipeline + bind group).  *out is NULL on failure; the message is
+ * then available from nb_last_error(NULL). */
+int nb_create(const nb_config *cfg, nb_sim **out);
+
+/* destroy: the reference never frees (util.js:72-73 commented out). */
+void nb_destroy(nb_sim *s);
+
+/* upload: queue.writeBuffer of bodyData / velData (nbody3d.js:186,193) and the
+ * checkpoint restore (util.js:230-244).  bodies and vel hold 4*n elements
+ * (whole system, every rank passes the same arrays); accel may be NULL -> zeros
+ * (WebGPU zero-initialises accelBuffer, nbody3d.js:195-199). */
+int nb_upload(nb_sim *s, const void *bodies, const void *vel, const void *accel);
+
+/* set_params: uni.dtValue / uni.GValue + per-frame queue.writeBuffer of the
+ * uniform block (nbody3d.js:470,516-517; util.js:45,53). */
+int nb_set_params(nb_sim *s, double dt, double G);
+
+/* step: `if (dt > 0)` compute pass + submit (nbody3d.js:474-480,489-490),
+ * nsteps times back to back.  dt <= 0 -> no-op, state untouched (:474). */
+int nb_step(nb_sim *s, uint32_t nsteps);
+
+/* download: exportSimulation's three readBuffer() copies (util.js:163-178).
+ * Blocks until all enqueued steps are done.  Any pointer may be NULL (skipped).
+ * bodies receives all 4*n elements; vel/accel receive the 4*n-element arrays
+ * with only this handle's shard rows filled (others untouched). */
+int nb_download(nb_sim *s, void *bodies, void *vel, void *accel);
+
+/* sync: await device idle (the mapAsync await of util.js:174). */
+int nb_sync(nb_sim *s);
+
+/* Message for the last failed call on s (s == NULL: last failed nb_create on
+ * this thread).  Never NULL; valid until the next call on the same handle. */
+const char *nb_last_error(nb_sim *s);
+
+/* ---- multi-GPU support (no reference analogue) ----------- */
+
+/* Device address of a state array (bodies: 4*n elements, replicated;
+ * vel/accel: 4*shard_count elements). */
+int nb_device_ptr(nb_sim *s, int which /* nb_array */, void **out);
+
+/* Exchange hook: called on the calling thread once per step, after the
+ * integrate kernel has been ENQUEUED for this handle's shard, with the stream
+ * the work was enqueued on.  The hook must make bodies[shard rows of every
+ * other rank] current on that stream (an all-gather of position rows) before
+ * returning control, and return 0 on success.  NULL -> no exchange (single
+ * shard).  The reference has no collective; this is where RCCL plugs in. */
+typedef int (*nb_exchange_fn)(void *user, void *bodies_dev, size_t elem_size,
+                              uint32_t n, uint32_t shard_begin,
+                              uint32_t shard_count, void *hip_stream);
+int nb_set_exchange(nb_sim *s, nb_exchange_fn fn, void *user);
+
+/* ---- measurement (role of TimingHelper, util.js:297-423) ------------------- */
+
+/* When enabled, each nb_step records HIP events around every force-kernel and
+ * integrate-kernel launch on the engine stream.  nb_kernel_times then blocks
+ * for them and returns the averages since the last call (milliseconds) and the
+ * number of launches averaged; it resets the accumulators. */
+int nb_enable_timing(nb_sim *s, int on);
+int nb_kernel_times(nb_sim *s, double *force_ms, double *integrate_ms,
+                    uint32_t *launches);
+
+/* Name of the force-kernel variant a handle resolved to (for reports), e.g.
+ * "f32_lds256_ipl2_js4".  Valid until nb_destroy. */
+const char *nb_variant_name(nb_sim *s);
+
+/* ---- on-device diagnostics (no reference analogue) ------- */
+
+/* out[0] = kinetic energy of this handle's shard (sum 1/2 m v^2),
+ * out[1] = potential energy share of this handle's shard
+ *          (-G/2 * sum_i sum_{j != i} m_i m_j / sqrt(r^2 + eps2), i in shard),
+ * out[2..4] = momentum of the shard.  Accumulated in fp64 on the device. */
+int nb_diagnostics(nb_sim *s, double out[5]);
+
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* NBODY3D_HIP_H */

@@ -1,0 +1,412 @@
+// nb_engine.hip -- C ABI (include/nbody3d_hip.h) over the HIP particle pool
+// and the two gfx950 kernels in nb_kernels.hip.h.
+//
+// Device state per handle (reference layout float4 AoS,
+// nbody3d.js:179-199, kept as-is on the device because one 16-B lane access is
+// the widest coalesced load and the j-tile is read back as one ds_read_b128):
+//   bodies  : 4*n elements, replicated on every shard (x, y, z, mass)
+//   vel     : 4*shard_count elements
+//   accel   : 4*shard_count elements (acceleration of the previous step)
+//   partial : jsplit * 4*shard_count elements (K1 output, summed by K2)
+#include "../../include/nbody3d_hip.h"
+#include "nb_kernels.hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_create_error = "";
+
+struct EventTriple { hipEvent_t e0, e1, e2; };
+
+}  // namespace
+
+struct nb_sim {
+    uint32_t n = 0, sb = 0, sc = 0;
+    bool f64 = false;
+    size_t esz = 4;
+    int device = 0;
+    double eps2 = 1e-4;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    void* bodies = nullptr;
+    bool own_bodies = false;
+    void* vel = nullptr;
+    void* acc = nullptr;
+    void* partial = nullptr;
+    double* diag = nullptr;
+    uint32_t diag_blocks = 0;
+    double dt = 0.0, G = 0.0;
+    bool params_set = false, uploaded = false;
+    int ipl = 1, ls = 1;
+    uint32_t jsplit = 1, j_per_split = 0;
+    std::string variant, err;
+    nb_exchange_fn xfn = nullptr;
+    void* xuser = nullptr;
+    bool timing = false;
+    std::vector<EventTriple> pool;   // recycled events
+    std::vector<EventTriple> pending;
+    size_t pool_next = 0;
+};
+
+namespace {
+
+int fail(nb_sim* s, int code, const std::string& msg)
+{
+    if (s) s->err = msg; else g_create_error = msg;
+    return code;
+}
+
+#define NB_HIP(s, call)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (call);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            return fail((s), NB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
+    } while (0)
+
+uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// Launch-shape heuristic.  Goal: >= ~4 waves per SIMD in flight chip-wide
+// (1024 SIMDs) so the VALU issue port is never starved by LDS/barrier latency
+// (one wave alone issues a VALU op only every 4 cycles, MI355X_MICROARCH.md
+// 'vector-instruction ISSUE cost'), while keeping >= 4 tiles per j-split.
+void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
+{
+    const uint32_t sc = s->sc, n = s->n;
+    int ipl, ls;
+    uint32_t variant = cfg.force_variant;
+    if (variant == 0) {
+        // auto: register-block when there are plenty of i-bodies, share a
+        // body between lanes when there are few
+        const uint64_t simds = (uint64_t)n_cu * 4;
+        if (sc >= simds * 64 * 2) variant = 2;         // IPL=2, LS=1
+        else if (sc >= simds * 16) variant = 1;        // IPL=1, LS=1
+        else if (sc >= simds * 2) variant = 14;        // LS=4
+        else if (sc >= simds / 4) variant = 116;       // LS=16
+        else variant = 164;                            // LS=64: a whole wave per body
+    }
+    switch (variant) {
+        case 1: ipl = 1; ls = 1; break;
+        case 2: ipl = 2; ls = 1; break;
+        case 4: ipl = 4; ls = 1; break;
+        case 14: ipl = 1; ls = 4; break;
+        case 116: ipl = 1; ls = 16; break;
+        case 164: ipl = 1; ls = 64; break;
+        default: ipl = 2; ls = 1; variant = 2; break;
+    }
+    s->ipl = ipl; s->ls = ls;
+    const uint32_t ipb = (nb::kBlock / ls) * ipl;
+    const uint32_t iblocks = ceil_div(sc, ipb);
+    uint32_t js = cfg.jsplit;
+    const uint32_t tiles = ceil_div(n, nb::kTile);
+    if (js == 0) {
+        const uint32_t want_blocks = (uint32_t)n_cu * 4;       // 4 blocks/CU = 4 waves/SIMD
+        js = ceil_div(want_blocks, iblocks);
+        const uint32_t max_js = tiles >= 4 ? tiles / 4 : 1;     // >= 4 tiles per split
+        if (js > max_js) js = max_js;
+        if (js > 64) js = 64;
+        if (js < 1) js = 1;
+    }
+    if (js > tiles) js = tiles ? tiles : 1;
+    s->jsplit = js;
+    s->j_per_split = ceil_div(tiles, js) * nb::kTile;
+    // a split may end up empty after rounding: shrink jsplit to what is used
+    s->jsplit = ceil_div(n, s->j_per_split);
+    char buf[96];
+    snprintf(buf, sizeof buf, "%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", nb::kTile, ipl, ls, s->jsplit);
+    s->variant = buf;
+}
+
+template <typename T>
+void launch_force(nb_sim* s)
+{
+    using V4 = typename nb::vec4<T>::type;
+    const uint32_t ipb = (nb::kBlock / s->ls) * s->ipl;
+    dim3 grid(ceil_div(s->sc, ipb), s->jsplit), block(nb::kBlock);
+    const V4* b = (const V4*)s->bodies;
+    V4* p = (V4*)s->partial;
+    const T G = (T)s->G, e2 = (T)s->eps2;
+#define NB_LAUNCH(IPL, LS)                                                                                      \
+    hipLaunchKernelGGL((nb::nb_force<T, IPL, LS>), grid, block, 0, s->stream, b, p, s->n, s->sb, s->sc, G, e2, \
+                       s->j_per_split)
+    if (s->ls == 1) {
+        if (s->ipl == 1) NB_LAUNCH(1, 1);
+        else if (s->ipl == 2) NB_LAUNCH(2, 1);
+        else NB_LAUNCH(4, 1);
+    } else if (s->ls == 4) NB_LAUNCH(1, 4);
+    else if (s->ls == 16) NB_LAUNCH(1, 16);
+    else NB_LAUNCH(1, 64);
+#undef NB_LAUNCH
+}
+
+template <typename T>
+void launch_integrate(nb_sim* s)
+{
+    using V4 = typename nb::vec4<T>::type;
+    dim3 grid(ceil_div(s->sc, nb::kBlock)), block(nb::kBlock);
+    hipLaunchKernelGGL((nb::nb_integrate<T>), grid, block, 0, s->stream, (V4*)s->bodies, (V4*)s->vel, (V4*)s->acc,
+                       (const V4*)s->partial, s->sb, s->sc, s->jsplit, (T)s->dt);
+}
+
+int get_events(nb_sim* s, EventTriple* out)
+{
+    if (s->pool_next == s->pool.size()) {
+        if (s->pool.size() >= 4096) return 1;   // stop recording, keep running
+        EventTriple t;
+        if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess ||
+            hipEventCreate(&t.e2) != hipSuccess)
+            return 1;
+        s->pool.push_back(t);
+    }
+    *out = s->pool[s->pool_next++];
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t nb_abi_version(void) { return NB_ABI_VERSION; }
+
+int nb_device_count(void)
+{
+    int c = 0;
+    if (hipGetDeviceCount(&c) != hipSuccess) return 0;
+    return c;
+}
+
+int nb_create(const nb_config* cfg_in, nb_sim** out)
+{
+    if (out) *out = nullptr;
+    if (!cfg_in || !out) return fail(nullptr, NB_ERR_INVALID, "nb_create: null argument");
+    if (cfg_in->struct_size < offsetof(nb_config, reserved))
+        return fail(nullptr, NB_ERR_INVALID, "nb_create: struct_size too small (set it to sizeof(nb_config))");
+    nb_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    memcpy(&cfg, cfg_in, cfg_in->struct_size < sizeof cfg ? cfg_in->struct_size : sizeof cfg);
+    if (cfg.n == 0) return fail(nullptr, NB_ERR_INVALID, "nb_create: n must be >= 1");
+    if (cfg.precision > NB_F64) return fail(nullptr, NB_ERR_INVALID, "nb_create: unknown precision");
+    if (cfg.tile != 0 && cfg.tile != (uint32_t)nb::kTile)
+        return fail(nullptr, NB_ERR_INVALID, "nb_create: only tile = 256 is built (reference TILE_SIZE)");
+    const double eps2 = cfg.eps2 == 0.0 ? 1e-4 : cfg.eps2;
+    if (!(eps2 >= 1e-12))
+        return fail(nullptr, NB_ERR_INVALID, "nb_create: eps2 must be >= 1e-12 (branch-free self term needs it)");
+    uint32_t sb = cfg.shard_begin, sc = cfg.shard_count;
+    if (sc == 0) { sb = 0; sc = cfg.n; }
+    if ((uint64_t)sb + sc > cfg.n) return fail(nullptr, NB_ERR_INVALID, "nb_create: shard exceeds n");
+
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(nullptr, NB_ERR_NO_DEVICE,
+                    std::string("nb_create: no HIP device (") + (e != hipSuccess ? hipGetErrorString(e) : "count = 0") +
+                        "); this engine has no CPU fallback");
+    int dev = cfg.device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= count) return fail(nullptr, NB_ERR_INVALID, "nb_create: device ordinal out of range");
+
+    nb_sim* s = new (std::nothrow) nb_sim;
+    if (!s) return fail(nullptr, NB_ERR_NOMEM, "nb_create: out of host memory");
+    s->n = cfg.n; s->sb = sb; s->sc = sc;
+    s->f64 = cfg.precision == NB_F64;
+    s->esz = s->f64 ? 8 : 4;
+    s->eps2 = eps2;
+    s->device = dev;
+
+    auto bail = [&](int code, const std::string& msg) {
+        std::string m = msg;
+        nb_destroy(s);
+        return fail(nullptr, code, m);
+    };
+#define NB_HIPC(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) return bail(NB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+    NB_HIPC(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    NB_HIPC(hipGetDeviceProperties(&prop, dev));
+    if (cfg.ext_stream || (cfg.flags & NB_FLAG_EXT_STREAM)) { s->stream = (hipStream_t)cfg.ext_stream; s->own_stream = false; }
+    else { NB_HIPC(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
+
+    choose_shape(s, cfg, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+
+    const size_t row = 4 * s->esz;
+    if (cfg.ext_bodies) { s->bodies = cfg.ext_bodies; s->own_bodies = false; }
+    else { NB_HIPC(hipMalloc(&s->bodies, row * s->n)); s->own_bodies = true; }
+    NB_HIPC(hipMalloc(&s->vel, row * s->sc));
+    NB_HIPC(hipMalloc(&s->acc, row * s->sc));
+    NB_HIPC(hipMalloc(&s->partial, row * s->sc * s->jsplit));
+    s->diag_blocks = ceil_div(s->sc, nb::kBlock);
+    NB_HIPC(hipMalloc((void**)&s->diag, sizeof(double) * 5 * s->diag_blocks));
+#undef NB_HIPC
+    *out = s;
+    return NB_OK;
+}
+
+void nb_destroy(nb_sim* s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    for (auto& t : s->pool) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
+    if (s->own_bodies && s->bodies) (void)hipFree(s->bodies);
+    if (s->vel) (void)hipFree(s->vel);
+    if (s->acc) (void)hipFree(s->acc);
+    if (s->partial) (void)hipFree(s->partial);
+    if (s->diag) (void)hipFree(s->diag);
+    if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+const char* nb_last_error(nb_sim* s) { return s ? s->err.c_str() : g_create_error.c_str(); }
+
+int nb_upload(nb_sim* s, const void* bodies, const void* vel, const void* accel)
+{
+    if (!s) return NB_ERR_INVALID;
+    if (!bodies || !vel) return fail(s, NB_ERR_INVALID, "nb_upload: bodies and vel are required");
+    NB_HIP(s, hipSetDevice(s->device));
+    const size_t row = 4 * s->esz;
+    // the reference's writeBuffer copies out of the typed array before returning
+    // (nbody3d.js:186,193): synchronous copies, host pointers are not retained
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    NB_HIP(s, hipMemcpy(s->bodies, bodies, row * s->n, hipMemcpyHostToDevice));
+    NB_HIP(s, hipMemcpy(s->vel, (const char*)vel + row * s->sb, row * s->sc, hipMemcpyHostToDevice));
+    if (accel) NB_HIP(s, hipMemcpy(s->acc, (const char*)accel + row * s->sb, row * s->sc, hipMemcpyHostToDevice));
+    else NB_HIP(s, hipMemset(s->acc, 0, row * s->sc));   // WebGPU zero-init, nbody3d.js:195-199
+    s->uploaded = true;
+    return NB_OK;
+}
+
+int nb_set_params(nb_sim* s, double dt, double G)
+{
+    if (!s) return NB_ERR_INVALID;
+    if (!(dt == dt) || !(G == G)) return fail(s, NB_ERR_INVALID, "nb_set_params: NaN");
+    s->dt = dt; s->G = G; s->params_set = true;
+    return NB_OK;
+}
+
+int nb_step(nb_sim* s, uint32_t nsteps)
+{
+    if (!s) return NB_ERR_INVALID;
+    if (!s->uploaded) return fail(s, NB_ERR_STATE, "nb_step: nb_upload has not been called");
+    if (!s->params_set) return fail(s, NB_ERR_STATE, "nb_step: nb_set_params has not been called");
+    if (!(s->dt > 0.0)) return NB_OK;   // `if (dt > 0)` gate, nbody3d.js:474
+    NB_HIP(s, hipSetDevice(s->device));
+    for (uint32_t k = 0; k < nsteps; ++k) {
+        EventTriple ev;
+        const bool rec = s->timing && get_events(s, &ev) == 0;
+        if (rec) NB_HIP(s, hipEventRecord(ev.e0, s->stream));
+        if (s->f64) launch_force<double>(s); else launch_force<float>(s);
+        if (rec) NB_HIP(s, hipEventRecord(ev.e1, s->stream));
+        if (s->f64) launch_integrate<double>(s); else launch_integrate<float>(s);
+        if (rec) { NB_HIP(s, hipEventRecord(ev.e2, s->stream)); s->pending.push_back(ev); }
+        NB_HIP(s, hipGetLastError());
+        if (s->xfn) {
+            int rc = s->xfn(s->xuser, s->bodies, s->esz, s->n, s->sb, s->sc, (void*)s->stream);
+            if (rc != 0) return fail(s, NB_ERR_COMM, "nb_step: exchange hook failed with code " + std::to_string(rc));
+        }
+    }
+    return NB_OK;
+}
+
+int nb_sync(nb_sim* s)
+{
+    if (!s) return NB_ERR_INVALID;
+    NB_HIP(s, hipSetDevice(s->device));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    return NB_OK;
+}
+
+int nb_download(nb_sim* s, void* bodies, void* vel, void* accel)
+{
+    if (!s) return NB_ERR_INVALID;
+    if (!s->uploaded) return fail(s, NB_ERR_STATE, "nb_download: nothing uploaded yet");
+    NB_HIP(s, hipSetDevice(s->device));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    const size_t row = 4 * s->esz;
+    if (bodies) NB_HIP(s, hipMemcpy(bodies, s->bodies, row * s->n, hipMemcpyDeviceToHost));
+    if (vel) NB_HIP(s, hipMemcpy((char*)vel + row * s->sb, s->vel, row * s->sc, hipMemcpyDeviceToHost));
+    if (accel) NB_HIP(s, hipMemcpy((char*)accel + row * s->sb, s->acc, row * s->sc, hipMemcpyDeviceToHost));
+    return NB_OK;
+}
+
+int nb_device_ptr(nb_sim* s, int which, void** out)
+{
+    if (!s || !out) return NB_ERR_INVALID;
+    switch (which) {
+        case NB_BODIES: *out = s->bodies; break;
+        case NB_VEL: *out = s->vel; break;
+        case NB_ACCEL: *out = s->acc; break;
+        default: return fail(s, NB_ERR_INVALID, "nb_device_ptr: unknown array");
+    }
+    return NB_OK;
+}
+
+int nb_set_exchange(nb_sim* s, nb_exchange_fn fn, void* user)
+{
+    if (!s) return NB_ERR_INVALID;
+    s->xfn = fn; s->xuser = user;
+    return NB_OK;
+}
+
+int nb_enable_timing(nb_sim* s, int on)
+{
+    if (!s) return NB_ERR_INVALID;
+    s->timing = on != 0;
+    return NB_OK;
+}
+
+int nb_kernel_times(nb_sim* s, double* force_ms, double* integrate_ms, uint32_t* launches)
+{
+    if (!s) return NB_ERR_INVALID;
+    NB_HIP(s, hipSetDevice(s->device));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    double f = 0, g = 0;
+    for (auto& ev : s->pending) {
+        float a = 0, b = 0;
+        NB_HIP(s, hipEventElapsedTime(&a, ev.e0, ev.e1));
+        NB_HIP(s, hipEventElapsedTime(&b, ev.e1, ev.e2));
+        f += a; g += b;
+    }
+    const uint32_t cnt = (uint32_t)s->pending.size();
+    if (force_ms) *force_ms = cnt ? f / cnt : 0.0;
+    if (integrate_ms) *integrate_ms = cnt ? g / cnt : 0.0;
+    if (launches) *launches = cnt;
+    s->pending.clear();
+    s->pool_next = 0;
+    return NB_OK;
+}
+
+const char* nb_variant_name(nb_sim* s) { return s ? s->variant.c_str() : ""; }
+
+int nb_diagnostics(nb_sim* s, double out[5])
+{
+    if (!s || !out) return NB_ERR_INVALID;
+    if (!s->uploaded) return fail(s, NB_ERR_STATE, "nb_diagnostics: nothing uploaded yet");
+    NB_HIP(s, hipSetDevice(s->device));
+    dim3 grid(s->diag_blocks), block(nb::kBlock);
+    if (s->f64)
+        hipLaunchKernelGGL((nb::nb_diag<double>), grid, block, 0, s->stream, (const double4*)s->bodies,
+                           (const double4*)s->vel, s->n, s->sb, s->sc, s->G, s->eps2, s->diag);
+    else
+        hipLaunchKernelGGL((nb::nb_diag<float>), grid, block, 0, s->stream, (const float4*)s->bodies,
+                           (const float4*)s->vel, s->n, s->sb, s->sc, s->G, s->eps2, s->diag);
+    NB_HIP(s, hipGetLastError());
+    std::vector<double> h((size_t)5 * s->diag_blocks);
+    NB_HIP(s, hipMemcpyAsync(h.data(), s->diag, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s->stream));
+    NB_HIP(s, hipStreamSynchronize(s->stream));
+    for (int q = 0; q < 5; ++q) out[q] = 0.0;
+    for (uint32_t b = 0; b < s->diag_blocks; ++b)
+        for (int q = 0; q < 5; ++q) out[q] += h[(size_t)b * 5 + q];
+    return NB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,236 @@
+// nb_kernels.hip.h -- device code of the MI355X (gfx950) direct N-body engine.
+//
+// Two kernels replace the reference's single WGSL compute pass
+// (/root/reference nbody3d.js:219-292):
+//
+//   K1 nb_force<T,IPL,LS>   tiled O(N^2) softened-gravity accumulation
+//                           (nbody3d.js:232-237 pair force, :255-272 tile loop)
+//   K2 nb_integrate<T>      the "velocity verlet with frame shift" update
+//                           (nbody3d.js:274-290)
+//
+// The split is what makes a step well defined: the reference writes positions
+// in place (:283) while other workgroups still stage them (:257); here K1 only
+// reads positions and K2 only runs after every K1 block has finished.
+//
+// CDNA4 mapping of K1 (wave = 64 lanes, 4 SIMDs/CU, 160 KiB LDS/CU):
+//   * a 256-thread workgroup (4 waves, one per SIMD) stages a 256-body j-tile
+//     (x, y, z, G*m) in LDS, double buffered, ONE s_barrier per tile; the next
+//     tile's global_load_dwordx4 is in flight while the current tile computes;
+//   * the inner loop reads the tile with ds_read_b128 at a wave-uniform address
+//     (LDS broadcast: one read feeds 64*IPL pair evaluations) -- LS == 1 -- or
+//     at LS consecutive addresses when LS lanes share one i-body (small N);
+//   * each lane keeps IPL i-bodies in VGPRs (register blocking: 1 LDS read per
+//     IPL*64 pairs), loaded with coalesced 16-B accesses (lane stride 16 B);
+//   * the pair body is 13 VALU instructions: 3 v_sub, 3 v_fma (r^2 + eps2),
+//     2 v_mul (cube), 1 v_rsq_f32, 1 v_mul (G*m_j), 3 v_fma (accumulate);
+//     no branch: with eps2 > 0 the self term is exactly 0*finite = 0 and
+//     bodies past N are staged as zero-mass;
+//   * when LS > 1 the LS partial sums of a body are reduced with wavefront
+//     shuffles (DPP row ops / ds_bpermute) before one lane stores;
+//   * grid = (i-blocks, jsplit): j is also partitioned over blockIdx.y so small
+//     i-counts (N = 65,536, or a 1/8 shard) still put >= 2 waves on every SIMD;
+//     K2 sums the jsplit partials in ascending order (deterministic, no atomics).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace nb {
+
+template <typename T> struct vec4;
+template <> struct vec4<float> { using type = float4; };
+template <> struct vec4<double> { using type = double4; };
+
+constexpr int kBlock = 256;  // threads per workgroup = reference TILE_SIZE (nbody3d.js:4,240)
+constexpr int kTile = 256;   // j-bodies per LDS tile (nbody3d.js:229)
+
+__device__ __forceinline__ float nb_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }  // bare v_rsq_f32 (1 ulp)
+__device__ __forceinline__ double nb_rsqrt(double x) { return rsqrt(x); }                 // v_rsq_f64 + Newton
+__device__ __forceinline__ float nb_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ double nb_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+// One pair: nbody3d.js:232-237 with b.w already multiplied by G at staging
+// time ((G*m)*inv is the reference's left-associated product, :236).
+template <typename T>
+__device__ __forceinline__ void pair(const T bx, const T by, const T bz, const T bgm, const T xi, const T yi, const T zi,
+                                     const T eps2, T& ax, T& ay, T& az)
+{
+    const T dx = bx - xi, dy = by - yi, dz = bz - zi;                  // :233
+    const T d2 = nb_fma(dz, dz, nb_fma(dy, dy, nb_fma(dx, dx, eps2)));  // :234 (contracted; WGSL permits it)
+    const T d6 = d2 * d2 * d2;                                         // :235
+    const T s = bgm * nb_rsqrt(d6);                                    // :235-236
+    ax = nb_fma(s, dx, ax);                                            // :266
+    ay = nb_fma(s, dy, ay);
+    az = nb_fma(s, dz, az);
+}
+
+// K1.  partial[by * i_count + il] = sum over this block's j-range.
+//   IPL: i-bodies per lane group; LS: lanes sharing one i-body (power of two, <= 64).
+template <typename T, int IPL, int LS>
+__global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type* __restrict__ bodies,
+                                                  typename vec4<T>::type* __restrict__ partial, uint32_t n,
+                                                  uint32_t i_begin, uint32_t i_count, T G, T eps2,
+                                                  uint32_t j_per_split)
+{
+    using V4 = typename vec4<T>::type;
+    static_assert(LS >= 1 && LS <= 64 && (LS & (LS - 1)) == 0, "LS must be a power of two <= 64");
+    constexpr int GROUPS = kBlock / LS;    // i-groups per block per k
+    constexpr int IPB = GROUPS * IPL;      // i-bodies per block
+    __shared__ V4 tile[2][kTile];
+
+    const int tid = threadIdx.x;
+    const int grp = tid / LS;
+    const int js = tid % LS;
+
+    T xi[IPL], yi[IPL], zi[IPL], ax[IPL], ay[IPL], az[IPL];
+#pragma unroll
+    for (int k = 0; k < IPL; ++k) {
+        const uint32_t il = blockIdx.x * IPB + k * GROUPS + grp;
+        V4 b = V4{0, 0, 0, 0};
+        if (il < i_count) b = bodies[i_begin + il];
+        xi[k] = b.x; yi[k] = b.y; zi[k] = b.z;
+        ax[k] = 0; ay[k] = 0; az[k] = 0;
+    }
+
+    const uint32_t j0 = blockIdx.y * j_per_split;
+    uint32_t j1 = j0 + j_per_split;
+    if (j1 > n) j1 = n;
+    const uint32_t ntiles = (j1 > j0) ? (j1 - j0 + kTile - 1) / kTile : 0;
+
+    auto stage = [&](uint32_t t) -> V4 {
+        const uint32_t j = j0 + t * kTile + tid;
+        V4 b = V4{0, 0, 0, 0};              // past the range: zero mass, contributes exactly 0
+        if (j < j1) { b = bodies[j]; b.w *= G; }
+        return b;
+    };
+
+    if (ntiles) tile[0][tid] = stage(0);
+    __syncthreads();
+
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        V4 nxt;
+        const bool more = (t + 1 < ntiles);
+        if (more) nxt = stage(t + 1);        // global load in flight under the tile's compute
+#pragma unroll 8
+        for (int jj = 0; jj < kTile / LS; ++jj) {
+            const V4 b = tile[cur][jj * LS + js];
+#pragma unroll
+            for (int k = 0; k < IPL; ++k) pair<T>(b.x, b.y, b.z, b.w, xi[k], yi[k], zi[k], eps2, ax[k], ay[k], az[k]);
+        }
+        if (more) tile[cur ^ 1][tid] = nxt;
+        __syncthreads();
+    }
+
+    // wavefront-shuffle reduction of the LS partial sums that share a body
+    if constexpr (LS > 1) {
+#pragma unroll
+        for (int k = 0; k < IPL; ++k) {
+#pragma unroll
+            for (int m = LS / 2; m >= 1; m >>= 1) {
+                ax[k] += __shfl_xor(ax[k], m, 64);
+                ay[k] += __shfl_xor(ay[k], m, 64);
+                az[k] += __shfl_xor(az[k], m, 64);
+            }
+        }
+    }
+    if (js == 0) {
+#pragma unroll
+        for (int k = 0; k < IPL; ++k) {
+            const uint32_t il = blockIdx.x * IPB + k * GROUPS + grp;
+            if (il < i_count) partial[(size_t)blockIdx.y * i_count + il] = V4{ax[k], ay[k], az[k], 0};
+        }
+    }
+}
+
+// K2.  nbody3d.js:274-290 on all four components (the .w lane is integrated
+// too, exactly as the reference does; mass stays constant because vel.w = 0).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_integrate(typename vec4<T>::type* __restrict__ bodies,
+                                                      typename vec4<T>::type* __restrict__ vel,
+                                                      typename vec4<T>::type* __restrict__ acc,
+                                                      const typename vec4<T>::type* __restrict__ partial,
+                                                      uint32_t i_begin, uint32_t i_count, uint32_t jsplit, T dt)
+{
+    using V4 = typename vec4<T>::type;
+    const uint32_t il = blockIdx.x * kBlock + threadIdx.x;
+    if (il >= i_count) return;
+    V4 a = partial[il];
+    for (uint32_t s = 1; s < jsplit; ++s) {
+        const V4 p = partial[(size_t)s * i_count + il];
+        a.x += p.x; a.y += p.y; a.z += p.z;
+    }
+    a.w = 0;                                                            // :274
+    const T h = dt * T(0.5);                                            // :276
+    const V4 ao = acc[il];
+    const V4 v = vel[il];
+    const V4 x = bodies[i_begin + il];
+    V4 nv, nx;
+    nv.x = nb_fma(ao.x + a.x, h, v.x);                                  // :280
+    nv.y = nb_fma(ao.y + a.y, h, v.y);
+    nv.z = nb_fma(ao.z + a.z, h, v.z);
+    nv.w = nb_fma(ao.w + a.w, h, v.w);
+    nx.x = nb_fma(nb_fma(h, a.x, nv.x), dt, x.x);                       // :283
+    nx.y = nb_fma(nb_fma(h, a.y, nv.y), dt, x.y);
+    nx.z = nb_fma(nb_fma(h, a.z, nv.z), dt, x.z);
+    nx.w = nb_fma(nb_fma(h, a.w, nv.w), dt, x.w);
+    vel[il] = nv;                                                       // :281
+    bodies[i_begin + il] = nx;                                          // :283
+    acc[il] = a;                                                        // :290
+}
+
+// Diagnostics (no reference analogue): per-block fp64 partial
+// sums of kinetic energy, momentum, and the shard's share of the softened
+// potential; finished on the host (a few hundred doubles).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_diag(const typename vec4<T>::type* __restrict__ bodies,
+                                                 const typename vec4<T>::type* __restrict__ vel, uint32_t n,
+                                                 uint32_t i_begin, uint32_t i_count, double G, double eps2,
+                                                 double* __restrict__ out /* [gridDim.x][5] */)
+{
+    using V4 = typename vec4<T>::type;
+    __shared__ V4 tile[kTile];
+    __shared__ double red[5][kBlock / 64];
+    const int tid = threadIdx.x;
+    const uint32_t il = blockIdx.x * kBlock + tid;
+    const bool valid = il < i_count;
+    V4 bi = V4{0, 0, 0, 0}, vi = V4{0, 0, 0, 0};
+    if (valid) { bi = bodies[i_begin + il]; vi = vel[il]; }
+    double pot = 0.0;
+    for (uint32_t j0 = 0; j0 < n; j0 += kTile) {
+        const uint32_t j = j0 + tid;
+        tile[tid] = (j < n) ? bodies[j] : V4{0, 0, 0, 0};
+        __syncthreads();
+        double p = 0.0;
+#pragma unroll 4
+        for (int jj = 0; jj < kTile; ++jj) {
+            const V4 b = tile[jj];
+            const double dx = (double)b.x - (double)bi.x, dy = (double)b.y - (double)bi.y, dz = (double)b.z - (double)bi.z;
+            const double r2 = dx * dx + dy * dy + dz * dz;
+            // exclude the self term exactly (j == i), keep everything else
+            const double w = (j0 + jj == i_begin + il) ? 0.0 : (double)b.w;
+            p += w * rsqrt(r2 + eps2);
+        }
+        pot += p;
+        __syncthreads();
+    }
+    double vals[5];
+    const double m = valid ? (double)bi.w : 0.0;
+    vals[0] = 0.5 * m * ((double)vi.x * vi.x + (double)vi.y * vi.y + (double)vi.z * vi.z);
+    vals[1] = valid ? -0.5 * G * m * pot : 0.0;
+    vals[2] = m * vi.x; vals[3] = m * vi.y; vals[4] = m * vi.z;
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+        double v = vals[q];
+#pragma unroll
+        for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+        if ((tid & 63) == 0) red[q][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < 5) {
+        double v = 0;
+        for (int w = 0; w < kBlock / 64; ++w) v += red[tid][w];
+        out[(size_t)blockIdx.x * 5 + tid] = v;
+    }
+}
+
+}  // namespace nb

@@ -1,0 +1,240 @@
+"""ctypes binding of include/nbody3d_hip.h.
+
+Mirrors the reference's host-side protocol for the hot path (file:line relative
+to /root/reference):
+
+    Simulation(n).init(bodies, vel)   nbody3d.js:177-199  (create + writeBuffer)
+    sim.step(dt)                      nbody3d.js:470,474-480,489-490
+    sim.simulate(k, dt)               k back-to-back frames of the above
+    sim.read()                        util.js:163-178     (exportSimulation copies)
+    sim.restore(bodies, vel, accel)   util.js:230-244     (importSimulation)
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.normpath(os.path.join(_PKG, "..", "csrc", "libnbody3d_hip.so"))
+
+NB_F32, NB_F64 = 0, 1
+NB_FLAG_EXT_STREAM = 1
+STATUS = {0: "NB_OK", 1: "NB_ERR_INVALID", 2: "NB_ERR_NO_DEVICE", 3: "NB_ERR_HIP",
+          4: "NB_ERR_STATE", 5: "NB_ERR_NOMEM", 6: "NB_ERR_COMM"}
+
+
+class NBodyError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("%s: %s" % (STATUS.get(code, code), msg))
+        self.code = code
+
+
+class nb_config(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("n", C.c_uint32), ("precision", C.c_uint32), ("tile", C.c_uint32),
+        ("eps2", C.c_double), ("device", C.c_int32), ("shard_begin", C.c_uint32), ("shard_count", C.c_uint32),
+        ("ext_stream", C.c_void_p), ("ext_bodies", C.c_void_p),
+        ("force_variant", C.c_uint32), ("jsplit", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32 * 5),
+    ]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
+
+# every symbol include/nbody3d_hip.h declares (tests check the export list)
+SYMBOLS = ["nb_abi_version", "nb_device_count", "nb_create", "nb_destroy", "nb_upload", "nb_set_params", "nb_step",
+           "nb_download", "nb_sync", "nb_last_error", "nb_device_ptr", "nb_set_exchange", "nb_enable_timing",
+           "nb_kernel_times", "nb_variant_name", "nb_diagnostics"]
+
+_lib = None
+
+
+def library_path():
+    return _LIB_PATH
+
+
+def load_library():
+    """Loads libnbody3d_hip.so; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB_PATH):
+        raise NBodyError(3, "HIP engine not built: %s is missing (run __graft_entry__.build() or "
+                            "make -C nbody3d-webgpu_amd/csrc)" % _LIB_PATH)
+    L = C.CDLL(_LIB_PATH)
+    vp = C.c_void_p
+    L.nb_abi_version.restype = C.c_uint32
+    L.nb_device_count.restype = C.c_int
+    L.nb_create.argtypes = [C.POINTER(nb_config), C.POINTER(vp)]
+    L.nb_destroy.argtypes = [vp]
+    L.nb_destroy.restype = None
+    L.nb_upload.argtypes = [vp, vp, vp, vp]
+    L.nb_set_params.argtypes = [vp, C.c_double, C.c_double]
+    L.nb_step.argtypes = [vp, C.c_uint32]
+    L.nb_download.argtypes = [vp, vp, vp, vp]
+    L.nb_sync.argtypes = [vp]
+    L.nb_last_error.argtypes = [vp]
+    L.nb_last_error.restype = C.c_char_p
+    L.nb_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.nb_set_exchange.argtypes = [vp, EXCHANGE_FN, vp]
+    L.nb_enable_timing.argtypes = [vp, C.c_int]
+    L.nb_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
+    L.nb_variant_name.argtypes = [vp]
+    L.nb_variant_name.restype = C.c_char_p
+    L.nb_diagnostics.argtypes = [vp, C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def abi_version():
+    return load_library().nb_abi_version()
+
+
+def device_count():
+    return load_library().nb_device_count()
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class Simulation:
+    """One engine handle = the reference's (bodyBuffer, velBuffer, accelBuffer,
+    uniforms, compute pipeline) bundle, nbody3d.js:13,179-204,296-311."""
+
+    def __init__(self, n, precision="f32", eps2=None, device=-1, shard=None, stream=None, ext_bodies=None,
+                 force_variant=0, jsplit=0, tile=0):
+        L = load_library()
+        self._L = L
+        self.n = int(n)
+        self.dtype = np.float64 if precision in ("f64", NB_F64, np.float64) else np.float32
+        cfg = nb_config()
+        cfg.struct_size = C.sizeof(nb_config)
+        cfg.n = self.n
+        cfg.precision = NB_F64 if self.dtype == np.float64 else NB_F32
+        cfg.tile = tile
+        cfg.eps2 = 0.0 if eps2 is None else float(eps2)
+        cfg.device = device
+        self.shard_begin, self.shard_count = (0, self.n) if shard is None else (int(shard[0]), int(shard[1]))
+        cfg.shard_begin, cfg.shard_count = self.shard_begin, self.shard_count
+        if stream is not None:
+            cfg.ext_stream = stream if stream else None
+            cfg.flags |= NB_FLAG_EXT_STREAM
+        if ext_bodies is not None:
+            cfg.ext_bodies = ext_bodies
+        cfg.force_variant = force_variant
+        cfg.jsplit = jsplit
+        h = C.c_void_p()
+        rc = L.nb_create(C.byref(cfg), C.byref(h))
+        if rc != 0:
+            raise NBodyError(rc, L.nb_last_error(None).decode())
+        self._h = h
+        self._hook = None
+        self.dt = 0.0
+        self.G = 0.0
+
+    # -- lifecycle ---------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nb_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NBodyError(rc, self._L.nb_last_error(self._h).decode())
+
+    def _arr(self, a, name):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.size != 4 * self.n:
+            raise ValueError("%s must hold 4*n = %d elements, got %d" % (name, 4 * self.n, a.size))
+        return a
+
+    # -- reference-shaped surface -------------------------------------------
+    def init(self, bodies, vel, accel=None):
+        """nbody3d.js:177-199: upload packed [x,y,z,m] / [vx,vy,vz,0]; accel zero."""
+        b = self._arr(bodies, "bodies")
+        v = self._arr(vel, "vel")
+        a = None if accel is None else self._arr(accel, "accel")
+        self._check(self._L.nb_upload(self._h, _ptr(b), _ptr(v), _ptr(a)))
+        return self
+
+    restore = init  # util.js:230-244 writes the same three arrays back
+
+    def set_params(self, dt, G):
+        self.dt, self.G = float(dt), float(G)
+        self._check(self._L.nb_set_params(self._h, self.dt, self.G))
+
+    def step(self, dt=None, G=None):
+        """One frame's compute pass (nbody3d.js:470-490); dt <= 0 is a no-op (:474)."""
+        if dt is not None or G is not None:
+            self.set_params(self.dt if dt is None else dt, self.G if G is None else G)
+        self._check(self._L.nb_step(self._h, 1))
+
+    def simulate(self, nsteps, dt=None, G=None):
+        if dt is not None or G is not None:
+            self.set_params(self.dt if dt is None else dt, self.G if G is None else G)
+        self._check(self._L.nb_step(self._h, int(nsteps)))
+
+    def sync(self):
+        self._check(self._L.nb_sync(self._h))
+
+    def read(self, bodies=True, vel=True, accel=True):
+        """util.js:163-178: fresh host copies of (bodies, vel, accel), shape (N,4).
+        On a shard handle vel/accel rows outside the shard are zero."""
+        out = [np.zeros((self.n, 4), self.dtype) if f else None for f in (bodies, vel, accel)]
+        self._check(self._L.nb_download(self._h, _ptr(out[0]), _ptr(out[1]), _ptr(out[2])))
+        return tuple(out)
+
+    # -- multi-GPU / measurement / diagnostics ------------------------------
+    def device_ptr(self, which):
+        p = C.c_void_p()
+        self._check(self._L.nb_device_ptr(self._h, {"bodies": 0, "vel": 1, "accel": 2}[which], C.byref(p)))
+        return p.value
+
+    def set_exchange(self, fn):
+        """fn(bodies_dev_ptr, elem_size, n, shard_begin, shard_count, stream) -> 0."""
+        if fn is None:
+            self._hook = None
+            self._check(self._L.nb_set_exchange(self._h, C.cast(None, EXCHANGE_FN), None))
+            return
+
+        def tramp(user, bodies, esz, n, sb, sc, stream):
+            try:
+                return int(fn(bodies, esz, n, sb, sc, stream) or 0)
+            except Exception:  # never unwind through the C frame
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        self._hook = EXCHANGE_FN(tramp)  # keep alive
+        self._check(self._L.nb_set_exchange(self._h, self._hook, None))
+
+    def enable_timing(self, on=True):
+        self._check(self._L.nb_enable_timing(self._h, 1 if on else 0))
+
+    def kernel_times(self):
+        """(avg force-kernel ms, avg integrate-kernel ms, launches) since last call."""
+        f, g, c = C.c_double(), C.c_double(), C.c_uint32()
+        self._check(self._L.nb_kernel_times(self._h, C.byref(f), C.byref(g), C.byref(c)))
+        return f.value, g.value, c.value
+
+    @property
+    def variant(self):
+        return self._L.nb_variant_name(self._h).decode()
+
+    def diagnostics(self):
+        """(kinetic, potential share, momentum[3]) of this handle's shard, fp64 on device."""
+        out = (C.c_double * 5)()
+        self._check(self._L.nb_diagnostics(self._h, out))
+        return out[0], out[1], np.array(out[2:5])

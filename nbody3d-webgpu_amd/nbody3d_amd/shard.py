@@ -1,0 +1,67 @@
+"""i-shard planning and the per-step position all-gather.
+
+The force pass shards over i-bodies: rank r of g owns a contiguous block of
+rows, holds the FULL replicated bodies array, and after its integrate kernel
+all ranks all-gather their rows.  One process per GPU; the collective goes
+through torch.distributed (backend "nccl" = RCCL over xGMI on GPUs, "gloo" in
+the CPU tests).  The reference has no multi-device code at all.
+"""
+import numpy as np
+
+ROW_ALIGN = 256  # keep shard boundaries on the reference's tile size (nbody3d.js:4)
+
+
+class ShardPlan:
+    """Contiguous, ROW_ALIGN-aligned i-blocks; the last rank takes the remainder.
+
+    Equal counts are required by all_gather_into_tensor; when n is not divisible
+    the plan pads: every rank owns ``rows`` rows of a padded array of
+    ``padded_n = rows * world`` bodies, and rows >= n are zero-mass bodies at the
+    origin that exert and feel no force (zero mass, finite distance).
+    """
+
+    def __init__(self, n, world, rank=0, align=ROW_ALIGN):
+        if world < 1 or not (0 <= rank < world):
+            raise ValueError("bad world/rank")
+        self.n, self.world, self.rank = int(n), int(world), int(rank)
+        per = -(-self.n // self.world)
+        per = -(-per // align) * align
+        self.rows = per
+        self.padded_n = per * self.world
+        self.begin = per * self.rank
+        self.count = per
+
+    def pad(self, a):
+        """(n,4) -> (padded_n,4) with zero rows appended."""
+        a = np.asarray(a).reshape(-1, 4)
+        if a.shape[0] == self.padded_n:
+            return np.ascontiguousarray(a)
+        out = np.zeros((self.padded_n, 4), a.dtype)
+        out[: a.shape[0]] = a
+        return out
+
+    def pairs_per_step(self):
+        """Real pair interactions of one step of the whole job: N(N-1)."""
+        return self.n * (self.n - 1)
+
+
+def torch_allgather_hook(bodies_tensor, plan, group=None):
+    """Exchange hook for Simulation.set_exchange: in-place all-gather of each
+    rank's rows of ``bodies_tensor`` (shape (padded_n, 4), the tensor whose
+    storage the engine uses as its replicated bodies array).
+
+    The engine enqueues its kernels on torch's current stream (it is created
+    with stream=torch.cuda.current_stream().cuda_stream), so the collective --
+    which torch orders after the current stream and makes the current stream
+    wait for -- is correctly ordered against the integrate kernel before it and
+    the next step's force kernel after it.
+    """
+    import torch.distributed as dist
+
+    mine = bodies_tensor[plan.begin: plan.begin + plan.count]
+
+    def hook(bodies_ptr, esz, n, sb, sc, stream):
+        dist.all_gather_into_tensor(bodies_tensor, mine, group=group)
+        return 0
+
+    return hook

@@ -1,0 +1,60 @@
+"""No-GPU checks of the C-ABI library: it loads, exports every symbol the
+header declares, and fails loudly (no CPU fallback) when there is no device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from conftest import ROOT, have_gpu
+from nbody3d_amd import capi
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "nbody3d_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(nb_[a-z_]+)\s*\(", src)) - {"nb_exchange_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    L = capi.load_library()
+    syms = header_symbols()
+    assert sorted(capi.SYMBOLS) == syms
+    for s in syms:
+        assert hasattr(L, s), s
+
+
+def test_abi_version_and_config_layout():
+    assert capi.abi_version() == 1
+    # layout must match the C struct: 4*4 + 8 + 3*4 (+4 pad) + 2*8 + 3*4 + 5*4 = 88
+    assert C.sizeof(capi.nb_config) == 88
+
+
+def test_bad_config_is_rejected_without_touching_a_device():
+    L = capi.load_library()
+    h = C.c_void_p()
+    cfg = capi.nb_config()
+    cfg.struct_size = C.sizeof(capi.nb_config)
+    cfg.n = 0
+    assert L.nb_create(C.byref(cfg), C.byref(h)) == 1 and not h.value
+    assert b"n must be" in L.nb_last_error(None)
+    cfg.n = 16
+    cfg.eps2 = -1.0
+    assert L.nb_create(C.byref(cfg), C.byref(h)) == 1
+    cfg.eps2 = 0.0
+    cfg.shard_begin, cfg.shard_count = 10, 10
+    assert L.nb_create(C.byref(cfg), C.byref(h)) == 1
+    cfg.struct_size = 8
+    assert L.nb_create(C.byref(cfg), C.byref(h)) == 1
+    assert L.nb_step(None, 1) == 1 and L.nb_sync(None) == 1
+    L.nb_destroy(None)  # no-op
+
+
+@pytest.mark.skipif(have_gpu(), reason="checks the no-device error path")
+def test_no_device_is_an_ordinary_error_not_a_fallback():
+    """Reference: alert + return when WebGPU is missing (nbody3d.js:151-155).
+    Here: NB_ERR_NO_DEVICE and an exception; nothing computes on the CPU."""
+    assert capi.device_count() == 0
+    with pytest.raises(capi.NBodyError) as e:
+        capi.Simulation(1024)
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)

@@ -1,0 +1,272 @@
+"""GPU parity tests: the HIP engine, called through the C ABI, against the
+oracle and the committed golden vectors.  Tolerances are stated here.
+
+  TOL_POS   = 1e-4  BASELINE.json: "positions within 1e-4 rel of reference after
+                    100 steps" (metric: conftest.rel_pos_err)
+  TOL_TIGHT = 2e-5  what we actually hold the f32 engine to against the fp64
+                    oracle (the fp32 oracle itself sits at ~9e-7; the engine
+                    differs from it by fma contraction, v_rsq_f32 (1 ulp) and
+                    the j-split summation order)
+  TOL_ACC   = 2e-5  single force evaluation, relative to max |a|
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden32, load_golden64, rel_pos_err
+from oracle import oracle
+from nbody3d_amd import Simulation, ic
+
+pytestmark = pytest.mark.gpu
+
+TOL_POS, TOL_TIGHT, TOL_ACC = 1e-4, 2e-5, 2e-5
+
+# (force_variant, jsplit): every kernel instantiation, with and without a j-split
+VARIANTS = [(0, 0), (1, 1), (1, 3), (2, 1), (2, 2), (4, 1), (4, 4), (14, 1), (14, 2), (116, 1), (164, 1), (164, 2)]
+
+
+def run_engine(b, v, dt, G, steps, a=None, **kw):
+    with Simulation(b.shape[0], **kw) as sim:
+        sim.init(b, v, a)
+        sim.simulate(steps, dt, G)
+        out = sim.read()
+        name = sim.variant
+    return out + (name,)
+
+
+@pytest.mark.parametrize("variant,jsplit", VARIANTS)
+def test_single_step_matches_oracle_acceleration(variant, jsplit):
+    """accel after one call == oracle accelerations of the initial positions."""
+    b, v = ic.plummer(2048, seed=11)
+    bb, vv, aa, name = run_engine(b, v, 1e-3, 1.0, 1, force_variant=variant, jsplit=jsplit)
+    ref = oracle.accel_f64(b, 1.0)
+    scale = np.abs(ref[:, :3]).max()
+    err = np.abs(aa[:, :3] - ref[:, :3]).max() / scale
+    assert err < TOL_ACC, (name, err)
+    assert np.all(aa[:, 3] == 0) and np.all(vv[:, 3] == 0)
+    assert np.array_equal(bb[:, 3], b[:, 3])           # masses untouched
+    # and the integrator: same update applied to the engine's own accelerations
+    b2, v2, a2 = oracle.run_f32(b, v, None, 1e-3, 1.0, 1)
+    assert rel_pos_err(bb, b2, 1.0) < 1e-6
+    assert np.abs(vv - v2).max() < 1e-5 * np.abs(v2).max() + 1e-7
+
+
+@pytest.mark.parametrize("name,steps", [("plummer1024", 100), ("cube1000", 20), ("disk771", 50)])
+@pytest.mark.parametrize("variant,jsplit", [(0, 0), (2, 1), (1, 2), (164, 1)])
+def test_golden_trajectories(manifest, name, steps, variant, jsplit):
+    """BASELINE.json config 1 (Plummer N=1024, dt=1e-3, 100 steps) and the
+    ragged-N / harsh-mass-ratio fixtures, against fp64 and fp32 oracle vectors."""
+    m = manifest[name]
+    b0, v0 = load_golden32(name + "_bodies0"), load_golden32(name + "_vel0")
+    bb, vv, aa, vname = run_engine(b0, v0, m["dt"], m["G"], steps, force_variant=variant, jsplit=jsplit)
+    ref64 = load_golden64("%s_s%d_bodies" % (name, steps))
+    ref32 = load_golden32("%s_s%d_bodies" % (name, steps))
+    e64 = rel_pos_err(bb, ref64, m["r_scale"])
+    e32 = rel_pos_err(bb, ref32, m["r_scale"])
+    assert e64 < TOL_TIGHT < TOL_POS, (vname, e64)
+    assert e32 < TOL_TIGHT, (vname, e32)
+    a32 = load_golden32("%s_s%d_accel" % (name, steps))
+    assert np.abs(aa[:, :3] - a32[:, :3]).max() < 1e-4 * np.abs(a32[:, :3]).max()
+    v32 = load_golden32("%s_s%d_vel" % (name, steps))
+    assert np.abs(vv[:, :3] - v32[:, :3]).max() < 1e-4 * np.abs(v32[:, :3]).max()
+
+
+def test_intermediate_checkpoints_and_restore(manifest):
+    """read() then restore() mid-run (util.js:163-178 / :230-244 round trip)
+    continues exactly as an uninterrupted run."""
+    m = manifest["plummer1024"]
+    b0, v0 = load_golden32("plummer1024_bodies0"), load_golden32("plummer1024_vel0")
+    with Simulation(1024) as sim:
+        sim.init(b0, v0)
+        sim.simulate(10, m["dt"], m["G"])
+        b10, v10, a10 = sim.read()
+        assert rel_pos_err(b10, load_golden32("plummer1024_s10_bodies"), m["r_scale"]) < 1e-6
+        sim.simulate(15)
+        straight = sim.read()
+    with Simulation(1024) as sim2:
+        sim2.restore(b10, v10, a10)
+        sim2.simulate(15, m["dt"], m["G"])
+        resumed = sim2.read()
+    for x, y in zip(straight, resumed):
+        assert x.tobytes() == y.tobytes()
+
+
+def test_dt_zero_and_negative_are_noops():
+    """`if (dt > 0)` gate, nbody3d.js:474: state stays bit-identical."""
+    b, v = ic.plummer(512, seed=12)
+    a = np.random.default_rng(0).random((512, 4)).astype(np.float32)
+    with Simulation(512) as sim:
+        sim.init(b, v, a)
+        sim.simulate(3, 0.0, 1.0)
+        sim.step(-1e-3)
+        bb, vv, aa = sim.read()
+    assert bb.tobytes() == b.tobytes() and vv.tobytes() == v.tobytes() and aa.tobytes() == a.tobytes()
+
+
+def test_first_step_uses_zero_accel_when_none_uploaded():
+    """accelBuffer starts zeroed (nbody3d.js:195-199): vel_1 = v0 + dt/2 * a0."""
+    b, v = ic.uniform_cube(768, seed=13)
+    bb, vv, aa, _ = run_engine(b, v, 1e-2, 1.0, 1)
+    exp = v[:, :3] + 0.5 * 1e-2 * aa[:, :3]
+    assert np.abs(vv[:, :3] - exp).max() < 1e-6 * max(np.abs(exp).max(), 1e-3)
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 255, 257, 1000, 4099])
+def test_ragged_sizes(n):
+    """N not a multiple of 64/256 (the reference is undefined there, SURVEY.md
+    §3.4); here it is bounds-guarded.  N=1: no pairs, body drifts freely."""
+    rng = np.random.default_rng(n)
+    b = np.zeros((n, 4), np.float32)
+    b[:, :3] = rng.random((n, 3)) * 2 - 1
+    b[:, 3] = rng.random(n) + 0.5
+    v = np.zeros((n, 4), np.float32)
+    v[:, :3] = rng.random((n, 3)) - 0.5
+    bb, vv, aa, name = run_engine(b, v, 1e-3, 0.01, 3)
+    rb, rv, ra = oracle.run_f32(b, v, None, 1e-3, 0.01, 3)
+    assert rel_pos_err(bb, rb, 1.0) < 1e-6, name
+    assert np.abs(aa - ra).max() <= 2e-5 * max(np.abs(ra).max(), 1e-30), name
+
+
+def test_coincident_bodies_and_zero_mass():
+    """Self term / coincident pairs contribute exactly 0 (eps2 > 0); zero-mass
+    bodies exert nothing but still move."""
+    b = np.zeros((256, 4), np.float32)
+    b[:128, 3] = 1.0                       # 128 massive bodies all at the origin
+    b[128:, 0] = np.linspace(1, 2, 128)    # 128 massless tracers
+    v = np.zeros((256, 4), np.float32)
+    bb, vv, aa, _ = run_engine(b, v, 1e-3, 1.0, 1)
+    assert np.all(aa[:128] == 0)           # coincident: exactly zero
+    ref = oracle.accel_f64(b, 1.0)
+    assert np.allclose(aa[128:, :3], ref[128:, :3], rtol=2e-5, atol=1e-7)
+
+
+def test_newton_third_law_on_device():
+    b, v = ic.plummer(4096, seed=14)
+    _, _, aa, _ = run_engine(b, v, 1e-3, 1.0, 1)
+    f = (b[:, 3:4].astype(np.float64) * aa[:, :3]).sum(0)
+    scale = np.abs(b[:, 3:4] * aa[:, :3]).sum(0)
+    assert np.all(np.abs(f) < 2e-6 * scale)
+
+
+def test_shards_on_one_device_compose_to_the_single_handle_result():
+    """SURVEY.md §8(e) 'virtual shard' check: g handles on ONE GPU, each owning
+    an i-block, host-side gather of rows between steps == one unsharded handle
+    (bit for bit when the launch shape is pinned)."""
+    n, g, steps = 2048, 4, 5
+    b, v = ic.plummer(n, seed=15)
+    kw = dict(force_variant=1, jsplit=2)
+    with Simulation(n, **kw) as one:
+        one.init(b, v)
+        one.simulate(steps, 1e-3, 1.0)
+        ref = one.read()
+    per = n // g
+    sims = [Simulation(n, shard=(r * per, per), **kw) for r in range(g)]
+    try:
+        for s in sims:
+            s.init(b, v)
+            s.set_params(1e-3, 1.0)
+        bodies = b.copy()
+        for _ in range(steps):
+            rows = []
+            for r, s in enumerate(sims):
+                s.step()
+                rows.append(s.read(vel=False, accel=False)[0][r * per:(r + 1) * per])
+            bodies = np.concatenate(rows)
+            for r, s in enumerate(sims):
+                bb, vv, aa = s.read()
+                s.restore(bodies, vv, aa)
+        vel = np.zeros((n, 4), np.float32)
+        acc = np.zeros((n, 4), np.float32)
+        for r, s in enumerate(sims):
+            _, vv, aa = s.read()
+            vel[r * per:(r + 1) * per] = vv[r * per:(r + 1) * per]
+            acc[r * per:(r + 1) * per] = aa[r * per:(r + 1) * per]
+    finally:
+        for s in sims:
+            s.close()
+    assert bodies.tobytes() == ref[0].tobytes()
+    assert vel.tobytes() == ref[1].tobytes() and acc.tobytes() == ref[2].tobytes()
+
+
+def test_exchange_hook_is_called_once_per_step():
+    b, v = ic.plummer(512, seed=16)
+    calls = []
+    with Simulation(512, shard=(0, 256)) as sim:
+        sim.init(b, v)
+        sim.set_exchange(lambda ptr, esz, n, sb, sc, stream: calls.append((esz, n, sb, sc)) or 0)
+        sim.simulate(4, 1e-3, 1.0)
+        sim.sync()
+        assert calls == [(4, 512, 0, 256)] * 4
+        sim.set_exchange(lambda *a: 7)
+        with pytest.raises(Exception) as e:
+            sim.step()
+        assert "NB_ERR_COMM" in str(e.value)
+
+
+def test_f64_engine_matches_f64_oracle(manifest):
+    """BASELINE.json config 5 (fp64 variant): same trajectory as the fp64 oracle."""
+    m = manifest["plummer1024"]
+    b0 = load_golden32("plummer1024_bodies0").astype(np.float64)
+    v0 = load_golden32("plummer1024_vel0").astype(np.float64)
+    bb, vv, aa, name = run_engine(b0, v0, m["dt"], m["G"], 100, precision="f64")
+    assert bb.dtype == np.float64
+    assert rel_pos_err(bb, load_golden64("plummer1024_s100_bodies"), m["r_scale"]) < 1e-12, name
+
+
+def test_diagnostics_match_host_energy():
+    b, v = ic.plummer(3000, seed=17)
+    with Simulation(3000) as sim:
+        sim.init(b, v)
+        sim.set_params(1e-3, 1.0)
+        ke, pe, mom = sim.diagnostics()
+    rke, rpe, rmom = oracle.energy(b, v, 1.0)
+    assert abs(ke - rke) < 1e-9 * abs(rke) and abs(pe - rpe) < 1e-6 * abs(rpe)
+    assert np.abs(mom - rmom).max() < 1e-9
+
+
+def test_energy_drift_reported_and_small(manifest):
+    """Energy bookkeeping of SURVEY.md §8(c): KE(vel after call n) with
+    PE(positions before call n)."""
+    m = manifest["plummer1024"]
+    b0, v0 = load_golden32("plummer1024_bodies0"), load_golden32("plummer1024_vel0")
+    ke0, pe0, _ = oracle.energy(b0, v0, m["G"])
+    with Simulation(1024) as sim:
+        sim.init(b0, v0)
+        sim.simulate(99, m["dt"], m["G"])
+        bprev = sim.read()[0]
+        sim.step()
+        _, vk, _ = sim.read()
+    ke, _, _ = oracle.energy(bprev, vk, m["G"])
+    _, pe, _ = oracle.energy(bprev, vk, m["G"])
+    drift = abs((ke + pe - (ke0 + pe0)) / (ke0 + pe0))
+    assert drift < 5 * m["energy_drift"]["f64"] + 1e-6
+
+
+@pytest.mark.parametrize("n", [65536, 262144])
+def test_full_size_properties(n):
+    """BASELINE.json configs 2 and 3 at full size, through size-independent
+    properties (the oracle would take minutes): a sampled i-slice against the
+    fp64 oracle, Newton's third law, and shard-composition (row blocks of a
+    1/8 shard handle equal the full handle's rows)."""
+    b, v = (ic.uniform_cube(n, seed=2) if n == 65536 else ic.plummer(n, seed=1))
+    with Simulation(n) as sim:
+        sim.init(b, v)
+        sim.simulate(1, 1e-3, 1.0)
+        bb, vv, aa = sim.read()
+        name = sim.variant
+    rows = np.random.default_rng(0).choice(n, 96, replace=False)
+    rows.sort()
+    b64 = b.astype(np.float64)
+    for i in rows[:: 96 // 24]:
+        ref = oracle.accel_f64(b64, 1.0, i0=int(i), i1=int(i) + 1)[0, :3]
+        assert np.abs(aa[i, :3] - ref).max() < TOL_ACC * max(np.abs(ref).max(), 1e-3), (name, i)
+    f = (b[:, 3:4].astype(np.float64) * aa[:, :3]).sum(0)
+    assert np.all(np.abs(f) < 1e-5 * np.abs(b[:, 3:4] * aa[:, :3]).sum(0))
+    per = n // 8
+    with Simulation(n, shard=(3 * per, per)) as sh:
+        sh.init(b, v)
+        sh.simulate(1, 1e-3, 1.0)
+        sb, sv, sa = sh.read()
+        sname = sh.variant
+    blk = slice(3 * per, 4 * per)
+    assert rel_pos_err(sb[blk], bb[blk], 1.0) < 1e-6, sname
+    assert np.abs(sa[blk] - aa[blk]).max() < TOL_ACC * np.abs(aa[blk]).max(), sname
