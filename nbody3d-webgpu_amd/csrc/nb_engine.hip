@@ -17,6 +17,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace {
@@ -45,6 +46,7 @@ struct nb_sim {
     double dt = 0.0, G = 0.0;
     bool params_set = false, uploaded = false;
     int ipl = 1, ls = 1;
+    bool packed = false;   // nb_force_pk (f32 only)
     uint32_t jsplit = 1, j_per_split = 0;
     std::string variant, err;
     nb_exchange_fn xfn = nullptr;
@@ -72,24 +74,35 @@ int fail(nb_sim* s, int code, const std::string& msg)
 
 uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// Launch-shape heuristic.  Goal: >= ~4 waves per SIMD in flight chip-wide
-// (1024 SIMDs) so the VALU issue port is never starved by LDS/barrier latency
-// (one wave alone issues a VALU op only every 4 cycles, MI355X_MICROARCH.md
-// 'vector-instruction ISSUE cost'), while keeping >= 4 tiles per j-split.
+// Launch-shape heuristic (measured: profiles/r01/sweep_*.txt).
+//   * f32 uses the packed kernel; 8 i-bodies per lane (4 packed groups) when
+//     the shard has enough rows to make >= 16 i-blocks, else 4 or 2 per lane;
+//     fewer rows than that: the scalar kernel with LS lanes per body.
+//   * j is split over blockIdx.y until the grid has ~4096 workgroups (the
+//     118-VGPR packed kernel keeps 4 waves per SIMD = 1024 workgroups resident,
+//     so 4 rounds: short blocks even out DVFS/tail imbalance; +4 % over 1024),
+//     keeping >= 4 tiles per split and <= 64 splits.
 void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
 {
     const uint32_t sc = s->sc, n = s->n;
     int ipl, ls;
+    bool pk = false;
     uint32_t variant = cfg.force_variant;
     if (variant == 0) {
-        // auto: register-block when there are plenty of i-bodies, share a
-        // body between lanes when there are few
-        const uint64_t simds = (uint64_t)n_cu * 4;
-        if (sc >= simds * 64 * 2) variant = 2;         // IPL=2, LS=1
-        else if (sc >= simds * 16) variant = 1;        // IPL=1, LS=1
-        else if (sc >= simds * 2) variant = 14;        // LS=4
-        else if (sc >= simds / 4) variant = 116;       // LS=16
-        else variant = 164;                            // LS=64: a whole wave per body
+        if (!s->f64) {
+            if (sc >= 16u * 2048) variant = 28;        // packed, IPL=8
+            else if (sc >= 16u * 1024) variant = 24;   // packed, IPL=4
+            else if (sc >= 4096) variant = 22;         // packed, IPL=2
+            else if (sc >= 1024) variant = 14;         // LS=4
+            else if (sc >= 256) variant = 116;         // LS=16
+            else variant = 164;                        // LS=64: a whole wave per body
+        } else {
+            if (sc >= 16u * 512) variant = 2;
+            else if (sc >= 4096) variant = 1;
+            else if (sc >= 1024) variant = 14;
+            else if (sc >= 256) variant = 116;
+            else variant = 164;
+        }
     }
     switch (variant) {
         case 1: ipl = 1; ls = 1; break;
@@ -98,15 +111,19 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         case 14: ipl = 1; ls = 4; break;
         case 116: ipl = 1; ls = 16; break;
         case 164: ipl = 1; ls = 64; break;
+        case 22: ipl = 2; ls = 1; pk = true; break;    // packed across 2 i-bodies
+        case 24: ipl = 4; ls = 1; pk = true; break;
+        case 28: ipl = 8; ls = 1; pk = true; break;
         default: ipl = 2; ls = 1; variant = 2; break;
     }
-    s->ipl = ipl; s->ls = ls;
+    if (s->f64) pk = false;
+    s->ipl = ipl; s->ls = ls; s->packed = pk;
     const uint32_t ipb = (nb::kBlock / ls) * ipl;
     const uint32_t iblocks = ceil_div(sc, ipb);
     uint32_t js = cfg.jsplit;
     const uint32_t tiles = ceil_div(n, nb::kTile);
     if (js == 0) {
-        const uint32_t want_blocks = (uint32_t)n_cu * 4;       // 4 blocks/CU = 4 waves/SIMD
+        const uint32_t want_blocks = (uint32_t)n_cu * 16;
         js = ceil_div(want_blocks, iblocks);
         const uint32_t max_js = tiles >= 4 ? tiles / 4 : 1;     // >= 4 tiles per split
         if (js > max_js) js = max_js;
@@ -119,7 +136,8 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
     // a split may end up empty after rounding: shrink jsplit to what is used
     s->jsplit = ceil_div(n, s->j_per_split);
     char buf[96];
-    snprintf(buf, sizeof buf, "%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", nb::kTile, ipl, ls, s->jsplit);
+    snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", pk ? "pk" : "", nb::kTile, ipl, ls,
+             s->jsplit);
     s->variant = buf;
 }
 
@@ -132,6 +150,18 @@ void launch_force(nb_sim* s)
     const V4* b = (const V4*)s->bodies;
     V4* p = (V4*)s->partial;
     const T G = (T)s->G, e2 = (T)s->eps2;
+    if constexpr (std::is_same<T, float>::value) {
+        if (s->packed) {
+#define NB_LAUNCH_PK(NG)                                                                                            \
+    hipLaunchKernelGGL((nb::nb_force_pk<NG, 1>), grid, block, 0, s->stream, b, p, s->n, s->sb, s->sc, G, e2,       \
+                       s->j_per_split)
+            if (s->ipl == 2) NB_LAUNCH_PK(1);
+            else if (s->ipl == 4) NB_LAUNCH_PK(2);
+            else NB_LAUNCH_PK(4);
+#undef NB_LAUNCH_PK
+            return;
+        }
+    }
 #define NB_LAUNCH(IPL, LS)                                                                                      \
     hipLaunchKernelGGL((nb::nb_force<T, IPL, LS>), grid, block, 0, s->stream, b, p, s->n, s->sb, s->sc, G, e2, \
                        s->j_per_split)

@@ -142,6 +142,110 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
     }
 }
 
+// K1, packed form (f32 only).  Same algorithm as nb_force<float,...>, but the
+// arithmetic is vectorised ACROSS TWO i-BODIES of the lane with the CDNA packed
+// f32 instructions (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32: two f32 lanes
+// per VGPR pair).  Measured on MI355X (profiles/r01/ubench_run1.txt): a wave
+// issues one VALU op per 4 cycles whether it is packed or not, so the packed
+// body (12 v_pk + 2 v_rsq per TWO pairs instead of 24 + 2) sustains ~25 % more
+// pairs/s than the scalar body at the same occupancy.  The j-body needs no
+// shuffles: the ds_read_b128 result quad (x,y | z,m) feeds the packed ops
+// through op_sel (lo/hi broadcast), which the backend folds from the splats.
+//   NG = packed groups per lane -> IPL = 2*NG i-bodies per lane.
+typedef float nb_f2 __attribute__((ext_vector_type(2)));
+
+template <int NG, int LS>
+__global__ __launch_bounds__(kBlock) void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial,
+                                                     uint32_t n, uint32_t i_begin, uint32_t i_count, float G,
+                                                     float eps2, uint32_t j_per_split)
+{
+    static_assert(LS >= 1 && LS <= 64 && (LS & (LS - 1)) == 0, "LS must be a power of two <= 64");
+    constexpr int IPL = 2 * NG;
+    constexpr int GROUPS = kBlock / LS;
+    constexpr int IPB = GROUPS * IPL;
+    __shared__ float4 tile[2][kTile];
+
+    const int tid = threadIdx.x;
+    const int grp = tid / LS;
+    const int js = tid % LS;
+
+    nb_f2 xi[NG], yi[NG], zi[NG], ax[NG], ay[NG], az[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        float4 b0 = float4{0, 0, 0, 0}, b1 = float4{0, 0, 0, 0};
+        const uint32_t il0 = blockIdx.x * IPB + (2 * g) * GROUPS + grp;
+        const uint32_t il1 = il0 + GROUPS;
+        if (il0 < i_count) b0 = bodies[i_begin + il0];
+        if (il1 < i_count) b1 = bodies[i_begin + il1];
+        xi[g] = nb_f2{b0.x, b1.x}; yi[g] = nb_f2{b0.y, b1.y}; zi[g] = nb_f2{b0.z, b1.z};
+        ax[g] = nb_f2{0, 0}; ay[g] = nb_f2{0, 0}; az[g] = nb_f2{0, 0};
+    }
+    const nb_f2 e2 = nb_f2{eps2, eps2};
+
+    const uint32_t j0 = blockIdx.y * j_per_split;
+    uint32_t j1 = j0 + j_per_split;
+    if (j1 > n) j1 = n;
+    const uint32_t ntiles = (j1 > j0) ? (j1 - j0 + kTile - 1) / kTile : 0;
+
+    auto stage = [&](uint32_t t) -> float4 {
+        const uint32_t j = j0 + t * kTile + tid;
+        float4 b = float4{0, 0, 0, 0};
+        if (j < j1) { b = bodies[j]; b.w *= G; }
+        return b;
+    };
+
+    if (ntiles) tile[0][tid] = stage(0);
+    __syncthreads();
+
+    for (uint32_t t = 0; t < ntiles; ++t) {
+        const int cur = t & 1;
+        float4 nxt;
+        const bool more = (t + 1 < ntiles);
+        if (more) nxt = stage(t + 1);
+#pragma unroll 8
+        for (int jj = 0; jj < kTile / LS; ++jj) {
+            const float4 b = tile[cur][jj * LS + js];
+            const nb_f2 bx = nb_f2{b.x, b.x}, by = nb_f2{b.y, b.y}, bz = nb_f2{b.z, b.z}, bm = nb_f2{b.w, b.w};
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const nb_f2 dx = bx - xi[g], dy = by - yi[g], dz = bz - zi[g];
+                const nb_f2 d2 = __builtin_elementwise_fma(
+                    dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
+                const nb_f2 d6 = d2 * d2 * d2;
+                const nb_f2 r = nb_f2{__builtin_amdgcn_rsqf(d6.x), __builtin_amdgcn_rsqf(d6.y)};
+                const nb_f2 s = bm * r;
+                ax[g] = __builtin_elementwise_fma(s, dx, ax[g]);
+                ay[g] = __builtin_elementwise_fma(s, dy, ay[g]);
+                az[g] = __builtin_elementwise_fma(s, dz, az[g]);
+            }
+        }
+        if (more) tile[cur ^ 1][tid] = nxt;
+        __syncthreads();
+    }
+
+    if constexpr (LS > 1) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+#pragma unroll
+            for (int m = LS / 2; m >= 1; m >>= 1) {
+                ax[g].x += __shfl_xor(ax[g].x, m, 64); ax[g].y += __shfl_xor(ax[g].y, m, 64);
+                ay[g].x += __shfl_xor(ay[g].x, m, 64); ay[g].y += __shfl_xor(ay[g].y, m, 64);
+                az[g].x += __shfl_xor(az[g].x, m, 64); az[g].y += __shfl_xor(az[g].y, m, 64);
+            }
+        }
+    }
+    if (js == 0) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const uint32_t il0 = blockIdx.x * IPB + (2 * g) * GROUPS + grp;
+            const uint32_t il1 = il0 + GROUPS;
+            float4* out = partial + (size_t)blockIdx.y * i_count;
+            if (il0 < i_count) out[il0] = float4{ax[g].x, ay[g].x, az[g].x, 0};
+            if (il1 < i_count) out[il1] = float4{ax[g].y, ay[g].y, az[g].y, 0};
+        }
+    }
+}
+
 // K2.  nbody3d.js:274-290 on all four components (the .w lane is integrated
 // too, exactly as the reference does; mass stays constant because vel.w = 0).
 template <typename T>
