@@ -1,0 +1,356 @@
+/*
+ * nb_napi.c -- raw N-API binding of include/nbody3d_hip.h for Node.js.
+ *
+ * The reference's host side is browser JavaScript talking to WebGPU
+ * (/root/reference nbody3d.js:136-521).  This addon is the thin FFI that lets
+ * the same JavaScript-side calls reach the HIP engine: typed arrays are passed
+ * by pointer (napi_get_typedarray_info, zero copy on the JS side), every C
+ * status code becomes a thrown Error carrying nb_last_error().
+ *
+ * Built with plain gcc against /usr/include/node (no node-gyp, no network):
+ *   gcc -O2 -fPIC -shared -I/usr/include/node -o nb_napi.node nb_napi.c -ldl
+ * The engine library is dlopen()ed at load(path) time, so the addon itself
+ * loads on a machine without ROCm and reports that as an ordinary error.
+ */
+#define NAPI_VERSION 6
+#include <node_api.h>
+
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../../../include/nbody3d_hip.h"
+
+/* ---- engine entry points, resolved at load() ---------------------------- */
+static void *g_lib;
+static uint32_t (*p_abi_version)(void);
+static int (*p_device_count)(void);
+static int (*p_create)(const nb_config *, nb_sim **);
+static void (*p_destroy)(nb_sim *);
+static int (*p_upload)(nb_sim *, const void *, const void *, const void *);
+static int (*p_set_params)(nb_sim *, double, double);
+static int (*p_step)(nb_sim *, uint32_t);
+static int (*p_download)(nb_sim *, void *, void *, void *);
+static int (*p_sync)(nb_sim *);
+static const char *(*p_last_error)(nb_sim *);
+static int (*p_enable_timing)(nb_sim *, int);
+static int (*p_kernel_times)(nb_sim *, double *, double *, uint32_t *);
+static const char *(*p_variant_name)(nb_sim *);
+static int (*p_diagnostics)(nb_sim *, double *);
+
+typedef struct { nb_sim *sim; uint32_t n; int f64; } handle_t;
+
+#define CHECK_NAPI(env, call)                                                        \
+    do {                                                                             \
+        if ((call) != napi_ok) {                                                     \
+            napi_throw_error((env), NULL, "N-API call failed: " #call);              \
+            return NULL;                                                             \
+        }                                                                            \
+    } while (0)
+
+static napi_value throw_nb(napi_env env, int code, nb_sim *s, const char *where)
+{
+    char buf[768];
+    const char *msg = p_last_error ? p_last_error(s) : "engine not loaded";
+    snprintf(buf, sizeof buf, "%s: status %d: %s", where, code, msg ? msg : "");
+    char codes[16];
+    snprintf(codes, sizeof codes, "NB_%d", code);
+    napi_throw_error(env, codes, buf);
+    return NULL;
+}
+
+static int need_lib(napi_env env)
+{
+    if (!g_lib) { napi_throw_error(env, "NB_NOLIB", "libnbody3d_hip.so is not loaded; call load(path) first"); return 0; }
+    return 1;
+}
+
+static napi_value undefined(napi_env env) { napi_value u; napi_get_undefined(env, &u); return u; }
+
+/* load(path) -> abi version */
+static napi_value js_load(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    char path[4096]; size_t len = 0;
+    if (argc < 1 || napi_get_value_string_utf8(env, argv[0], path, sizeof path, &len) != napi_ok) {
+        napi_throw_type_error(env, NULL, "load(path): path string required"); return NULL;
+    }
+    if (!g_lib) {
+        void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+            char buf[4600]; snprintf(buf, sizeof buf, "cannot load HIP engine %s: %s", path, dlerror());
+            napi_throw_error(env, "NB_NOLIB", buf); return NULL;
+        }
+#define SYM(var, name)                                                                            \
+    do {                                                                                          \
+        *(void **)(&var) = dlsym(h, name);                                                        \
+        if (!var) { dlclose(h); napi_throw_error(env, "NB_NOLIB", "missing symbol " name); return NULL; } \
+    } while (0)
+        SYM(p_abi_version, "nb_abi_version"); SYM(p_device_count, "nb_device_count");
+        SYM(p_create, "nb_create"); SYM(p_destroy, "nb_destroy"); SYM(p_upload, "nb_upload");
+        SYM(p_set_params, "nb_set_params"); SYM(p_step, "nb_step"); SYM(p_download, "nb_download");
+        SYM(p_sync, "nb_sync"); SYM(p_last_error, "nb_last_error"); SYM(p_enable_timing, "nb_enable_timing");
+        SYM(p_kernel_times, "nb_kernel_times"); SYM(p_variant_name, "nb_variant_name");
+        SYM(p_diagnostics, "nb_diagnostics");
+#undef SYM
+        g_lib = h;
+    }
+    if (p_abi_version() != NB_ABI_VERSION) { napi_throw_error(env, "NB_ABI", "ABI version mismatch"); return NULL; }
+    napi_value v; CHECK_NAPI(env, napi_create_uint32(env, p_abi_version(), &v)); return v;
+}
+
+static napi_value js_device_count(napi_env env, napi_callback_info info)
+{
+    (void)info;
+    if (!need_lib(env)) return NULL;
+    napi_value v; CHECK_NAPI(env, napi_create_int32(env, p_device_count(), &v)); return v;
+}
+
+static void finalize_handle(napi_env env, void *data, void *hint)
+{
+    (void)env; (void)hint;
+    handle_t *h = (handle_t *)data;
+    if (h) { if (h->sim && p_destroy) p_destroy(h->sim); free(h); }
+}
+
+static int get_u32_prop(napi_env env, napi_value obj, const char *name, uint32_t *out)
+{
+    bool has = false; napi_value v;
+    if (napi_has_named_property(env, obj, name, &has) != napi_ok || !has) return 0;
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok) return 0;
+    napi_valuetype t; napi_typeof(env, v, &t);
+    if (t != napi_number) return 0;
+    double d; napi_get_value_double(env, v, &d);
+    *out = (uint32_t)d; return 1;
+}
+
+static int get_f64_prop(napi_env env, napi_value obj, const char *name, double *out)
+{
+    bool has = false; napi_value v;
+    if (napi_has_named_property(env, obj, name, &has) != napi_ok || !has) return 0;
+    if (napi_get_named_property(env, obj, name, &v) != napi_ok) return 0;
+    napi_valuetype t; napi_typeof(env, v, &t);
+    if (t != napi_number) return 0;
+    napi_get_value_double(env, v, out); return 1;
+}
+
+/* create({n, f64, eps2, device, shardBegin, shardCount, variant, jsplit}) -> external */
+static napi_value js_create(napi_env env, napi_callback_info info)
+{
+    if (!need_lib(env)) return NULL;
+    size_t argc = 1; napi_value argv[1];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 1) { napi_throw_type_error(env, NULL, "create(options) requires an object"); return NULL; }
+    nb_config cfg; memset(&cfg, 0, sizeof cfg);
+    cfg.struct_size = sizeof cfg; cfg.device = -1;
+    uint32_t u; double d;
+    if (get_u32_prop(env, argv[0], "n", &u)) cfg.n = u;
+    if (get_u32_prop(env, argv[0], "f64", &u)) cfg.precision = u ? NB_F64 : NB_F32;
+    if (get_f64_prop(env, argv[0], "eps2", &d)) cfg.eps2 = d;
+    if (get_f64_prop(env, argv[0], "device", &d)) cfg.device = (int32_t)d;
+    if (get_u32_prop(env, argv[0], "shardBegin", &u)) cfg.shard_begin = u;
+    if (get_u32_prop(env, argv[0], "shardCount", &u)) cfg.shard_count = u;
+    if (get_u32_prop(env, argv[0], "variant", &u)) cfg.force_variant = u;
+    if (get_u32_prop(env, argv[0], "jsplit", &u)) cfg.jsplit = u;
+    if (get_u32_prop(env, argv[0], "tile", &u)) cfg.tile = u;
+    nb_sim *sim = NULL;
+    int rc = p_create(&cfg, &sim);
+    if (rc != NB_OK) return throw_nb(env, rc, NULL, "nb_create");
+    handle_t *h = (handle_t *)calloc(1, sizeof *h);
+    if (!h) { p_destroy(sim); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    h->sim = sim; h->n = cfg.n; h->f64 = cfg.precision == NB_F64;
+    napi_value ext;
+    if (napi_create_external(env, h, finalize_handle, NULL, &ext) != napi_ok) {
+        finalize_handle(env, h, NULL); napi_throw_error(env, NULL, "napi_create_external failed"); return NULL;
+    }
+    return ext;
+}
+
+static handle_t *get_handle(napi_env env, napi_value v)
+{
+    void *p = NULL;
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((handle_t *)p)->sim) {
+        napi_throw_error(env, "NB_1", "invalid or destroyed simulation handle"); return NULL;
+    }
+    return (handle_t *)p;
+}
+
+/* typed array -> pointer; NULL allowed when nullable; checks element type + length */
+static int get_array(napi_env env, napi_value v, const handle_t *h, int nullable, void **out, const char *name)
+{
+    napi_valuetype t; napi_typeof(env, v, &t);
+    *out = NULL;
+    if (t == napi_null || t == napi_undefined) {
+        if (nullable) return 1;
+        napi_throw_type_error(env, NULL, name); return 0;
+    }
+    bool is_ta = false; napi_is_typedarray(env, v, &is_ta);
+    if (!is_ta) { napi_throw_type_error(env, NULL, name); return 0; }
+    napi_typedarray_type tt; size_t len; void *data; napi_value ab; size_t off;
+    if (napi_get_typedarray_info(env, v, &tt, &len, &data, &ab, &off) != napi_ok) { napi_throw_type_error(env, NULL, name); return 0; }
+    if ((h->f64 && tt != napi_float64_array) || (!h->f64 && tt != napi_float32_array)) {
+        napi_throw_type_error(env, NULL, h->f64 ? "expected Float64Array (f64 simulation)" : "expected Float32Array");
+        return 0;
+    }
+    if (len != (size_t)4 * h->n) {
+        char buf[160]; snprintf(buf, sizeof buf, "%s: expected %zu elements (4*n), got %zu", name, (size_t)4 * h->n, len);
+        napi_throw_range_error(env, NULL, buf); return 0;
+    }
+    *out = data; return 1;
+}
+
+static napi_value js_upload(napi_env env, napi_callback_info info)
+{
+    size_t argc = 4; napi_value argv[4];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 3) { napi_throw_type_error(env, NULL, "upload(handle, bodies, vel[, accel])"); return NULL; }
+    handle_t *h = get_handle(env, argv[0]); if (!h) return NULL;
+    void *b, *v, *a = NULL;
+    if (!get_array(env, argv[1], h, 0, &b, "bodies must be a typed array of 4*n elements")) return NULL;
+    if (!get_array(env, argv[2], h, 0, &v, "vel must be a typed array of 4*n elements")) return NULL;
+    if (argc >= 4 && !get_array(env, argv[3], h, 1, &a, "accel must be a typed array of 4*n elements or null")) return NULL;
+    int rc = p_upload(h->sim, b, v, a);
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_upload");
+    return undefined(env);
+}
+
+static napi_value js_set_params(napi_env env, napi_callback_info info)
+{
+    size_t argc = 3; napi_value argv[3];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 3) { napi_throw_type_error(env, NULL, "setParams(handle, dt, G)"); return NULL; }
+    handle_t *h = get_handle(env, argv[0]); if (!h) return NULL;
+    double dt, G;
+    if (napi_get_value_double(env, argv[1], &dt) != napi_ok || napi_get_value_double(env, argv[2], &G) != napi_ok) {
+        napi_throw_type_error(env, NULL, "dt and G must be numbers"); return NULL;
+    }
+    int rc = p_set_params(h->sim, dt, G);
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_set_params");
+    return undefined(env);
+}
+
+static napi_value js_step(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2; napi_value argv[2];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 1) { napi_throw_type_error(env, NULL, "step(handle[, nsteps])"); return NULL; }
+    handle_t *h = get_handle(env, argv[0]); if (!h) return NULL;
+    uint32_t n = 1;
+    if (argc >= 2) { double d; if (napi_get_value_double(env, argv[1], &d) == napi_ok && d >= 0) n = (uint32_t)d; }
+    int rc = p_step(h->sim, n);
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_step");
+    return undefined(env);
+}
+
+static napi_value js_download(napi_env env, napi_callback_info info)
+{
+    size_t argc = 4; napi_value argv[4];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 4) { napi_throw_type_error(env, NULL, "download(handle, bodies|null, vel|null, accel|null)"); return NULL; }
+    handle_t *h = get_handle(env, argv[0]); if (!h) return NULL;
+    void *b, *v, *a;
+    if (!get_array(env, argv[1], h, 1, &b, "bodies: typed array of 4*n elements or null")) return NULL;
+    if (!get_array(env, argv[2], h, 1, &v, "vel: typed array of 4*n elements or null")) return NULL;
+    if (!get_array(env, argv[3], h, 1, &a, "accel: typed array of 4*n elements or null")) return NULL;
+    int rc = p_download(h->sim, b, v, a);
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_download");
+    return undefined(env);
+}
+
+static napi_value js_sync(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    int rc = p_sync(h->sim);
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_sync");
+    return undefined(env);
+}
+
+static napi_value js_destroy(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    void *p = NULL;
+    if (argc && napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
+        handle_t *h = (handle_t *)p;
+        if (h->sim) { p_destroy(h->sim); h->sim = NULL; }   /* idempotent; finalizer frees the shell */
+    }
+    return undefined(env);
+}
+
+static napi_value js_enable_timing(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2; napi_value argv[2];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    bool on = true; if (argc >= 2) napi_get_value_bool(env, argv[1], &on);
+    int rc = p_enable_timing(h->sim, on ? 1 : 0);
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_enable_timing");
+    return undefined(env);
+}
+
+/* kernelTimes(handle) -> {forceMs, integrateMs, launches} */
+static napi_value js_kernel_times(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    double f, g; uint32_t c;
+    int rc = p_kernel_times(h->sim, &f, &g, &c);
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_kernel_times");
+    napi_value o, v;
+    CHECK_NAPI(env, napi_create_object(env, &o));
+    napi_create_double(env, f, &v); napi_set_named_property(env, o, "forceMs", v);
+    napi_create_double(env, g, &v); napi_set_named_property(env, o, "integrateMs", v);
+    napi_create_uint32(env, c, &v); napi_set_named_property(env, o, "launches", v);
+    return o;
+}
+
+static napi_value js_variant(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    napi_value v; CHECK_NAPI(env, napi_create_string_utf8(env, p_variant_name(h->sim), NAPI_AUTO_LENGTH, &v)); return v;
+}
+
+/* diagnostics(handle) -> {kinetic, potential, momentum:[3]} */
+static napi_value js_diagnostics(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    double out[5];
+    int rc = p_diagnostics(h->sim, out);
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_diagnostics");
+    napi_value o, v, arr;
+    CHECK_NAPI(env, napi_create_object(env, &o));
+    napi_create_double(env, out[0], &v); napi_set_named_property(env, o, "kinetic", v);
+    napi_create_double(env, out[1], &v); napi_set_named_property(env, o, "potential", v);
+    napi_create_array_with_length(env, 3, &arr);
+    for (uint32_t i = 0; i < 3; ++i) { napi_create_double(env, out[2 + i], &v); napi_set_element(env, arr, i, v); }
+    napi_set_named_property(env, o, "momentum", arr);
+    return o;
+}
+
+static napi_value init_module(napi_env env, napi_value exports)
+{
+    static const struct { const char *name; napi_callback fn; } fns[] = {
+        {"load", js_load}, {"deviceCount", js_device_count}, {"create", js_create}, {"upload", js_upload},
+        {"setParams", js_set_params}, {"step", js_step}, {"download", js_download}, {"sync", js_sync},
+        {"destroy", js_destroy}, {"enableTiming", js_enable_timing}, {"kernelTimes", js_kernel_times},
+        {"variant", js_variant}, {"diagnostics", js_diagnostics},
+    };
+    for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
+        napi_value f;
+        if (napi_create_function(env, fns[i].name, NAPI_AUTO_LENGTH, fns[i].fn, NULL, &f) != napi_ok) return NULL;
+        if (napi_set_named_property(env, exports, fns[i].name, f) != napi_ok) return NULL;
+    }
+    return exports;
+}
+
+NAPI_MODULE(nb_napi, init_module)

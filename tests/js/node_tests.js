@@ -1,0 +1,78 @@
+'use strict';
+/* Node-side tests, driven by tests/test_node_host.py.
+ *   node tests/js/node_tests.js cpu   -> oracle + wrapper checks, no GPU
+ *   node tests/js/node_tests.js gpu   -> parity of the JS host path on the GPU
+ * Prints one JSON object; exit code 0 iff every check passed. */
+const fs = require('fs');
+const path = require('path');
+const ROOT = path.join(__dirname, '..', '..');
+const nb = require(path.join(ROOT, 'nbody3d-webgpu_amd', 'js', 'nbody3d_hip.js'));
+const oracle = require(path.join(ROOT, 'oracle', 'js_oracle.js'));
+const GOLD = path.join(ROOT, 'tests', 'golden');
+
+function loadF32(name) { const b = fs.readFileSync(path.join(GOLD, name + '.f32')); return new Float32Array(b.buffer, b.byteOffset, b.length / 4).slice(); }
+function loadF64(name) { const b = fs.readFileSync(path.join(GOLD, name + '.f64')); return new Float64Array(b.buffer.slice(b.byteOffset, b.byteOffset + b.length)); }
+function bitsEqual(a, b) { if (a.length !== b.length) return false; const x = new Uint32Array(a.buffer, a.byteOffset, a.length), y = new Uint32Array(b.buffer, b.byteOffset, b.length); for (let i = 0; i < x.length; i++) if (x[i] !== y[i]) return false; return true; }
+function relPosErr(x, ref, rScale) { let m = 0; for (let i = 0; i < x.length / 4; i++) { let d = 0, r2 = 0; for (let c = 0; c < 3; c++) { d = Math.max(d, Math.abs(x[4 * i + c] - ref[4 * i + c])); r2 += ref[4 * i + c] * ref[4 * i + c]; } m = Math.max(m, d / Math.max(Math.sqrt(r2), rScale)); } return m; }
+
+const manifest = JSON.parse(fs.readFileSync(path.join(GOLD, 'manifest.json'), 'utf8'));
+const results = {}; let ok = true;
+function check(name, cond, info) { results[name] = { pass: !!cond, info: info }; if (!cond) ok = false; }
+function throws(fn, re) { try { fn(); } catch (e) { return re.test(String(e.message) + ' ' + String(e.code)); } return false; }
+
+const mode = process.argv[2] || 'cpu';
+const m = manifest.plummer1024;
+const b0 = loadF32('plummer1024_bodies0'), v0 = loadF32('plummer1024_vel0');
+
+if (mode === 'cpu') {
+  // 1. JS oracle reproduces the C oracle's committed vectors bit for bit (10 steps)
+  const t0 = Date.now();
+  const r = oracle.runF32(b0, v0, null, m.dt, m.G, 10);
+  const secs = (Date.now() - t0) / 1e3;
+  check('js_oracle_bit_exact_vs_golden_s10', bitsEqual(r.bodies, loadF32('plummer1024_s10_bodies')) && bitsEqual(r.vel, loadF32('plummer1024_s10_vel')) && bitsEqual(r.accel, loadF32('plummer1024_s10_accel')), { seconds: secs, pairs_per_s: 10 * 1024 * 1023 / secs });
+  const d = oracle.runF32(loadF32('disk771_bodies0'), loadF32('disk771_vel0'), null, manifest.disk771.dt, manifest.disk771.G, 1);
+  check('js_oracle_bit_exact_disk771_s1', bitsEqual(d.bodies, loadF32('disk771_s1_bodies')) && bitsEqual(d.accel, loadF32('disk771_s1_accel')));
+  // 2. wrapper loads the addon + engine library, and reports a missing GPU as an Error
+  check('addon_loads', nb.load() === 1);
+  check('surface', ['init', 'step', 'simulate', 'read'].every(function (k) { return typeof nb[k] === 'function'; }) && typeof nb.Simulation === 'function');
+  if (nb.deviceCount() === 0) {
+    check('no_device_throws', throws(function () { nb.init([b0, v0]); }, /no HIP device.*NB_2|NB_2/));
+  }
+  check('step_before_init_throws', throws(function () { new nb.Simulation().step(1e-3); }, /not initialised/));
+  check('bad_particles_throws', throws(function () { new nb.Simulation().init({}); }, /expected/));
+  // 3. pause semantics (util.js:36-64)
+  const s = new nb.Simulation({ dt: 1e-3 });
+  s.togglePause(); const paused = s.dt === 0; s.setDt(2e-3); const still = s.dt === 0; s.togglePause();
+  check('pause_semantics', paused && still && s.dt === 2e-3);
+} else {
+  // GPU: the JS host path end to end on the golden fixture
+  const sim = nb.init([b0, v0], { G: m.G, dt: m.dt });
+  nb.simulate(10);
+  const s10 = nb.read();
+  check('gpu_s10_vs_oracle', relPosErr(s10.bodies, loadF32('plummer1024_s10_bodies'), m.r_scale) < 1e-6);
+  for (let k = 0; k < 90; k++) nb.step(m.dt);
+  const s100 = nb.read();
+  const e64 = relPosErr(s100.bodies, loadF64('plummer1024_s100_bodies'), m.r_scale);
+  check('gpu_s100_vs_f64_oracle_le_1e-4', e64 < 2e-5, { err: e64, variant: sim.variant() });
+  // dt = 0 / pause is a no-op (nbody3d.js:474)
+  sim.togglePause(); nb.step(); const p = nb.read(); sim.togglePause();
+  check('pause_noop', bitsEqual(p.bodies, s100.bodies) && bitsEqual(p.vel, s100.vel) && bitsEqual(p.accel, s100.accel));
+  // export / import round trip (util.js:186-263)
+  const json = sim.exportJSON();
+  const sim2 = new nb.Simulation({ dt: m.dt }).importJSON(json);
+  check('json_roundtrip_G', Math.abs(sim2.G - 1.0) < 1e-12 && sim2.nBodies === 1024);
+  sim.step(); sim2.step();
+  check('json_roundtrip_continues_identically', bitsEqual(sim.read().bodies, sim2.read().bodies));
+  // wrong array length is an error, not a crash
+  check('bad_length_throws', throws(function () { sim.restore({ bodies: new Float32Array(8), vel: new Float32Array(8) }); }, /expected/));
+  const d = sim.diagnostics();
+  check('diagnostics', isFinite(d.kinetic) && d.potential < 0 && d.momentum.length === 3, d);
+  // f64 simulation takes Float64Array
+  const s64 = new nb.Simulation({ f64: true, G: m.G, dt: m.dt }).init([Float64Array.from(b0), Float64Array.from(v0)]);
+  s64.simulate(100);
+  const e = relPosErr(s64.read().bodies, loadF64('plummer1024_s100_bodies'), m.r_scale);
+  check('gpu_f64_vs_f64_oracle', e < 1e-12, { err: e });
+  s64.destroy(); sim2.destroy(); sim.destroy();
+}
+console.log(JSON.stringify({ ok: ok, mode: mode, results: results }));
+process.exit(ok ? 0 : 1);
