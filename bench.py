@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the torch.distributed/RCCL exchange path even with one rank (plumbing test)")
     return ap.parse_args()
 
 
@@ -126,8 +128,10 @@ def main():
         sys.exit("bench.py: no GPU visible -- the engine has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:      # --force-dist without a launcher
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.n or (N_HEADLINE if args.scaling == "strong" or world == 1 else weak_n(world))
@@ -139,7 +143,7 @@ def main():
 
     stream = torch.cuda.current_stream()
     kw = dict(precision=args.precision, device=local_rank, force_variant=args.variant, jsplit=args.jsplit)
-    if world > 1:
+    if dist is not None:
         # torch owns the replicated bodies array so the collective runs on it directly
         t_bodies = torch.empty((plan.padded_n, 4), device="cuda",
                                dtype=torch.float64 if args.precision == "f64" else torch.float32)

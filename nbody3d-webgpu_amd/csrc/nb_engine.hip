@@ -52,6 +52,12 @@ struct nb_sim {
     nb_exchange_fn xfn = nullptr;
     void* xuser = nullptr;
     bool timing = false;
+    // HIP-graph replay of multi-step calls (launch-bound small N): kGraphChunk
+    // [K1,K2] pairs captured once per (dt, G) and replayed
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    double graph_dt = 0.0, graph_G = 0.0;
+    bool graphs_ok = true;           // cleared if capture ever fails: fall back to plain launches
     std::vector<EventTriple> pool;   // recycled events
     std::vector<EventTriple> pending;
     size_t pool_next = 0;
@@ -75,59 +81,55 @@ int fail(nb_sim* s, int code, const std::string& msg)
 uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
 // Launch-shape heuristic (measured: profiles/r01/sweep_*.txt).
-//   * f32 uses the packed kernel; 8 i-bodies per lane (4 packed groups) when
-//     the shard has enough rows to make >= 16 i-blocks, else 4 or 2 per lane;
-//     fewer rows than that: the scalar kernel with LS lanes per body.
-//   * j is split over blockIdx.y until the grid has ~4096 workgroups (the
-//     118-VGPR packed kernel keeps 4 waves per SIMD = 1024 workgroups resident,
-//     so 4 rounds: short blocks even out DVFS/tail imbalance; +4 % over 1024),
-//     keeping >= 4 tiles per split and <= 64 splits.
+//   grid = (i-blocks, jsplit) workgroups of 4 waves.  Wanted: ~4096 workgroups
+//   (the 118-VGPR packed kernel keeps 4 waves per SIMD = 1024 workgroups
+//   resident, so 4 rounds of short blocks even out DVFS/tail imbalance: +4 %
+//   over 1024), and never fewer than ~1024 when the problem allows it.
+//   * i-side: f32 uses the packed kernel with the largest register blocking
+//     (8, 4, 2 bodies per lane) that still reaches 1024 workgroups with the
+//     j-split available; below that the scalar kernel lets LS = 4/16/64 lanes
+//     share one body (shuffle-reduced), which multiplies the i-blocks by LS.
+//   * j-side: split over blockIdx.y, at most one split per 256-body tile, <= 64.
+struct Shape { int ipl, ls; bool pk; };
+
 void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
 {
     const uint32_t sc = s->sc, n = s->n;
-    int ipl, ls;
-    bool pk = false;
-    uint32_t variant = cfg.force_variant;
-    if (variant == 0) {
-        if (!s->f64) {
-            if (sc >= 16u * 2048) variant = 28;        // packed, IPL=8
-            else if (sc >= 16u * 1024) variant = 24;   // packed, IPL=4
-            else if (sc >= 4096) variant = 22;         // packed, IPL=2
-            else if (sc >= 1024) variant = 14;         // LS=4
-            else if (sc >= 256) variant = 116;         // LS=16
-            else variant = 164;                        // LS=64: a whole wave per body
-        } else {
-            if (sc >= 16u * 512) variant = 2;
-            else if (sc >= 4096) variant = 1;
-            else if (sc >= 1024) variant = 14;
-            else if (sc >= 256) variant = 116;
-            else variant = 164;
-        }
-    }
-    switch (variant) {
-        case 1: ipl = 1; ls = 1; break;
-        case 2: ipl = 2; ls = 1; break;
-        case 4: ipl = 4; ls = 1; break;
-        case 14: ipl = 1; ls = 4; break;
-        case 116: ipl = 1; ls = 16; break;
-        case 164: ipl = 1; ls = 64; break;
-        case 22: ipl = 2; ls = 1; pk = true; break;    // packed across 2 i-bodies
-        case 24: ipl = 4; ls = 1; pk = true; break;
-        case 28: ipl = 8; ls = 1; pk = true; break;
-        default: ipl = 2; ls = 1; variant = 2; break;
-    }
-    if (s->f64) pk = false;
-    s->ipl = ipl; s->ls = ls; s->packed = pk;
-    const uint32_t ipb = (nb::kBlock / ls) * ipl;
-    const uint32_t iblocks = ceil_div(sc, ipb);
-    uint32_t js = cfg.jsplit;
     const uint32_t tiles = ceil_div(n, nb::kTile);
+    const uint32_t js_cap = tiles < 64 ? (tiles ? tiles : 1) : 64;
+    const uint32_t want_blocks = (uint32_t)n_cu * 16, min_blocks = (uint32_t)n_cu * 4;
+    auto iblocks_of = [&](const Shape& sh) { return ceil_div(sc, (uint32_t)(nb::kBlock / sh.ls) * sh.ipl); };
+
+    Shape sh{2, 1, false};
+    const uint32_t variant = cfg.force_variant;
+    if (variant == 0) {
+        const Shape f32_order[] = {{8, 1, true}, {4, 1, true}, {2, 1, true}, {1, 4, false}, {1, 16, false}, {1, 64, false}};
+        const Shape f64_order[] = {{2, 1, false}, {1, 1, false}, {1, 4, false}, {1, 16, false}, {1, 64, false}};
+        const Shape* order = s->f64 ? f64_order : f32_order;
+        const int cnt = s->f64 ? 5 : 6;
+        sh = order[cnt - 1];
+        for (int k = 0; k < cnt; ++k)
+            if ((uint64_t)iblocks_of(order[k]) * js_cap >= min_blocks) { sh = order[k]; break; }
+    } else {
+        switch (variant) {
+            case 1: sh = {1, 1, false}; break;
+            case 2: sh = {2, 1, false}; break;
+            case 4: sh = {4, 1, false}; break;
+            case 14: sh = {1, 4, false}; break;
+            case 116: sh = {1, 16, false}; break;
+            case 164: sh = {1, 64, false}; break;
+            case 22: sh = {2, 1, true}; break;     // packed across 2 i-bodies
+            case 24: sh = {4, 1, true}; break;
+            case 28: sh = {8, 1, true}; break;
+            default: sh = {2, 1, false}; break;
+        }
+        if (s->f64) sh.pk = false;
+    }
+    s->ipl = sh.ipl; s->ls = sh.ls; s->packed = sh.pk;
+    uint32_t js = cfg.jsplit;
     if (js == 0) {
-        const uint32_t want_blocks = (uint32_t)n_cu * 16;
-        js = ceil_div(want_blocks, iblocks);
-        const uint32_t max_js = tiles >= 4 ? tiles / 4 : 1;     // >= 4 tiles per split
-        if (js > max_js) js = max_js;
-        if (js > 64) js = 64;
+        js = ceil_div(want_blocks, iblocks_of(sh));
+        if (js > js_cap) js = js_cap;
         if (js < 1) js = 1;
     }
     if (js > tiles) js = tiles ? tiles : 1;
@@ -136,8 +138,8 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
     // a split may end up empty after rounding: shrink jsplit to what is used
     s->jsplit = ceil_div(n, s->j_per_split);
     char buf[96];
-    snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", pk ? "pk" : "", nb::kTile, ipl, ls,
-             s->jsplit);
+    snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.pk ? "pk" : "", nb::kTile, sh.ipl,
+             sh.ls, s->jsplit);
     s->variant = buf;
 }
 
@@ -179,9 +181,42 @@ template <typename T>
 void launch_integrate(nb_sim* s)
 {
     using V4 = typename nb::vec4<T>::type;
-    dim3 grid(ceil_div(s->sc, nb::kBlock)), block(nb::kBlock);
-    hipLaunchKernelGGL((nb::nb_integrate<T>), grid, block, 0, s->stream, (V4*)s->bodies, (V4*)s->vel, (V4*)s->acc,
-                       (const V4*)s->partial, s->sb, s->sc, s->jsplit, (T)s->dt);
+    // lanes per body: enough to keep ~8 partial loads per lane at most
+    const int R = s->jsplit >= 32 ? 8 : s->jsplit >= 8 ? 4 : 1;
+    dim3 grid(ceil_div(s->sc * (uint32_t)R, nb::kBlock)), block(nb::kBlock);
+#define NB_K2(RR)                                                                                                   \
+    hipLaunchKernelGGL((nb::nb_integrate<T, RR>), grid, block, 0, s->stream, (V4*)s->bodies, (V4*)s->vel,           \
+                       (V4*)s->acc, (const V4*)s->partial, s->sb, s->sc, s->jsplit, (T)s->dt)
+    if (R == 8) NB_K2(8); else if (R == 4) NB_K2(4); else NB_K2(1);
+#undef NB_K2
+}
+
+constexpr uint32_t kGraphChunk = 16;
+
+void drop_graph(nb_sim* s)
+{
+    if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
+    if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+}
+
+// Captures kGraphChunk steps of [force, integrate] on the engine's own stream.
+// Returns false (and disables graphs for the handle) if anything goes wrong;
+// the caller then issues plain launches -- same kernels, same results.
+bool ensure_graph(nb_sim* s)
+{
+    if (s->graph_exec && s->graph_dt == s->dt && s->graph_G == s->G) return true;
+    drop_graph(s);
+    if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { s->graphs_ok = false; return false; }
+    for (uint32_t k = 0; k < kGraphChunk; ++k) {
+        if (s->f64) { launch_force<double>(s); launch_integrate<double>(s); }
+        else { launch_force<float>(s); launch_integrate<float>(s); }
+    }
+    hipGraph_t g = nullptr;
+    if (hipStreamEndCapture(s->stream, &g) != hipSuccess || !g) { (void)hipGetLastError(); s->graphs_ok = false; return false; }
+    hipGraphExec_t ge = nullptr;
+    if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); (void)hipGetLastError(); s->graphs_ok = false; return false; }
+    s->graph = g; s->graph_exec = ge; s->graph_dt = s->dt; s->graph_G = s->G;
+    return true;
 }
 
 int get_events(nb_sim* s, EventTriple* out)
@@ -286,6 +321,7 @@ void nb_destroy(nb_sim* s)
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
+    drop_graph(s);
     for (auto& t : s->pool) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
     if (s->own_bodies && s->bodies) (void)hipFree(s->bodies);
     if (s->vel) (void)hipFree(s->vel);
@@ -330,6 +366,14 @@ int nb_step(nb_sim* s, uint32_t nsteps)
     if (!s->params_set) return fail(s, NB_ERR_STATE, "nb_step: nb_set_params has not been called");
     if (!(s->dt > 0.0)) return NB_OK;   // `if (dt > 0)` gate, nbody3d.js:474
     NB_HIP(s, hipSetDevice(s->device));
+    // Multi-step calls on the engine's own stream replay a captured graph of
+    // kGraphChunk steps (no exchange hook, no per-kernel timing requested).
+    if (s->own_stream && s->graphs_ok && !s->xfn && !s->timing && nsteps >= kGraphChunk) {
+        while (nsteps >= kGraphChunk && ensure_graph(s)) {
+            NB_HIP(s, hipGraphLaunch(s->graph_exec, s->stream));
+            nsteps -= kGraphChunk;
+        }
+    }
     for (uint32_t k = 0; k < nsteps; ++k) {
         EventTriple ev;
         const bool rec = s->timing && get_events(s, &ev) == 0;

@@ -248,7 +248,12 @@ __global__ __launch_bounds__(kBlock) void nb_force_pk(const float4* __restrict__
 
 // K2.  nbody3d.js:274-290 on all four components (the .w lane is integrated
 // too, exactly as the reference does; mass stays constant because vel.w = 0).
-template <typename T>
+// R lanes cooperate on one body: lane r sums partials r, r+R, r+2R, ... (ascending,
+// independent 16-B loads in flight), the R sums are combined by wavefront shuffles
+// in a fixed order (deterministic), and lane 0 of the group applies the update.
+// With jsplit = 64 partials a single lane per body is latency-bound (20 us at
+// 16,384 rows); R = 8 brings it to the launch floor.
+template <typename T, int R>
 __global__ __launch_bounds__(kBlock) void nb_integrate(typename vec4<T>::type* __restrict__ bodies,
                                                       typename vec4<T>::type* __restrict__ vel,
                                                       typename vec4<T>::type* __restrict__ acc,
@@ -256,13 +261,40 @@ __global__ __launch_bounds__(kBlock) void nb_integrate(typename vec4<T>::type* _
                                                       uint32_t i_begin, uint32_t i_count, uint32_t jsplit, T dt)
 {
     using V4 = typename vec4<T>::type;
-    const uint32_t il = blockIdx.x * kBlock + threadIdx.x;
-    if (il >= i_count) return;
-    V4 a = partial[il];
-    for (uint32_t s = 1; s < jsplit; ++s) {
-        const V4 p = partial[(size_t)s * i_count + il];
-        a.x += p.x; a.y += p.y; a.z += p.z;
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t il = gid / R;
+    const uint32_t r = gid % R;
+    const bool valid = il < i_count;
+    T sx = 0, sy = 0, sz = 0;
+    if (valid) {
+        uint32_t sp = r;
+        // 4 independent loads per trip, summed in ascending split order
+        for (; sp + 3 * R < jsplit; sp += 4 * R) {
+            const V4 p0 = partial[(size_t)sp * i_count + il];
+            const V4 p1 = partial[(size_t)(sp + R) * i_count + il];
+            const V4 p2 = partial[(size_t)(sp + 2 * R) * i_count + il];
+            const V4 p3 = partial[(size_t)(sp + 3 * R) * i_count + il];
+            sx += p0.x; sy += p0.y; sz += p0.z;
+            sx += p1.x; sy += p1.y; sz += p1.z;
+            sx += p2.x; sy += p2.y; sz += p2.z;
+            sx += p3.x; sy += p3.y; sz += p3.z;
+        }
+        for (; sp < jsplit; sp += R) {
+            const V4 p = partial[(size_t)sp * i_count + il];
+            sx += p.x; sy += p.y; sz += p.z;
+        }
     }
+    if constexpr (R > 1) {
+#pragma unroll
+        for (int m = 1; m < R; m <<= 1) {
+            sx += __shfl_xor(sx, m, 64);
+            sy += __shfl_xor(sy, m, 64);
+            sz += __shfl_xor(sz, m, 64);
+        }
+    }
+    if (!valid || r != 0) return;
+    V4 a;
+    a.x = sx; a.y = sy; a.z = sz;
     a.w = 0;                                                            // :274
     const T h = dt * T(0.5);                                            // :276
     const V4 ao = acc[il];

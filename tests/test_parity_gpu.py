@@ -91,6 +91,25 @@ def test_intermediate_checkpoints_and_restore(manifest):
         assert x.tobytes() == y.tobytes()
 
 
+def test_graph_replay_equals_single_steps():
+    """nb_step(k >= 16) replays a captured HIP graph of 16 [force, integrate]
+    pairs; it must be bit-identical to k single-step calls, and follow dt/G
+    changes between calls (the graph bakes them in and is re-captured)."""
+    b, v = ic.plummer(1024, seed=18)
+    with Simulation(1024) as a, Simulation(1024) as c:
+        a.init(b, v)
+        c.init(b, v)
+        a.simulate(40, 1e-3, 1.0)          # 2 graph launches + 8 plain steps
+        for _ in range(40):
+            c.step(1e-3, 1.0)
+        a.simulate(35, 5e-4, 0.5)          # new params: re-capture
+        for _ in range(35):
+            c.step(5e-4, 0.5)
+        ra, rc = a.read(), c.read()
+    for x, y in zip(ra, rc):
+        assert x.tobytes() == y.tobytes()
+
+
 def test_dt_zero_and_negative_are_noops():
     """`if (dt > 0)` gate, nbody3d.js:474: state stays bit-identical."""
     b, v = ic.plummer(512, seed=12)
