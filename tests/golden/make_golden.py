@@ -13,6 +13,8 @@ Files are raw little-endian arrays (.f32 / .f64) + manifest.json.
 """
 import json
 import os
+import shutil
+import subprocess
 import sys
 
 import numpy as np
@@ -102,6 +104,15 @@ def main():
     v[1:, 0] = -sp * np.sin(th)
     v[1:, 1] = sp * np.cos(th)
     case(manifest, "disk771", b, v, 1e-4, 1e-4, [1, 50])
+    # reference-native initial conditions: produced by RUNNING the reference's
+    # generateGalaxy text under node (make_galaxy_fixture.js; needs /root/reference),
+    # stepped here with the reference's default G = dt = 1e-4 (nbody3d.js:6-7).
+    # N = 789: not a multiple of 256, mass ratio 1e6 -- the harshest ordering/tail case.
+    if os.path.isdir("/root/reference") and shutil.which("node"):
+        subprocess.check_call(["node", os.path.join(HERE, "make_galaxy_fixture.js")])
+    gb = np.fromfile(os.path.join(HERE, "galaxy_ref_bodies0.f32"), "<f4").reshape(-1, 4)
+    gv = np.fromfile(os.path.join(HERE, "galaxy_ref_vel0.f32"), "<f4").reshape(-1, 4)
+    case(manifest, "galaxy_ref", gb, gv, 1e-4, 1e-4, [1, 30])
     with open(os.path.join(HERE, "manifest.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     print(json.dumps(manifest, indent=1, sort_keys=True))

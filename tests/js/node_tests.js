@@ -40,6 +40,18 @@ if (mode === 'cpu') {
   }
   check('step_before_init_throws', throws(function () { new nb.Simulation().step(1e-3); }, /not initialised/));
   check('bad_particles_throws', throws(function () { new nb.Simulation().init({}); }, /expected/));
+  // 2b. the seedable generateGalaxy port reproduces, bit for bit, the arrays the
+  //     reference's own generator text produced from the same random stream
+  const ic = require(path.join(ROOT, 'nbody3d-webgpu_amd', 'js', 'ic.js'));
+  const gp = JSON.parse(fs.readFileSync(path.join(GOLD, 'galaxy_ref_params.json'), 'utf8'));
+  const stream = ic.mulberry32(gp.seed);
+  const list = ic.galaxySettings(gp.numGalaxies, { random: stream, minBodies: gp.minBodies, maxBodies: gp.maxBodies });
+  const gal = ic.galaxies(list, { random: stream, G: gp.G, sizeFactor: gp.outerHeight });
+  check('galaxy_port_settings', JSON.stringify(list) === JSON.stringify(gp.galaxySettings));
+  check('galaxy_port_bit_exact_vs_reference_generator', gal[0].length === 4 * gp.n && bitsEqual(gal[0], loadF32('galaxy_ref_bodies0')) && bitsEqual(gal[1], loadF32('galaxy_ref_vel0')));
+  const pl = ic.plummer(2048, { seed: 3 }); let msum = 0, cx = 0;
+  for (let i = 0; i < 2048; i++) { msum += pl[0][4 * i + 3]; cx += pl[0][4 * i]; }
+  check('plummer_js_sane', Math.abs(msum - 1) < 1e-5 && Math.abs(cx / 2048) < 1e-6 && pl[1][3] === 0);
   // 3. pause semantics (util.js:36-64)
   const s = new nb.Simulation({ dt: 1e-3 });
   s.togglePause(); const paused = s.dt === 0; s.setDt(2e-3); const still = s.dt === 0; s.togglePause();

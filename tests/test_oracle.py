@@ -78,7 +78,8 @@ def test_dt_zero_is_a_noop():
     assert b2.tobytes() == b.tobytes() and v2.tobytes() == v.tobytes() and a2.tobytes() == a.tobytes()
 
 
-@pytest.mark.parametrize("name,steps", [("plummer1024", [1, 10, 100]), ("cube1000", [1, 20]), ("disk771", [1, 50])])
+@pytest.mark.parametrize("name,steps", [("plummer1024", [1, 10, 100]), ("cube1000", [1, 20]), ("disk771", [1, 50]),
+                                        ("galaxy_ref", [1, 30])])
 def test_golden_vectors_bit_exact(manifest, name, steps):
     """The committed vectors are reproduced bit for bit by the oracle."""
     m = manifest[name]

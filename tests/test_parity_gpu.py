@@ -51,7 +51,7 @@ def test_single_step_matches_oracle_acceleration(variant, jsplit):
     assert np.abs(vv - v2).max() < 1e-5 * np.abs(v2).max() + 1e-7
 
 
-@pytest.mark.parametrize("name,steps", [("plummer1024", 100), ("cube1000", 20), ("disk771", 50)])
+@pytest.mark.parametrize("name,steps", [("plummer1024", 100), ("cube1000", 20), ("disk771", 50), ("galaxy_ref", 30)])
 @pytest.mark.parametrize("variant,jsplit", [(0, 0), (2, 1), (1, 2), (164, 1), (22, 1), (24, 2), (28, 1)])
 def test_golden_trajectories(manifest, name, steps, variant, jsplit):
     """BASELINE.json config 1 (Plummer N=1024, dt=1e-3, 100 steps) and the
