@@ -154,8 +154,12 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
 //   NG = packed groups per lane -> IPL = 2*NG i-bodies per lane.
 typedef float nb_f2 __attribute__((ext_vector_type(2)));
 
+// Occupancy target handed to the register allocator/scheduler: NG = 4 needs
+// ~118 VGPRs (4 waves/SIMD); telling the backend so keeps it from re-serialising
+// the stage-major order to chase an occupancy it cannot reach anyway.
 template <int NG, int LS>
-__global__ __launch_bounds__(kBlock) void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial,
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NG >= 4 ? 4 : (NG == 2 ? 6 : 8), NG >= 4 ? 4 : (NG == 2 ? 6 : 8))))
+void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial,
                                                      uint32_t n, uint32_t i_begin, uint32_t i_count, float G,
                                                      float eps2, uint32_t j_per_split)
 {
@@ -202,22 +206,49 @@ __global__ __launch_bounds__(kBlock) void nb_force_pk(const float4* __restrict__
         float4 nxt;
         const bool more = (t + 1 < ntiles);
         if (more) nxt = stage(t + 1);
-#pragma unroll 8
-        for (int jj = 0; jj < kTile / LS; ++jj) {
-            const float4 b = tile[cur][jj * LS + js];
-            const nb_f2 bx = nb_f2{b.x, b.x}, by = nb_f2{b.y, b.y}, bz = nb_f2{b.z, b.z}, bm = nb_f2{b.w, b.w};
+        // JB j-bodies x NG groups = 4 independent dependency chains, issued
+        // stage-major: consecutive packed ops never depend on each other, so the
+        // backend needs no s_nop between a v_pk_* / v_rsq result and its consumer
+        // (gfx950 VALU hazard) and one wave alone keeps the issue port busy.
+        constexpr int JB = NG >= 4 ? 1 : 4 / NG;
+        constexpr int NC = JB * NG;
+        constexpr int UNR = 8 / JB;
+#pragma unroll UNR
+        for (int jj = 0; jj < kTile / LS; jj += JB) {
+            nb_f2 bx[JB], by[JB], bz[JB], bm[JB];
 #pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const nb_f2 dx = bx - xi[g], dy = by - yi[g], dz = bz - zi[g];
-                const nb_f2 d2 = __builtin_elementwise_fma(
-                    dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
-                const nb_f2 d6 = d2 * d2 * d2;
-                const nb_f2 r = nb_f2{__builtin_amdgcn_rsqf(d6.x), __builtin_amdgcn_rsqf(d6.y)};
-                const nb_f2 s = bm * r;
-                ax[g] = __builtin_elementwise_fma(s, dx, ax[g]);
-                ay[g] = __builtin_elementwise_fma(s, dy, ay[g]);
-                az[g] = __builtin_elementwise_fma(s, dz, az[g]);
+            for (int u = 0; u < JB; ++u) {
+                const float4 b = tile[cur][(jj + u) * LS + js];
+                bx[u] = nb_f2{b.x, b.x}; by[u] = nb_f2{b.y, b.y}; bz[u] = nb_f2{b.z, b.z}; bm[u] = nb_f2{b.w, b.w};
             }
+            nb_f2 dx[NC], dy[NC], dz[NC], d2[NC], r[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dx[c] = bx[c / NG] - xi[c % NG];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dy[c] = by[c / NG] - yi[c % NG];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dz[c] = bz[c / NG] - zi[c % NG];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = d2[c] * d2[c];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = bm[c / NG] * r[c];
+            // accumulate in ascending j for every group (same order as the plain loop)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) ax[c % NG] = __builtin_elementwise_fma(r[c], dx[c], ax[c % NG]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) ay[c % NG] = __builtin_elementwise_fma(r[c], dy[c], ay[c % NG]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) az[c % NG] = __builtin_elementwise_fma(r[c], dz[c], az[c % NG]);
         }
         if (more) tile[cur ^ 1][tid] = nxt;
         __syncthreads();
