@@ -159,6 +159,54 @@ def test_coincident_bodies_and_zero_mass():
     assert np.allclose(aa[128:, :3], ref[128:, :3], rtol=2e-5, atol=1e-7)
 
 
+def test_custom_eps2_and_zero_G():
+    """nb_config.eps2 replaces the hard-coded 1e-4 (nbody3d.js:234); G = 0 leaves pure drift."""
+    b, v = ic.plummer(600, seed=19)
+    for eps2 in (1e-6, 2.5e-3):
+        _, _, aa, name = run_engine(b, v, 1e-3, 1.0, 1, eps2=eps2)
+        ref = oracle.accel_f64(b, 1.0, eps2=eps2)
+        assert np.abs(aa[:, :3] - ref[:, :3]).max() < TOL_ACC * np.abs(ref[:, :3]).max(), (name, eps2)
+    bb, vv, aa, _ = run_engine(b, v, 1e-2, 0.0, 3)
+    assert np.all(aa == 0) and vv.tobytes() == v.tobytes()
+    rb, _, _ = oracle.run_f32(b, v, None, 1e-2, 0.0, 3)
+    assert bb.tobytes() == rb.tobytes()
+
+
+def test_far_pairs_overflow_to_zero_like_the_reference():
+    """distSqr^3 overflows binary32 beyond ~2.6e6 length units; inverseSqrt(inf) = 0,
+    so such pairs contribute exactly 0 in the reference arithmetic (nbody3d.js:235).
+    Same here (v_rsq_f32(inf) = 0), no NaNs."""
+    b = np.zeros((512, 4), np.float32)
+    b[:256, :3] = np.random.default_rng(0).random((256, 3))
+    b[256:, :3] = np.random.default_rng(1).random((256, 3)) + 1e7     # a second cluster 1e7 away
+    b[:, 3] = 1.0
+    v = np.zeros((512, 4), np.float32)
+    bb, vv, aa, _ = run_engine(b, v, 1e-3, 1.0, 1)
+    ra = oracle.accel_f32(b, 1.0)
+    assert np.isfinite(aa).all() and np.isfinite(bb).all()
+    # each cluster only feels itself
+    own = oracle.accel_f32(b[:256], 1.0)
+    assert np.abs(ra[:256] - own).max() == 0
+    assert np.abs(aa[:256, :3] - own[:, :3]).max() < TOL_ACC * np.abs(own[:, :3]).max()
+
+
+def test_invalid_arguments_raise():
+    b, v = ic.plummer(256, seed=20)
+    with Simulation(256) as sim:
+        with pytest.raises(Exception) as e:
+            sim.simulate(1, 1e-3, 1.0)          # step before init: NB_ERR_STATE
+        assert "NB_ERR_STATE" in str(e.value)
+        with pytest.raises(ValueError):
+            sim.init(b[:100], v)                # wrong length caught before any copy
+        sim.init(b, v)
+        with pytest.raises(Exception) as e:
+            sim.set_params(float("nan"), 1.0)
+        assert "NB_ERR_INVALID" in str(e.value)
+    with pytest.raises(Exception) as e:
+        Simulation(256, tile=128)               # only the reference's 256 tile is built
+    assert "NB_ERR_INVALID" in str(e.value)
+
+
 def test_newton_third_law_on_device():
     b, v = ic.plummer(4096, seed=14)
     _, _, aa, _ = run_engine(b, v, 1e-3, 1.0, 1)
