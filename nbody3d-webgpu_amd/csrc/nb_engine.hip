@@ -96,7 +96,8 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
 {
     const uint32_t sc = s->sc, n = s->n;
     const uint32_t tiles = ceil_div(n, nb::kTile);
-    const uint32_t js_cap = tiles < 64 ? (tiles ? tiles : 1) : 64;
+    const uint32_t kMaxSplit = 128;   // 1/8-shard shape: +2.7 % over 64 (profiles/r01/sweep_jsplit_cap.txt)
+    const uint32_t js_cap = tiles < kMaxSplit ? (tiles ? tiles : 1) : kMaxSplit;
     const uint32_t want_blocks = (uint32_t)n_cu * 16, min_blocks = (uint32_t)n_cu * 4;
     auto iblocks_of = [&](const Shape& sh) { return ceil_div(sc, (uint32_t)(nb::kBlock / sh.ls) * sh.ipl); };
 

@@ -44,7 +44,17 @@ constexpr int kBlock = 256;  // threads per workgroup = reference TILE_SIZE (nbo
 constexpr int kTile = 256;   // j-bodies per LDS tile (nbody3d.js:229)
 
 __device__ __forceinline__ float nb_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }  // bare v_rsq_f32 (1 ulp)
-__device__ __forceinline__ double nb_rsqrt(double x) { return rsqrt(x); }                 // v_rsq_f64 + Newton
+// v_rsq_f64 seed (~2^-26) + one Newton step y(1 + e/2), e = 1 - x y^2: 4 DP ops
+// instead of ocml rsqrt()'s 5 + class test + 2 selects.  x is clamped so an
+// overflowed d^6 cannot turn into inf*0 = NaN (such pairs then contribute ~1e-150*m,
+// i.e. nothing; the f32 path gets the reference's exact 0 from v_rsq_f32(inf)).
+__device__ __forceinline__ double nb_rsqrt(double x)
+{
+    x = __builtin_fmin(x, 1e300);
+    const double y = __builtin_amdgcn_rsq(x);
+    const double e = __builtin_fma(-x * y, y, 1.0);
+    return __builtin_fma(y * e, 0.5, y);
+}
 __device__ __forceinline__ float nb_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double nb_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 

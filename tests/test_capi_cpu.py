@@ -58,3 +58,14 @@ def test_no_device_is_an_ordinary_error_not_a_fallback():
     with pytest.raises(capi.NBodyError) as e:
         capi.Simulation(1024)
     assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+
+
+@pytest.mark.skipif(have_gpu(), reason="checks the no-device error path")
+def test_bench_refuses_to_run_without_a_gpu():
+    """bench.py must not fall back to any CPU path (the oracle is only its baseline leg)."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1"], capture_output=True, text=True,
+                       timeout=300)
+    assert p.returncode != 0 and "no GPU visible" in (p.stderr + p.stdout)
+    assert not any(l.startswith("{") for l in p.stdout.splitlines())

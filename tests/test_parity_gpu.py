@@ -309,9 +309,9 @@ def test_energy_drift_reported_and_small(manifest):
     assert drift < 5 * m["energy_drift"]["f64"] + 1e-6
 
 
-@pytest.mark.parametrize("n", [65536, 262144])
+@pytest.mark.parametrize("n", [65536, 262144, 1048576])
 def test_full_size_properties(n):
-    """BASELINE.json configs 2 and 3 at full size, through size-independent
+    """BASELINE.json configs 2, 3 and 4 (N=1,048,576) at full size, through size-independent
     properties (the oracle would take minutes): a sampled i-slice against the
     fp64 oracle, Newton's third law, and shard-composition (row blocks of a
     1/8 shard handle equal the full handle's rows)."""
