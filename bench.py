@@ -122,7 +122,10 @@ def main():
 
     import torch
     from nbody3d_amd import Simulation, capi, ic
-    from nbody3d_amd.shard import ShardPlan, torch_allgather_hook
+    if not os.path.exists(capi.library_path()) and rank == 0:
+        import __graft_entry__
+        __graft_entry__.build()       # fresh checkout: compile the engine (never a CPU fallback)
+    from nbody3d_amd.shard import ShardPlan, torch_allgather_hook, torch_allgather_overlapped_hooks
 
     if not torch.cuda.is_available() or capi.device_count() < 1:
         sys.exit("bench.py: no GPU visible -- the engine has no CPU fallback")
@@ -149,7 +152,10 @@ def main():
                                dtype=torch.float64 if args.precision == "f64" else torch.float32)
         sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count), stream=stream.cuda_stream,
                          ext_bodies=t_bodies.data_ptr(), **kw)
-        sim.set_exchange(torch_allgather_hook(t_bodies, plan))
+        if os.environ.get("NB_NO_OVERLAP"):
+            sim.set_exchange(torch_allgather_hook(t_bodies, plan))
+        else:   # all-gather of step n hidden behind the own-rows force work of step n+1
+            sim.set_exchange_overlapped(*torch_allgather_overlapped_hooks(t_bodies, plan))
     else:
         sim = Simulation(plan.padded_n, stream=stream.cuda_stream, **kw)
     sim.init(bodies_p, vel_p)
@@ -186,7 +192,8 @@ def main():
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "N=%d %s, dt=1e-3, G=1, eps2=1e-4, i-sharded over %d GPU(s)" % (
             n, "Plummer sphere" if args.workload == "plummer" else "uniform cube", world),
-            "n": n, "kernel_variant": sim.variant, "parallelism": "ishard%d+allgather" % world if world > 1 else "1gpu"},
+            "n": n, "kernel_variant": sim.variant, "parallelism": ("ishard%d+allgather%s" % (world, "" if os.environ.get("NB_NO_OVERLAP") else "(overlapped)"))
+                   if world > 1 else "1gpu"},
         "frac_of_fp32_roofline": value / (roof_pairs * world),
     }
     if launches:

@@ -153,6 +153,18 @@ typedef int (*nb_exchange_fn)(void *user, void *bodies_dev, size_t elem_size,
                               uint32_t shard_count, void *hip_stream);
 int nb_set_exchange(nb_sim *s, nb_exchange_fn fn, void *user);
 
+/* Overlapped (two-phase) exchange.  begin() is called where the one-phase hook
+ * would be (after the integrate kernel is enqueued) and must START the
+ * all-gather without making the engine stream wait for it; wait() is called
+ * before the engine enqueues work that reads other ranks' rows and must make
+ * `hip_stream` wait for the gather begin() started.  Between the two the engine
+ * enqueues the next step's force work on the j-range of its OWN rows (which the
+ * gather does not touch), hiding the collective behind 1/world of the force
+ * pass.  Falls back to calling wait() right after begin() when the j-splits do
+ * not line up with the shard boundaries.  Replaces any one-phase hook. */
+typedef int (*nb_exchange_wait_fn)(void *user, void *hip_stream);
+int nb_set_exchange_overlapped(nb_sim *s, nb_exchange_fn begin, nb_exchange_wait_fn wait, void *user);
+
 /* ---- measurement (role of TimingHelper, util.js:297-423) ------------------- */
 
 /* When enabled, each nb_step records HIP events around every force-kernel and

@@ -24,7 +24,9 @@ namespace {
 
 thread_local std::string g_create_error = "";
 
-struct EventTriple { hipEvent_t e0, e1, e2; };
+// e0..e1: force launch(es) issued before a pending gather is waited for (or the
+// only force launch); e3..e4: force launch issued after it; e1/e4..e2: integrate.
+struct EventTriple { hipEvent_t e0, e1, e2, e3, e4; bool two; };
 
 }  // namespace
 
@@ -50,7 +52,10 @@ struct nb_sim {
     uint32_t jsplit = 1, j_per_split = 0;
     std::string variant, err;
     nb_exchange_fn xfn = nullptr;
+    nb_exchange_wait_fn xwait = nullptr;   // non-null: two-phase (overlapped) exchange
     void* xuser = nullptr;
+    bool gather_pending = false;           // begin() called, wait() not yet
+    uint32_t own_split0 = 0, own_splits = 0;   // j-splits lying entirely inside this shard's rows
     bool timing = false;
     // HIP-graph replay of multi-step calls (launch-bound small N): kGraphChunk
     // [K1,K2] pairs captured once per (dt, G) and replayed
@@ -138,18 +143,34 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
     s->j_per_split = ceil_div(tiles, js) * nb::kTile;
     // a split may end up empty after rounding: shrink jsplit to what is used
     s->jsplit = ceil_div(n, s->j_per_split);
+    // j-splits that lie entirely inside this shard's own rows (overlapped exchange)
+    s->own_split0 = 0; s->own_splits = 0;
+    if (sc < n && s->sb % s->j_per_split == 0) {
+        const uint32_t end = s->sb + sc;
+        if (end % s->j_per_split == 0 || end == n) {
+            s->own_split0 = s->sb / s->j_per_split;
+            s->own_splits = ceil_div(end, s->j_per_split) - s->own_split0;
+        }
+    }
     char buf[96];
     snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.pk ? "pk" : "", nb::kTile, sh.ipl,
              sh.ls, s->jsplit);
     s->variant = buf;
 }
 
+// part: 0 = all splits, 1 = only the splits inside this shard's own rows,
+//       2 = all the others
 template <typename T>
-void launch_force(nb_sim* s)
+void launch_force(nb_sim* s, int part = 0)
 {
     using V4 = typename nb::vec4<T>::type;
     const uint32_t ipb = (nb::kBlock / s->ls) * s->ipl;
-    dim3 grid(ceil_div(s->sc, ipb), s->jsplit), block(nb::kBlock);
+    nb::SplitWindow win{0, 0xffffffffu, 0};
+    uint32_t ny = s->jsplit;
+    if (part == 1) { win.base = s->own_split0; ny = s->own_splits; }
+    else if (part == 2) { win.hole_begin = s->own_split0; win.hole_count = s->own_splits; ny = s->jsplit - s->own_splits; }
+    if (ny == 0) return;
+    dim3 grid(ceil_div(s->sc, ipb), ny), block(nb::kBlock);
     const V4* b = (const V4*)s->bodies;
     V4* p = (V4*)s->partial;
     const T G = (T)s->G, e2 = (T)s->eps2;
@@ -157,7 +178,7 @@ void launch_force(nb_sim* s)
         if (s->packed) {
 #define NB_LAUNCH_PK(NG)                                                                                            \
     hipLaunchKernelGGL((nb::nb_force_pk<NG, 1>), grid, block, 0, s->stream, b, p, s->n, s->sb, s->sc, G, e2,       \
-                       s->j_per_split)
+                       s->j_per_split, win)
             if (s->ipl == 2) NB_LAUNCH_PK(1);
             else if (s->ipl == 4) NB_LAUNCH_PK(2);
             else NB_LAUNCH_PK(4);
@@ -167,7 +188,7 @@ void launch_force(nb_sim* s)
     }
 #define NB_LAUNCH(IPL, LS)                                                                                      \
     hipLaunchKernelGGL((nb::nb_force<T, IPL, LS>), grid, block, 0, s->stream, b, p, s->n, s->sb, s->sc, G, e2, \
-                       s->j_per_split)
+                       s->j_per_split, win)
     if (s->ls == 1) {
         if (s->ipl == 1) NB_LAUNCH(1, 1);
         else if (s->ipl == 2) NB_LAUNCH(2, 1);
@@ -220,13 +241,26 @@ bool ensure_graph(nb_sim* s)
     return true;
 }
 
+// Makes the engine stream wait for an all-gather started by the two-phase hook.
+int finish_gather(nb_sim* s)
+{
+    if (!s->gather_pending) return NB_OK;
+    s->gather_pending = false;
+    if (!s->xwait) return NB_OK;
+    const int rc = s->xwait(s->xuser, (void*)s->stream);
+    if (rc != 0) return fail(s, NB_ERR_COMM, "exchange wait hook failed with code " + std::to_string(rc));
+    return NB_OK;
+}
+
 int get_events(nb_sim* s, EventTriple* out)
 {
     if (s->pool_next == s->pool.size()) {
         if (s->pool.size() >= 4096) return 1;   // stop recording, keep running
         EventTriple t;
+        t.two = false;
         if (hipEventCreate(&t.e0) != hipSuccess || hipEventCreate(&t.e1) != hipSuccess ||
-            hipEventCreate(&t.e2) != hipSuccess)
+            hipEventCreate(&t.e2) != hipSuccess || hipEventCreate(&t.e3) != hipSuccess ||
+            hipEventCreate(&t.e4) != hipSuccess)
             return 1;
         s->pool.push_back(t);
     }
@@ -321,9 +355,10 @@ void nb_destroy(nb_sim* s)
 {
     if (!s) return;
     (void)hipSetDevice(s->device);
+    (void)finish_gather(s);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
     drop_graph(s);
-    for (auto& t : s->pool) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); }
+    for (auto& t : s->pool) { (void)hipEventDestroy(t.e0); (void)hipEventDestroy(t.e1); (void)hipEventDestroy(t.e2); (void)hipEventDestroy(t.e3); (void)hipEventDestroy(t.e4); }
     if (s->own_bodies && s->bodies) (void)hipFree(s->bodies);
     if (s->vel) (void)hipFree(s->vel);
     if (s->acc) (void)hipFree(s->acc);
@@ -340,6 +375,7 @@ int nb_upload(nb_sim* s, const void* bodies, const void* vel, const void* accel)
     if (!s) return NB_ERR_INVALID;
     if (!bodies || !vel) return fail(s, NB_ERR_INVALID, "nb_upload: bodies and vel are required");
     NB_HIP(s, hipSetDevice(s->device));
+    if (int rc = finish_gather(s)) return rc;
     const size_t row = 4 * s->esz;
     // the reference's writeBuffer copies out of the typed array before returning
     // (nbody3d.js:186,193): synchronous copies, host pointers are not retained
@@ -379,15 +415,32 @@ int nb_step(nb_sim* s, uint32_t nsteps)
         EventTriple ev;
         const bool rec = s->timing && get_events(s, &ev) == 0;
         if (rec) NB_HIP(s, hipEventRecord(ev.e0, s->stream));
-        if (s->f64) launch_force<double>(s); else launch_force<float>(s);
-        if (rec) NB_HIP(s, hipEventRecord(ev.e1, s->stream));
+        if (s->gather_pending) {
+            // the previous step's all-gather is still in flight: own-row splits first
+            if (s->f64) launch_force<double>(s, 1); else launch_force<float>(s, 1);
+            if (rec) NB_HIP(s, hipEventRecord(ev.e1, s->stream));
+            if (int rc = finish_gather(s)) return rc;
+            if (rec) NB_HIP(s, hipEventRecord(ev.e3, s->stream));
+            if (s->f64) launch_force<double>(s, 2); else launch_force<float>(s, 2);
+            if (rec) { NB_HIP(s, hipEventRecord(ev.e4, s->stream)); ev.two = true; }
+        } else {
+            ev.two = false;
+            if (s->f64) launch_force<double>(s); else launch_force<float>(s);
+            if (rec) NB_HIP(s, hipEventRecord(ev.e1, s->stream));
+        }
         if (s->f64) launch_integrate<double>(s); else launch_integrate<float>(s);
-        if (rec) { NB_HIP(s, hipEventRecord(ev.e2, s->stream)); s->pending.push_back(ev); }
+        if (rec) NB_HIP(s, hipEventRecord(ev.e2, s->stream));
         NB_HIP(s, hipGetLastError());
         if (s->xfn) {
             int rc = s->xfn(s->xuser, s->bodies, s->esz, s->n, s->sb, s->sc, (void*)s->stream);
             if (rc != 0) return fail(s, NB_ERR_COMM, "nb_step: exchange hook failed with code " + std::to_string(rc));
+            if (s->xwait) {
+                s->gather_pending = true;
+                // nothing to overlap with: splits do not line up with the shard, or last step of the call
+                if (s->own_splits == 0) { if (int rc2 = finish_gather(s)) return rc2; }
+            }
         }
+        if (rec) s->pending.push_back(ev);
     }
     return NB_OK;
 }
@@ -396,6 +449,7 @@ int nb_sync(nb_sim* s)
 {
     if (!s) return NB_ERR_INVALID;
     NB_HIP(s, hipSetDevice(s->device));
+    if (int rc = finish_gather(s)) return rc;
     NB_HIP(s, hipStreamSynchronize(s->stream));
     return NB_OK;
 }
@@ -405,6 +459,7 @@ int nb_download(nb_sim* s, void* bodies, void* vel, void* accel)
     if (!s) return NB_ERR_INVALID;
     if (!s->uploaded) return fail(s, NB_ERR_STATE, "nb_download: nothing uploaded yet");
     NB_HIP(s, hipSetDevice(s->device));
+    if (int rc = finish_gather(s)) return rc;
     NB_HIP(s, hipStreamSynchronize(s->stream));
     const size_t row = 4 * s->esz;
     if (bodies) NB_HIP(s, hipMemcpy(bodies, s->bodies, row * s->n, hipMemcpyDeviceToHost));
@@ -428,7 +483,17 @@ int nb_device_ptr(nb_sim* s, int which, void** out)
 int nb_set_exchange(nb_sim* s, nb_exchange_fn fn, void* user)
 {
     if (!s) return NB_ERR_INVALID;
-    s->xfn = fn; s->xuser = user;
+    if (int rc = finish_gather(s)) return rc;
+    s->xfn = fn; s->xwait = nullptr; s->xuser = user;
+    return NB_OK;
+}
+
+int nb_set_exchange_overlapped(nb_sim* s, nb_exchange_fn begin, nb_exchange_wait_fn wait, void* user)
+{
+    if (!s) return NB_ERR_INVALID;
+    if (!begin || !wait) return fail(s, NB_ERR_INVALID, "nb_set_exchange_overlapped: both hooks are required");
+    if (int rc = finish_gather(s)) return rc;
+    s->xfn = begin; s->xwait = wait; s->xuser = user;
     return NB_OK;
 }
 
@@ -443,13 +508,19 @@ int nb_kernel_times(nb_sim* s, double* force_ms, double* integrate_ms, uint32_t*
 {
     if (!s) return NB_ERR_INVALID;
     NB_HIP(s, hipSetDevice(s->device));
+    if (int rc = finish_gather(s)) return rc;
     NB_HIP(s, hipStreamSynchronize(s->stream));
     double f = 0, g = 0;
     for (auto& ev : s->pending) {
-        float a = 0, b = 0;
+        float a = 0, b = 0, c = 0;
         NB_HIP(s, hipEventElapsedTime(&a, ev.e0, ev.e1));
-        NB_HIP(s, hipEventElapsedTime(&b, ev.e1, ev.e2));
-        f += a; g += b;
+        if (ev.two) {   // own-row splits, [gather wait], remaining splits
+            NB_HIP(s, hipEventElapsedTime(&c, ev.e3, ev.e4));
+            NB_HIP(s, hipEventElapsedTime(&b, ev.e4, ev.e2));
+        } else {
+            NB_HIP(s, hipEventElapsedTime(&b, ev.e1, ev.e2));
+        }
+        f += a + c; g += b;
     }
     const uint32_t cnt = (uint32_t)s->pending.size();
     if (force_ms) *force_ms = cnt ? f / cnt : 0.0;
@@ -467,6 +538,7 @@ int nb_diagnostics(nb_sim* s, double out[5])
     if (!s || !out) return NB_ERR_INVALID;
     if (!s->uploaded) return fail(s, NB_ERR_STATE, "nb_diagnostics: nothing uploaded yet");
     NB_HIP(s, hipSetDevice(s->device));
+    if (int rc = finish_gather(s)) return rc;
     dim3 grid(s->diag_blocks), block(nb::kBlock);
     if (s->f64)
         hipLaunchKernelGGL((nb::nb_diag<double>), grid, block, 0, s->stream, (const double4*)s->bodies,

@@ -58,6 +58,20 @@ __device__ __forceinline__ double nb_rsqrt(double x)
 __device__ __forceinline__ float nb_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double nb_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
+// Which j-splits a launch covers.  A launch normally covers all of them
+// (base 0, no hole).  The overlapped multi-GPU step issues the splits that lie
+// inside the rank's OWN rows first (base = first own split) and, once the
+// all-gather of the other ranks' rows has landed, the rest (hole = own splits).
+struct SplitWindow {
+    uint32_t base, hole_begin, hole_count;
+    __device__ __forceinline__ uint32_t split(uint32_t y) const
+    {
+        uint32_t b = y + base;
+        if (b >= hole_begin) b += hole_count;
+        return b;
+    }
+};
+
 // One pair: nbody3d.js:232-237 with b.w already multiplied by G at staging
 // time ((G*m)*inv is the reference's left-associated product, :236).
 template <typename T>
@@ -79,10 +93,11 @@ template <typename T, int IPL, int LS>
 __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type* __restrict__ bodies,
                                                   typename vec4<T>::type* __restrict__ partial, uint32_t n,
                                                   uint32_t i_begin, uint32_t i_count, T G, T eps2,
-                                                  uint32_t j_per_split)
+                                                  uint32_t j_per_split, SplitWindow win)
 {
     using V4 = typename vec4<T>::type;
     static_assert(LS >= 1 && LS <= 64 && (LS & (LS - 1)) == 0, "LS must be a power of two <= 64");
+    const uint32_t by = win.split(blockIdx.y);
     constexpr int GROUPS = kBlock / LS;    // i-groups per block per k
     constexpr int IPB = GROUPS * IPL;      // i-bodies per block
     __shared__ V4 tile[2][kTile];
@@ -101,7 +116,7 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
         ax[k] = 0; ay[k] = 0; az[k] = 0;
     }
 
-    const uint32_t j0 = blockIdx.y * j_per_split;
+    const uint32_t j0 = by * j_per_split;
     uint32_t j1 = j0 + j_per_split;
     if (j1 > n) j1 = n;
     const uint32_t ntiles = (j1 > j0) ? (j1 - j0 + kTile - 1) / kTile : 0;
@@ -147,7 +162,7 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
 #pragma unroll
         for (int k = 0; k < IPL; ++k) {
             const uint32_t il = blockIdx.x * IPB + k * GROUPS + grp;
-            if (il < i_count) partial[(size_t)blockIdx.y * i_count + il] = V4{ax[k], ay[k], az[k], 0};
+            if (il < i_count) partial[(size_t)by * i_count + il] = V4{ax[k], ay[k], az[k], 0};
         }
     }
 }
@@ -171,9 +186,10 @@ template <int NG, int LS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NG >= 4 ? 4 : (NG == 2 ? 6 : 8), NG >= 4 ? 4 : (NG == 2 ? 6 : 8))))
 void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial,
                                                      uint32_t n, uint32_t i_begin, uint32_t i_count, float G,
-                                                     float eps2, uint32_t j_per_split)
+                                                     float eps2, uint32_t j_per_split, SplitWindow win)
 {
     static_assert(LS >= 1 && LS <= 64 && (LS & (LS - 1)) == 0, "LS must be a power of two <= 64");
+    const uint32_t by = win.split(blockIdx.y);
     constexpr int IPL = 2 * NG;
     constexpr int GROUPS = kBlock / LS;
     constexpr int IPB = GROUPS * IPL;
@@ -196,7 +212,7 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
     }
     const nb_f2 e2 = nb_f2{eps2, eps2};
 
-    const uint32_t j0 = blockIdx.y * j_per_split;
+    const uint32_t j0 = by * j_per_split;
     uint32_t j1 = j0 + j_per_split;
     if (j1 > n) j1 = n;
     const uint32_t ntiles = (j1 > j0) ? (j1 - j0 + kTile - 1) / kTile : 0;
@@ -280,7 +296,7 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
         for (int g = 0; g < NG; ++g) {
             const uint32_t il0 = blockIdx.x * IPB + (2 * g) * GROUPS + grp;
             const uint32_t il1 = il0 + GROUPS;
-            float4* out = partial + (size_t)blockIdx.y * i_count;
+            float4* out = partial + (size_t)by * i_count;
             if (il0 < i_count) out[il0] = float4{ax[g].x, ay[g].x, az[g].x, 0};
             if (il1 < i_count) out[il1] = float4{ax[g].y, ay[g].y, az[g].y, 0};
         }

@@ -39,10 +39,12 @@ class nb_config(C.Structure):
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
+EXCHANGE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 # every symbol include/nbody3d_hip.h declares (tests check the export list)
 SYMBOLS = ["nb_abi_version", "nb_device_count", "nb_create", "nb_destroy", "nb_upload", "nb_set_params", "nb_step",
-           "nb_download", "nb_sync", "nb_last_error", "nb_device_ptr", "nb_set_exchange", "nb_enable_timing",
+           "nb_download", "nb_sync", "nb_last_error", "nb_device_ptr", "nb_set_exchange",
+           "nb_set_exchange_overlapped", "nb_enable_timing",
            "nb_kernel_times", "nb_variant_name", "nb_diagnostics"]
 
 _lib = None
@@ -76,6 +78,7 @@ def load_library():
     L.nb_last_error.restype = C.c_char_p
     L.nb_device_ptr.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.nb_set_exchange.argtypes = [vp, EXCHANGE_FN, vp]
+    L.nb_set_exchange_overlapped.argtypes = [vp, EXCHANGE_FN, EXCHANGE_WAIT_FN, vp]
     L.nb_enable_timing.argtypes = [vp, C.c_int]
     L.nb_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.nb_variant_name.argtypes = [vp]
@@ -219,6 +222,28 @@ class Simulation:
 
         self._hook = EXCHANGE_FN(tramp)  # keep alive
         self._check(self._L.nb_set_exchange(self._h, self._hook, None))
+
+    def set_exchange_overlapped(self, begin, wait):
+        """Two-phase hook (nb_set_exchange_overlapped): begin(bodies_ptr, esz, n, sb, sc,
+        stream) starts the all-gather, wait(stream) makes the stream wait for it."""
+        def t_begin(user, bodies, esz, n, sb, sc, stream):
+            try:
+                return int(begin(bodies, esz, n, sb, sc, stream) or 0)
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        def t_wait(user, stream):
+            try:
+                return int(wait(stream) or 0)
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return -1
+
+        self._hook = (EXCHANGE_FN(t_begin), EXCHANGE_WAIT_FN(t_wait))  # keep alive
+        self._check(self._L.nb_set_exchange_overlapped(self._h, self._hook[0], self._hook[1], None))
 
     def enable_timing(self, on=True):
         self._check(self._L.nb_enable_timing(self._h, 1 if on else 0))

@@ -65,3 +65,28 @@ def torch_allgather_hook(bodies_tensor, plan, group=None):
         return 0
 
     return hook
+
+
+def torch_allgather_overlapped_hooks(bodies_tensor, plan, group=None):
+    """(begin, wait) for Simulation.set_exchange_overlapped: the all-gather is issued
+    with async_op=True right after the integrate kernel; the engine then enqueues
+    the next step's force work on the j-range of its OWN rows (which the in-place
+    gather does not write) and only then calls wait(), which makes the current
+    stream wait for the collective.  Hides the collective behind 1/world of the
+    force pass ("hide it by starting K1 on the rank's own j-block")."""
+    import torch.distributed as dist
+
+    mine = bodies_tensor[plan.begin: plan.begin + plan.count]
+    state = {"work": None}
+
+    def begin(bodies_ptr, esz, n, sb, sc, stream):
+        state["work"] = dist.all_gather_into_tensor(bodies_tensor, mine, group=group, async_op=True)
+        return 0
+
+    def wait(stream):
+        w, state["work"] = state["work"], None
+        if w is not None:
+            w.wait()
+        return 0
+
+    return begin, wait

@@ -255,6 +255,63 @@ def test_shards_on_one_device_compose_to_the_single_handle_result():
     assert vel.tobytes() == ref[1].tobytes() and acc.tobytes() == ref[2].tobytes()
 
 
+@pytest.mark.parametrize("g", [2, 4])
+def test_overlapped_exchange_with_virtual_shards(g):
+    """nb_set_exchange_overlapped on ONE GPU: g shard handles, each with its own
+    torch-owned bodies buffer; wait() copies the other shards' rows (as they
+    were before this step) on the engine's stream -- what the all-gather does.
+    The own-rows-first / rest-after-wait split must reproduce the unsharded
+    handle bit for bit."""
+    import torch
+    n, steps = 4096, 6
+    per = n // g
+    b, v = ic.plummer(n, seed=22)
+    kw = dict(force_variant=22, jsplit=8)             # j_per_split = 512 divides the shard rows
+    with Simulation(n, **kw) as one:
+        one.init(b, v)
+        one.simulate(steps, 1e-3, 1.0)
+        ref = one.read()
+    stream = torch.cuda.current_stream().cuda_stream
+    bufs = [torch.empty((n, 4), device="cuda", dtype=torch.float32) for _ in range(g)]
+    sims = [Simulation(n, shard=(r * per, per), stream=stream, ext_bodies=bufs[r].data_ptr(), **kw) for r in range(g)]
+    snap = {}
+    calls = {"begin": 0, "wait": 0}
+    try:
+        for r, s in enumerate(sims):
+            s.init(b, v)
+            s.set_params(1e-3, 1.0)
+
+            def begin(ptr, esz, nn, sb, sc, st, r=r):
+                calls["begin"] += 1
+                return 0
+
+            def wait(st, r=r):
+                calls["wait"] += 1
+                for q in range(g):
+                    if q != r:
+                        bufs[r][q * per:(q + 1) * per].copy_(snap[q])   # rows of rank q after the previous step
+                return 0
+
+            s.set_exchange_overlapped(begin, wait)
+        for k in range(steps):
+            # what every rank's rows look like after step k-1 (gathered during step k)
+            snap = {q: bufs[q][q * per:(q + 1) * per].clone() for q in range(g)}
+            for s in sims:
+                s.step()
+        for s in sims:
+            s.sync()                                   # finishes the last pending "gather"
+        bodies = np.concatenate([bufs[r][r * per:(r + 1) * per].cpu().numpy() for r in range(g)])
+        vel = np.zeros((n, 4), np.float32)
+        for r, s in enumerate(sims):
+            vel[r * per:(r + 1) * per] = s.read(bodies=False, accel=False)[1][r * per:(r + 1) * per]
+    finally:
+        for s in sims:
+            s.close()
+    assert calls["begin"] == g * steps and calls["wait"] == g * steps
+    assert bodies.tobytes() == ref[0].tobytes()
+    assert vel.tobytes() == ref[1].tobytes()
+
+
 def test_exchange_hook_is_called_once_per_step():
     b, v = ic.plummer(512, seed=16)
     calls = []
