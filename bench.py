@@ -169,6 +169,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    e_start = None
+    if world == 1 and dist is None and not args.no_check:
+        ke0, pe0, _ = sim.diagnostics()          # fp64 on the device; outside the timed region
+        e_start = ke0 + pe0
     sim.simulate(args.warmup)
     barrier()
     sim.enable_timing(True)
@@ -217,6 +221,14 @@ def main():
                                    "dense f32 MFMA peak); not HBM and not MFMA: rsqrt-bound scalar FMA",
                            "integrate_kernel_avg_ms": i_ms,
                            "integrate_kernel_GBps": 96.0 * plan.count / (i_ms * 1e-3) / 1e9 if i_ms > 0 else None}
+    if e_start is not None:
+        # total-energy drift of THIS run (north_star: "with total-energy drift reported"): one extra
+        # untimed step so that KE(vel after call n) pairs with PE(positions before call n)
+        _, pe_prev, _ = sim.diagnostics()
+        sim.step()
+        ke, _, _ = sim.diagnostics()
+        out["energy_drift_over_run"] = {"steps": args.warmup + args.steps + 1,
+                                        "dE_rel": abs((ke + pe_prev - e_start) / e_start)}
     if rank == 0 and world == 1 and not args.no_check:
         out["check"] = fixture_check()
     sim.close()

@@ -94,7 +94,7 @@ uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 //     (8, 4, 2 bodies per lane) that still reaches 1024 workgroups with the
 //     j-split available; below that the scalar kernel lets LS = 4/16/64 lanes
 //     share one body (shuffle-reduced), which multiplies the i-blocks by LS.
-//   * j-side: split over blockIdx.y, at most one split per 256-body tile, <= 64.
+//   * j-side: split over blockIdx.y, at most one split per 256-body tile, <= 128.
 struct Shape { int ipl, ls; bool pk; };
 
 void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)

@@ -71,6 +71,18 @@ def test_golden_trajectories(manifest, name, steps, variant, jsplit):
     assert np.abs(vv[:, :3] - v32[:, :3]).max() < 1e-4 * np.abs(v32[:, :3]).max()
 
 
+def test_mid_size_trajectory_against_fp64_oracle():
+    """N=8,192 Plummer, 20 steps, packed kernel with a j-split, against the fp64 oracle
+    run live (1.3e9 pair evaluations on the host cores)."""
+    n, steps = 8192, 20
+    b, v = ic.plummer(n, seed=23)
+    bb, vv, aa, name = run_engine(b, v, 1e-3, 1.0, steps, force_variant=24, jsplit=8)
+    rb, rv, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, steps)
+    assert rel_pos_err(bb, rb, 1.0) < TOL_TIGHT, name
+    assert np.abs(aa[:, :3] - ra[:, :3]).max() < TOL_ACC * np.abs(ra[:, :3]).max(), name
+    assert np.abs(vv[:, :3] - rv[:, :3]).max() < TOL_TIGHT * max(np.abs(rv[:, :3]).max(), 1.0), name
+
+
 def test_intermediate_checkpoints_and_restore(manifest):
     """read() then restore() mid-run (util.js:163-178 / :230-244 round trip)
     continues exactly as an uninterrupted run."""
