@@ -165,6 +165,30 @@ int nb_set_exchange(nb_sim *s, nb_exchange_fn fn, void *user);
 typedef int (*nb_exchange_wait_fn)(void *user, void *hip_stream);
 int nb_set_exchange_overlapped(nb_sim *s, nb_exchange_fn begin, nb_exchange_wait_fn wait, void *user);
 
+/* ---- single-process multi-device (for hosts that cannot run one process per
+ *      GPU, e.g. Node; no reference analogue) --------------------------------
+ * nb_multi_* wraps n_shards shard handles: shard k owns a contiguous block of
+ * rows (256-aligned; the system is padded with zero-mass rows at the origin,
+ * which exert and feel exactly nothing) on device devices[k].  After every
+ * step each shard's new rows are copied straight into every other shard's
+ * replicated bodies array (g*(g-1) device-to-device copies, ordered with HIP
+ * events): on the fully connected xGMI fabric of an 8-GPU node every copy has
+ * its own link, which is the all-gather the topology wants.  devices == NULL
+ * -> round-robin over the visible devices; several shards may share a device
+ * ("virtual shards": the way the partition logic is tested on one GPU).
+ * Host arrays hold the UNPADDED n rows, exactly as for a single handle. */
+typedef struct nb_multi nb_multi; /* opaque */
+int nb_multi_create(const nb_config *cfg, uint32_t n_shards, const int32_t *devices, nb_multi **out);
+void nb_multi_destroy(nb_multi *m);
+int nb_multi_upload(nb_multi *m, const void *bodies, const void *vel, const void *accel);
+int nb_multi_set_params(nb_multi *m, double dt, double G);
+int nb_multi_step(nb_multi *m, uint32_t nsteps);
+int nb_multi_download(nb_multi *m, void *bodies, void *vel, void *accel);
+int nb_multi_sync(nb_multi *m);
+const char *nb_multi_last_error(nb_multi *m);
+/* Name of shard 0's force-kernel variant (all shards resolve to the same shape). */
+const char *nb_multi_variant_name(nb_multi *m);
+
 /* ---- measurement (role of TimingHelper, util.js:297-423) ------------------- */
 
 /* When enabled, each nb_step records HIP events around every force-kernel and

@@ -556,4 +556,205 @@ int nb_diagnostics(nb_sim* s, double out[5])
     return NB_OK;
 }
 
+/* ------------------------------------------------------------------------- *
+ * nb_multi: g shard handles in one process, peer-copy all-gather             *
+ * ------------------------------------------------------------------------- */
+}  // extern "C" (nb_multi struct below needs C++ members)
+
+struct nb_multi {
+    uint32_t n = 0, rows = 0, padded_n = 0, g = 0;
+    size_t esz = 4;
+    std::vector<nb_sim*> shard;
+    std::vector<hipEvent_t> ev_k2, ev_copied;   // per shard: "own rows written", "all foreign rows received"
+    bool copied_pending = false;
+    std::vector<char> pad_b, pad_v, pad_a;       // host staging for the zero-mass padding rows
+    std::string err;
+};
+
+namespace {
+
+int mfail(nb_multi* m, int code, const std::string& msg) { if (m) m->err = msg; else g_create_error = msg; return code; }
+
+#define NB_MHIP(m, call)                                                                              \
+    do {                                                                                              \
+        hipError_t e_ = (call);                                                                       \
+        if (e_ != hipSuccess) return mfail((m), NB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+}  // namespace
+
+extern "C" {
+
+int nb_multi_create(const nb_config* cfg_in, uint32_t n_shards, const int32_t* devices, nb_multi** out)
+{
+    if (out) *out = nullptr;
+    if (!cfg_in || !out || n_shards == 0) return mfail(nullptr, NB_ERR_INVALID, "nb_multi_create: bad argument");
+    if (cfg_in->struct_size < offsetof(nb_config, reserved))
+        return mfail(nullptr, NB_ERR_INVALID, "nb_multi_create: struct_size too small");
+    nb_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    memcpy(&cfg, cfg_in, cfg_in->struct_size < sizeof cfg ? cfg_in->struct_size : sizeof cfg);
+    if (cfg.n == 0) return mfail(nullptr, NB_ERR_INVALID, "nb_multi_create: n must be >= 1");
+    if (cfg.shard_count || cfg.ext_bodies || cfg.ext_stream)
+        return mfail(nullptr, NB_ERR_INVALID, "nb_multi_create: shard/ext_* fields are managed by the multi handle");
+    const int count = nb_device_count();
+    if (count <= 0) return mfail(nullptr, NB_ERR_NO_DEVICE, "nb_multi_create: no HIP device; this engine has no CPU fallback");
+    nb_multi* m = new (std::nothrow) nb_multi;
+    if (!m) return mfail(nullptr, NB_ERR_NOMEM, "nb_multi_create: out of host memory");
+    m->n = cfg.n; m->g = n_shards;
+    m->esz = cfg.precision == NB_F64 ? 8 : 4;
+    uint32_t rows = ceil_div(cfg.n, n_shards);
+    rows = ceil_div(rows, (uint32_t)nb::kTile) * nb::kTile;     // 256-aligned blocks (reference tile, nbody3d.js:4)
+    m->rows = rows; m->padded_n = rows * n_shards;
+    for (uint32_t k = 0; k < n_shards; ++k) {
+        nb_config c = cfg;
+        c.struct_size = sizeof c;
+        c.n = m->padded_n;
+        c.shard_begin = k * rows; c.shard_count = rows;
+        c.device = devices ? devices[k] : (int32_t)(k % (uint32_t)count);
+        nb_sim* s = nullptr;
+        int rc = nb_create(&c, &s);
+        if (rc != NB_OK) { std::string e = g_create_error; nb_multi_destroy(m); return mfail(nullptr, rc, "nb_multi_create: shard " + std::to_string(k) + ": " + e); }
+        m->shard.push_back(s);
+    }
+    // peer access between every pair of distinct devices (ignore "already enabled")
+    for (uint32_t a = 0; a < n_shards; ++a)
+        for (uint32_t b = 0; b < n_shards; ++b) {
+            const int da = m->shard[a]->device, db = m->shard[b]->device;
+            if (da == db) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) {
+                (void)hipSetDevice(da);
+                hipError_t e = hipDeviceEnablePeerAccess(db, 0);
+                if (e != hipSuccess) (void)hipGetLastError();   // hipErrorPeerAccessAlreadyEnabled is fine
+            }
+        }
+    m->ev_k2.resize(n_shards); m->ev_copied.resize(n_shards);
+    for (uint32_t k = 0; k < n_shards; ++k) {
+        if (hipSetDevice(m->shard[k]->device) != hipSuccess ||
+            hipEventCreateWithFlags(&m->ev_k2[k], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&m->ev_copied[k], hipEventDisableTiming) != hipSuccess) {
+            nb_multi_destroy(m);
+            return mfail(nullptr, NB_ERR_HIP, "nb_multi_create: event creation failed");
+        }
+    }
+    *out = m;
+    return NB_OK;
+}
+
+void nb_multi_destroy(nb_multi* m)
+{
+    if (!m) return;
+    for (size_t k = 0; k < m->shard.size(); ++k) {
+        (void)hipSetDevice(m->shard[k]->device);
+        (void)hipStreamSynchronize(m->shard[k]->stream);
+    }
+    for (size_t k = 0; k < m->ev_k2.size(); ++k) {
+        if (k < m->shard.size()) (void)hipSetDevice(m->shard[k]->device);
+        if (m->ev_k2[k]) (void)hipEventDestroy(m->ev_k2[k]);
+        if (m->ev_copied[k]) (void)hipEventDestroy(m->ev_copied[k]);
+    }
+    for (nb_sim* s : m->shard) nb_destroy(s);
+    delete m;
+}
+
+const char* nb_multi_last_error(nb_multi* m) { return m ? m->err.c_str() : g_create_error.c_str(); }
+const char* nb_multi_variant_name(nb_multi* m) { return (m && !m->shard.empty()) ? m->shard[0]->variant.c_str() : ""; }
+
+int nb_multi_sync(nb_multi* m)
+{
+    if (!m) return NB_ERR_INVALID;
+    for (nb_sim* s : m->shard) { int rc = nb_sync(s); if (rc != NB_OK) return mfail(m, rc, s->err); }
+    return NB_OK;
+}
+
+int nb_multi_upload(nb_multi* m, const void* bodies, const void* vel, const void* accel)
+{
+    if (!m) return NB_ERR_INVALID;
+    if (!bodies || !vel) return mfail(m, NB_ERR_INVALID, "nb_multi_upload: bodies and vel are required");
+    if (int rc = nb_multi_sync(m)) return rc;
+    m->copied_pending = false;
+    const size_t row = 4 * m->esz, real = row * m->n, padded = row * m->padded_n;
+    const void *b = bodies, *v = vel, *a = accel;
+    if (m->padded_n != m->n) {     // zero-mass rows at the origin, zero velocity
+        m->pad_b.assign(padded, 0); memcpy(m->pad_b.data(), bodies, real); b = m->pad_b.data();
+        m->pad_v.assign(padded, 0); memcpy(m->pad_v.data(), vel, real); v = m->pad_v.data();
+        if (accel) { m->pad_a.assign(padded, 0); memcpy(m->pad_a.data(), accel, real); a = m->pad_a.data(); }
+    }
+    for (nb_sim* s : m->shard) { int rc = nb_upload(s, b, v, a); if (rc != NB_OK) return mfail(m, rc, s->err); }
+    return NB_OK;
+}
+
+int nb_multi_set_params(nb_multi* m, double dt, double G)
+{
+    if (!m) return NB_ERR_INVALID;
+    for (nb_sim* s : m->shard) { int rc = nb_set_params(s, dt, G); if (rc != NB_OK) return mfail(m, rc, s->err); }
+    return NB_OK;
+}
+
+int nb_multi_step(nb_multi* m, uint32_t nsteps)
+{
+    if (!m) return NB_ERR_INVALID;
+    const uint32_t g = m->g;
+    const size_t row = 4 * m->esz, blk = row * m->rows;
+    if (g == 1) { int rc = nb_step(m->shard[0], nsteps); return rc == NB_OK ? rc : mfail(m, rc, m->shard[0]->err); }
+    if (!m->shard[0]->params_set || !(m->shard[0]->dt > 0.0)) {
+        int rc = nb_step(m->shard[0], 0);      // reports state errors; dt <= 0 is the reference's no-op gate
+        return rc == NB_OK ? rc : mfail(m, rc, m->shard[0]->err);
+    }
+    for (uint32_t k = 0; k < nsteps; ++k) {
+        // force + integrate on every shard (asynchronous on the shard's own stream)
+        for (uint32_t d = 0; d < g; ++d) {
+            nb_sim* s = m->shard[d];
+            NB_MHIP(m, hipSetDevice(s->device));
+            if (m->copied_pending)      // nobody may still be reading the rows this shard is about to overwrite
+                for (uint32_t e = 0; e < g; ++e)
+                    if (e != d) NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_copied[e], 0));
+            int rc = nb_step(s, 1);
+            if (rc != NB_OK) return mfail(m, rc, s->err);
+            NB_MHIP(m, hipEventRecord(m->ev_k2[d], s->stream));
+        }
+        // all-gather by direct copies: shard e pulls the new rows of every other shard d
+        for (uint32_t e = 0; e < g; ++e) {
+            nb_sim* dst = m->shard[e];
+            NB_MHIP(m, hipSetDevice(dst->device));
+            for (uint32_t d = 0; d < g; ++d) {
+                if (d == e) continue;
+                nb_sim* src = m->shard[d];
+                NB_MHIP(m, hipStreamWaitEvent(dst->stream, m->ev_k2[d], 0));
+                NB_MHIP(m, hipMemcpyAsync((char*)dst->bodies + blk * d, (const char*)src->bodies + blk * d, blk,
+                                          hipMemcpyDeviceToDevice, dst->stream));
+            }
+            NB_MHIP(m, hipEventRecord(m->ev_copied[e], dst->stream));
+        }
+        m->copied_pending = true;
+    }
+    return NB_OK;
+}
+
+int nb_multi_download(nb_multi* m, void* bodies, void* vel, void* accel)
+{
+    if (!m) return NB_ERR_INVALID;
+    if (int rc = nb_multi_sync(m)) return rc;
+    const size_t row = 4 * m->esz, real = row * m->n, padded = row * m->padded_n;
+    const bool pad = m->padded_n != m->n;
+    void *b = bodies, *v = vel, *a = accel;
+    if (pad) {
+        if (bodies) { m->pad_b.assign(padded, 0); b = m->pad_b.data(); }
+        if (vel) { m->pad_v.assign(padded, 0); v = m->pad_v.data(); }
+        if (accel) { m->pad_a.assign(padded, 0); a = m->pad_a.data(); }
+    }
+    for (uint32_t k = 0; k < m->g; ++k) {
+        // bodies: every shard holds the full array; take it from shard 0 only
+        int rc = nb_download(m->shard[k], k == 0 ? b : nullptr, v, a);
+        if (rc != NB_OK) return mfail(m, rc, m->shard[k]->err);
+    }
+    if (pad) {
+        if (bodies) memcpy(bodies, b, real);
+        if (vel) memcpy(vel, v, real);
+        if (accel) memcpy(accel, a, real);
+    }
+    return NB_OK;
+}
+
 }  // extern "C"

@@ -39,8 +39,18 @@ static int (*p_enable_timing)(nb_sim *, int);
 static int (*p_kernel_times)(nb_sim *, double *, double *, uint32_t *);
 static const char *(*p_variant_name)(nb_sim *);
 static int (*p_diagnostics)(nb_sim *, double *);
+static int (*p_multi_create)(const nb_config *, uint32_t, const int32_t *, nb_multi **);
+static void (*p_multi_destroy)(nb_multi *);
+static int (*p_multi_upload)(nb_multi *, const void *, const void *, const void *);
+static int (*p_multi_set_params)(nb_multi *, double, double);
+static int (*p_multi_step)(nb_multi *, uint32_t);
+static int (*p_multi_download)(nb_multi *, void *, void *, void *);
+static int (*p_multi_sync)(nb_multi *);
+static const char *(*p_multi_last_error)(nb_multi *);
+static const char *(*p_multi_variant_name)(nb_multi *);
 
-typedef struct { nb_sim *sim; uint32_t n; int f64; } handle_t;
+/* one JS handle = a single-device nb_sim or a single-process multi-device nb_multi */
+typedef struct { nb_sim *sim; nb_multi *multi; uint32_t n; int f64; } handle_t;
 
 #define CHECK_NAPI(env, call)                                                        \
     do {                                                                             \
@@ -49,6 +59,16 @@ typedef struct { nb_sim *sim; uint32_t n; int f64; } handle_t;
             return NULL;                                                             \
         }                                                                            \
     } while (0)
+
+static napi_value throw_msg(napi_env env, int code, const char *msg, const char *where)
+{
+    char buf[768];
+    snprintf(buf, sizeof buf, "%s: status %d: %s", where, code, msg ? msg : "");
+    char codes[16];
+    snprintf(codes, sizeof codes, "NB_%d", code);
+    napi_throw_error(env, codes, buf);
+    return NULL;
+}
 
 static napi_value throw_nb(napi_env env, int code, nb_sim *s, const char *where)
 {
@@ -95,6 +115,11 @@ static napi_value js_load(napi_env env, napi_callback_info info)
         SYM(p_sync, "nb_sync"); SYM(p_last_error, "nb_last_error"); SYM(p_enable_timing, "nb_enable_timing");
         SYM(p_kernel_times, "nb_kernel_times"); SYM(p_variant_name, "nb_variant_name");
         SYM(p_diagnostics, "nb_diagnostics");
+        SYM(p_multi_create, "nb_multi_create"); SYM(p_multi_destroy, "nb_multi_destroy");
+        SYM(p_multi_upload, "nb_multi_upload"); SYM(p_multi_set_params, "nb_multi_set_params");
+        SYM(p_multi_step, "nb_multi_step"); SYM(p_multi_download, "nb_multi_download");
+        SYM(p_multi_sync, "nb_multi_sync"); SYM(p_multi_last_error, "nb_multi_last_error");
+        SYM(p_multi_variant_name, "nb_multi_variant_name");
 #undef SYM
         g_lib = h;
     }
@@ -113,7 +138,11 @@ static void finalize_handle(napi_env env, void *data, void *hint)
 {
     (void)env; (void)hint;
     handle_t *h = (handle_t *)data;
-    if (h) { if (h->sim && p_destroy) p_destroy(h->sim); free(h); }
+    if (h) {
+        if (h->sim && p_destroy) p_destroy(h->sim);
+        if (h->multi && p_multi_destroy) p_multi_destroy(h->multi);
+        free(h);
+    }
 }
 
 static int get_u32_prop(napi_env env, napi_value obj, const char *name, uint32_t *out)
@@ -156,12 +185,21 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     if (get_u32_prop(env, argv[0], "variant", &u)) cfg.force_variant = u;
     if (get_u32_prop(env, argv[0], "jsplit", &u)) cfg.jsplit = u;
     if (get_u32_prop(env, argv[0], "tile", &u)) cfg.tile = u;
+    uint32_t shards = 0;
+    get_u32_prop(env, argv[0], "shards", &shards);
     nb_sim *sim = NULL;
-    int rc = p_create(&cfg, &sim);
-    if (rc != NB_OK) return throw_nb(env, rc, NULL, "nb_create");
+    nb_multi *multi = NULL;
+    if (shards > 1) {   /* single-process multi-device: shards round-robin over the visible GPUs */
+        cfg.device = -1; cfg.shard_begin = cfg.shard_count = 0;
+        int rc = p_multi_create(&cfg, shards, NULL, &multi);
+        if (rc != NB_OK) return throw_msg(env, rc, p_multi_last_error(NULL), "nb_multi_create");
+    } else {
+        int rc = p_create(&cfg, &sim);
+        if (rc != NB_OK) return throw_nb(env, rc, NULL, "nb_create");
+    }
     handle_t *h = (handle_t *)calloc(1, sizeof *h);
-    if (!h) { p_destroy(sim); napi_throw_error(env, NULL, "out of memory"); return NULL; }
-    h->sim = sim; h->n = cfg.n; h->f64 = cfg.precision == NB_F64;
+    if (!h) { if (sim) p_destroy(sim); if (multi) p_multi_destroy(multi); napi_throw_error(env, NULL, "out of memory"); return NULL; }
+    h->sim = sim; h->multi = multi; h->n = cfg.n; h->f64 = cfg.precision == NB_F64;
     napi_value ext;
     if (napi_create_external(env, h, finalize_handle, NULL, &ext) != napi_ok) {
         finalize_handle(env, h, NULL); napi_throw_error(env, NULL, "napi_create_external failed"); return NULL;
@@ -172,7 +210,7 @@ static napi_value js_create(napi_env env, napi_callback_info info)
 static handle_t *get_handle(napi_env env, napi_value v)
 {
     void *p = NULL;
-    if (napi_get_value_external(env, v, &p) != napi_ok || !p || !((handle_t *)p)->sim) {
+    if (napi_get_value_external(env, v, &p) != napi_ok || !p || (!((handle_t *)p)->sim && !((handle_t *)p)->multi)) {
         napi_throw_error(env, "NB_1", "invalid or destroyed simulation handle"); return NULL;
     }
     return (handle_t *)p;
@@ -212,6 +250,11 @@ static napi_value js_upload(napi_env env, napi_callback_info info)
     if (!get_array(env, argv[1], h, 0, &b, "bodies must be a typed array of 4*n elements")) return NULL;
     if (!get_array(env, argv[2], h, 0, &v, "vel must be a typed array of 4*n elements")) return NULL;
     if (argc >= 4 && !get_array(env, argv[3], h, 1, &a, "accel must be a typed array of 4*n elements or null")) return NULL;
+    if (h->multi) {
+        int rc = p_multi_upload(h->multi, b, v, a);
+        if (rc != NB_OK) return throw_msg(env, rc, p_multi_last_error(h->multi), "nb_multi_upload");
+        return undefined(env);
+    }
     int rc = p_upload(h->sim, b, v, a);
     if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_upload");
     return undefined(env);
@@ -227,6 +270,11 @@ static napi_value js_set_params(napi_env env, napi_callback_info info)
     if (napi_get_value_double(env, argv[1], &dt) != napi_ok || napi_get_value_double(env, argv[2], &G) != napi_ok) {
         napi_throw_type_error(env, NULL, "dt and G must be numbers"); return NULL;
     }
+    if (h->multi) {
+        int rc = p_multi_set_params(h->multi, dt, G);
+        if (rc != NB_OK) return throw_msg(env, rc, p_multi_last_error(h->multi), "nb_multi_set_params");
+        return undefined(env);
+    }
     int rc = p_set_params(h->sim, dt, G);
     if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_set_params");
     return undefined(env);
@@ -240,6 +288,11 @@ static napi_value js_step(napi_env env, napi_callback_info info)
     handle_t *h = get_handle(env, argv[0]); if (!h) return NULL;
     uint32_t n = 1;
     if (argc >= 2) { double d; if (napi_get_value_double(env, argv[1], &d) == napi_ok && d >= 0) n = (uint32_t)d; }
+    if (h->multi) {
+        int rc = p_multi_step(h->multi, n);
+        if (rc != NB_OK) return throw_msg(env, rc, p_multi_last_error(h->multi), "nb_multi_step");
+        return undefined(env);
+    }
     int rc = p_step(h->sim, n);
     if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_step");
     return undefined(env);
@@ -255,6 +308,11 @@ static napi_value js_download(napi_env env, napi_callback_info info)
     if (!get_array(env, argv[1], h, 1, &b, "bodies: typed array of 4*n elements or null")) return NULL;
     if (!get_array(env, argv[2], h, 1, &v, "vel: typed array of 4*n elements or null")) return NULL;
     if (!get_array(env, argv[3], h, 1, &a, "accel: typed array of 4*n elements or null")) return NULL;
+    if (h->multi) {
+        int rc = p_multi_download(h->multi, b, v, a);
+        if (rc != NB_OK) return throw_msg(env, rc, p_multi_last_error(h->multi), "nb_multi_download");
+        return undefined(env);
+    }
     int rc = p_download(h->sim, b, v, a);
     if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_download");
     return undefined(env);
@@ -265,6 +323,11 @@ static napi_value js_sync(napi_env env, napi_callback_info info)
     size_t argc = 1; napi_value argv[1];
     CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    if (h->multi) {
+        int rc = p_multi_sync(h->multi);
+        if (rc != NB_OK) return throw_msg(env, rc, p_multi_last_error(h->multi), "nb_multi_sync");
+        return undefined(env);
+    }
     int rc = p_sync(h->sim);
     if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_sync");
     return undefined(env);
@@ -278,6 +341,7 @@ static napi_value js_destroy(napi_env env, napi_callback_info info)
     if (argc && napi_get_value_external(env, argv[0], &p) == napi_ok && p) {
         handle_t *h = (handle_t *)p;
         if (h->sim) { p_destroy(h->sim); h->sim = NULL; }   /* idempotent; finalizer frees the shell */
+        if (h->multi) { p_multi_destroy(h->multi); h->multi = NULL; }
     }
     return undefined(env);
 }
@@ -287,6 +351,7 @@ static napi_value js_enable_timing(napi_env env, napi_callback_info info)
     size_t argc = 2; napi_value argv[2];
     CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    if (h->multi) { napi_throw_error(env, "NB_1", "per-kernel timing is not available on a multi-device handle"); return NULL; }
     bool on = true; if (argc >= 2) napi_get_value_bool(env, argv[1], &on);
     int rc = p_enable_timing(h->sim, on ? 1 : 0);
     if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_enable_timing");
@@ -299,6 +364,7 @@ static napi_value js_kernel_times(napi_env env, napi_callback_info info)
     size_t argc = 1; napi_value argv[1];
     CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    if (h->multi) { napi_throw_error(env, "NB_1", "per-kernel timing is not available on a multi-device handle"); return NULL; }
     double f, g; uint32_t c;
     int rc = p_kernel_times(h->sim, &f, &g, &c);
     if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_kernel_times");
@@ -315,7 +381,9 @@ static napi_value js_variant(napi_env env, napi_callback_info info)
     size_t argc = 1; napi_value argv[1];
     CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
-    napi_value v; CHECK_NAPI(env, napi_create_string_utf8(env, p_variant_name(h->sim), NAPI_AUTO_LENGTH, &v)); return v;
+    napi_value v;
+    CHECK_NAPI(env, napi_create_string_utf8(env, h->multi ? p_multi_variant_name(h->multi) : p_variant_name(h->sim), NAPI_AUTO_LENGTH, &v));
+    return v;
 }
 
 /* diagnostics(handle) -> {kinetic, potential, momentum:[3]} */
@@ -324,6 +392,7 @@ static napi_value js_diagnostics(napi_env env, napi_callback_info info)
     size_t argc = 1; napi_value argv[1];
     CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    if (h->multi) { napi_throw_error(env, "NB_1", "diagnostics are not available on a multi-device handle"); return NULL; }
     double out[5];
     int rc = p_diagnostics(h->sim, out);
     if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_diagnostics");

@@ -58,7 +58,9 @@ function asParticles(particles) {
 }
 
 class Simulation {
-  /** options: {G, dt, f64, eps2, device, shardBegin, shardCount, variant, jsplit} */
+  /** options: {G, dt, f64, eps2, device, shards, shardBegin, shardCount, variant, jsplit}
+   *  shards > 1: single-process multi-device (i-shards round-robin over the visible GPUs,
+   *  peer-copy all-gather of positions after every step; no reference analogue). */
   constructor(options) {
     const o = options || {};
     this.options = o;
@@ -95,7 +97,7 @@ class Simulation {
       this._h = addon.create({
         n: n, f64: this.f64 ? 1 : 0, eps2: o.eps2 !== undefined ? o.eps2 : EPS2,
         device: o.device !== undefined ? o.device : -1, shardBegin: o.shardBegin || 0, shardCount: o.shardCount || 0,
-        variant: o.variant || 0, jsplit: o.jsplit || 0, tile: o.tile || 0,
+        variant: o.variant || 0, jsplit: o.jsplit || 0, tile: o.tile || 0, shards: o.shards || 0,
       });
     }
     addon.upload(this._h, this._coerce(p.bodies, 'bodies'), this._coerce(p.vel, 'vel'),

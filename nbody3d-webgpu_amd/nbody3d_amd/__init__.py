@@ -10,6 +10,7 @@ There is NO CPU compute path in here: every force/integrate call goes through
 the HIP library and fails loudly when it (or a GPU) is missing.
 """
 from .capi import (  # noqa: F401
+    MultiSimulation,
     NBodyError,
     Simulation,
     abi_version,

@@ -45,7 +45,9 @@ EXCHANGE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 SYMBOLS = ["nb_abi_version", "nb_device_count", "nb_create", "nb_destroy", "nb_upload", "nb_set_params", "nb_step",
            "nb_download", "nb_sync", "nb_last_error", "nb_device_ptr", "nb_set_exchange",
            "nb_set_exchange_overlapped", "nb_enable_timing",
-           "nb_kernel_times", "nb_variant_name", "nb_diagnostics"]
+           "nb_kernel_times", "nb_variant_name", "nb_diagnostics",
+           "nb_multi_create", "nb_multi_destroy", "nb_multi_upload", "nb_multi_set_params", "nb_multi_step",
+           "nb_multi_download", "nb_multi_sync", "nb_multi_last_error", "nb_multi_variant_name"]
 
 _lib = None
 
@@ -84,6 +86,18 @@ def load_library():
     L.nb_variant_name.argtypes = [vp]
     L.nb_variant_name.restype = C.c_char_p
     L.nb_diagnostics.argtypes = [vp, C.POINTER(C.c_double)]
+    L.nb_multi_create.argtypes = [C.POINTER(nb_config), C.c_uint32, C.POINTER(C.c_int32), C.POINTER(vp)]
+    L.nb_multi_destroy.argtypes = [vp]
+    L.nb_multi_destroy.restype = None
+    L.nb_multi_upload.argtypes = [vp, vp, vp, vp]
+    L.nb_multi_set_params.argtypes = [vp, C.c_double, C.c_double]
+    L.nb_multi_step.argtypes = [vp, C.c_uint32]
+    L.nb_multi_download.argtypes = [vp, vp, vp, vp]
+    L.nb_multi_sync.argtypes = [vp]
+    L.nb_multi_last_error.argtypes = [vp]
+    L.nb_multi_last_error.restype = C.c_char_p
+    L.nb_multi_variant_name.argtypes = [vp]
+    L.nb_multi_variant_name.restype = C.c_char_p
     _lib = L
     return L
 
@@ -263,3 +277,92 @@ class Simulation:
         out = (C.c_double * 5)()
         self._check(self._L.nb_diagnostics(self._h, out))
         return out[0], out[1], np.array(out[2:5])
+
+
+class MultiSimulation:
+    """Single-process multi-device handle (nb_multi_*): n_shards i-shards, one per
+    entry of ``devices`` (default: round-robin over the visible GPUs; several
+    shards may share a GPU), peer-copy all-gather after every step.  Same
+    host-side surface as Simulation; arrays hold the unpadded n rows."""
+
+    def __init__(self, n, n_shards, devices=None, precision="f32", eps2=None, force_variant=0, jsplit=0):
+        L = load_library()
+        self._L = L
+        self.n, self.n_shards = int(n), int(n_shards)
+        self.dtype = np.float64 if precision in ("f64", NB_F64, np.float64) else np.float32
+        cfg = nb_config()
+        cfg.struct_size = C.sizeof(nb_config)
+        cfg.n = self.n
+        cfg.precision = NB_F64 if self.dtype == np.float64 else NB_F32
+        cfg.eps2 = 0.0 if eps2 is None else float(eps2)
+        cfg.device = -1
+        cfg.force_variant, cfg.jsplit = force_variant, jsplit
+        dev = None
+        if devices is not None:
+            assert len(devices) == self.n_shards
+            dev = (C.c_int32 * self.n_shards)(*devices)
+        h = C.c_void_p()
+        rc = L.nb_multi_create(C.byref(cfg), self.n_shards, dev, C.byref(h))
+        if rc != 0:
+            raise NBodyError(rc, L.nb_multi_last_error(None).decode())
+        self._h = h
+        self.dt = self.G = 0.0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.nb_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def _check(self, rc):
+        if rc != 0:
+            raise NBodyError(rc, self._L.nb_multi_last_error(self._h).decode())
+
+    def _arr(self, a, name):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.size != 4 * self.n:
+            raise ValueError("%s must hold 4*n = %d elements, got %d" % (name, 4 * self.n, a.size))
+        return a
+
+    def init(self, bodies, vel, accel=None):
+        b, v = self._arr(bodies, "bodies"), self._arr(vel, "vel")
+        a = None if accel is None else self._arr(accel, "accel")
+        self._check(self._L.nb_multi_upload(self._h, _ptr(b), _ptr(v), _ptr(a)))
+        return self
+
+    restore = init
+
+    def set_params(self, dt, G):
+        self.dt, self.G = float(dt), float(G)
+        self._check(self._L.nb_multi_set_params(self._h, self.dt, self.G))
+
+    def step(self, dt=None, G=None):
+        self.simulate(1, dt, G)
+
+    def simulate(self, nsteps, dt=None, G=None):
+        if dt is not None or G is not None:
+            self.set_params(self.dt if dt is None else dt, self.G if G is None else G)
+        self._check(self._L.nb_multi_step(self._h, int(nsteps)))
+
+    def sync(self):
+        self._check(self._L.nb_multi_sync(self._h))
+
+    def read(self, bodies=True, vel=True, accel=True):
+        out = [np.zeros((self.n, 4), self.dtype) if f else None for f in (bodies, vel, accel)]
+        self._check(self._L.nb_multi_download(self._h, _ptr(out[0]), _ptr(out[1]), _ptr(out[2])))
+        return tuple(out)
+
+    @property
+    def variant(self):
+        return self._L.nb_multi_variant_name(self._h).decode()

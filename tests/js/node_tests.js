@@ -79,6 +79,13 @@ if (mode === 'cpu') {
   check('bad_length_throws', throws(function () { sim.restore({ bodies: new Float32Array(8), vel: new Float32Array(8) }); }, /expected/));
   const d = sim.diagnostics();
   check('diagnostics', isFinite(d.kinetic) && d.potential < 0 && d.momentum.length === 3, d);
+  // single-process multi-device handle from JS: 4 i-shards (virtual shards when fewer GPUs)
+  const sm = new nb.Simulation({ G: m.G, dt: m.dt, shards: 4 }).init([b0, v0]);
+  sm.simulate(100);
+  const em = relPosErr(sm.read().bodies, loadF64('plummer1024_s100_bodies'), m.r_scale);
+  check('gpu_multi_shard_handle_vs_f64_oracle', em < 2e-5, { err: em, variant: sm.variant() });
+  check('multi_has_no_diagnostics', throws(function () { sm.diagnostics(); }, /not available/));
+  sm.destroy();
   // f64 simulation takes Float64Array
   const s64 = new nb.Simulation({ f64: true, G: m.G, dt: m.dt }).init([Float64Array.from(b0), Float64Array.from(v0)]);
   s64.simulate(100);

@@ -14,7 +14,7 @@ import pytest
 
 from conftest import load_golden32, load_golden64, rel_pos_err
 from oracle import oracle
-from nbody3d_amd import Simulation, ic
+from nbody3d_amd import MultiSimulation, Simulation, ic
 
 pytestmark = pytest.mark.gpu
 
@@ -322,6 +322,50 @@ def test_overlapped_exchange_with_virtual_shards(g):
     assert calls["begin"] == g * steps and calls["wait"] == g * steps
     assert bodies.tobytes() == ref[0].tobytes()
     assert vel.tobytes() == ref[1].tobytes()
+
+
+@pytest.mark.parametrize("n,g", [(2048, 2), (4096, 4), (4096, 8), (1000, 3)])
+def test_single_process_multi_shard_handle(n, g):
+    """nb_multi_*: g shards in one process with the peer-copy all-gather.  With more
+    shards than GPUs they share the device ("virtual shards"), which
+    exercises exactly the partition / event / copy logic a real 8-GPU node runs.
+    Bit-identical to one unsharded handle when the launch shape is pinned; ragged n
+    is padded with zero-mass rows."""
+    steps = 7
+    b, v = (ic.plummer(n, seed=24) if n % 256 == 0 else ic.uniform_cube(n, seed=24))
+    a0 = np.random.default_rng(5).random((n, 4)).astype(np.float32) * 0.01
+    a0[:, 3] = 0
+    kw = dict(force_variant=1, jsplit=2)
+    with MultiSimulation(n, g, **kw) as ms:
+        ms.init(b, v, a0)
+        ms.simulate(3, 1e-3, 1.0)
+        for _ in range(steps - 3):
+            ms.step()
+        got = ms.read()
+        name = ms.variant
+    if n % 256 == 0:
+        with Simulation(n, **kw) as one:
+            one.init(b, v, a0)
+            one.simulate(steps, 1e-3, 1.0)
+            ref = one.read()
+        for x, y in zip(got, ref):
+            assert x.tobytes() == y.tobytes(), name
+    rb, rv, ra = oracle.run_f32(b, v, a0, 1e-3, 1.0, steps)
+    assert rel_pos_err(got[0], rb, 1.0) < 1e-6, name
+    assert np.abs(got[2] - ra).max() < TOL_ACC * np.abs(ra).max(), name
+    assert np.array_equal(got[0][:, 3], b[:, 3])
+
+
+def test_multi_handle_default_shape_and_noop():
+    b, v = ic.plummer(8192, seed=25)
+    with MultiSimulation(8192, 4) as ms:
+        ms.init(b, v)
+        ms.simulate(2, 0.0, 1.0)                      # dt = 0: no-op (nbody3d.js:474)
+        assert ms.read()[0].tobytes() == b.tobytes()
+        ms.simulate(5, 1e-3, 1.0)
+        got = ms.read()
+    rb, _, _ = oracle.run_f64(b, v, None, 1e-3, 1.0, 5)
+    assert rel_pos_err(got[0], rb, 1.0) < TOL_TIGHT
 
 
 def test_exchange_hook_is_called_once_per_step():
