@@ -13,6 +13,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -85,38 +87,71 @@ int fail(nb_sim* s, int code, const std::string& msg)
 
 uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-// Launch-shape heuristic (measured: profiles/r01/sweep_*.txt).
-//   grid = (i-blocks, jsplit) workgroups of 4 waves.  Wanted: ~4096 workgroups
-//   (the 118-VGPR packed kernel keeps 4 waves per SIMD = 1024 workgroups
-//   resident, so 4 rounds of short blocks even out DVFS/tail imbalance: +4 %
-//   over 1024), and never fewer than ~1024 when the problem allows it.
-//   * i-side: f32 uses the packed kernel with the largest register blocking
-//     (8, 4, 2 bodies per lane) that still reaches 1024 workgroups with the
-//     j-split available; below that the scalar kernel lets LS = 4/16/64 lanes
-//     share one body (shuffle-reduced), which multiplies the i-blocks by LS.
-//   * j-side: split over blockIdx.y, at most one split per 256-body tile, <= 128.
 struct Shape { int ipl, ls; bool pk; };
 
+// The force kernel instantiation for a shape (used for launching and for the
+// occupancy query of the launch-shape model).
+template <typename T>
+const void* force_kernel(const Shape& sh)
+{
+    if constexpr (std::is_same<T, float>::value) {
+        if (sh.pk) {
+            if (sh.ipl == 2) return (const void*)&nb::nb_force_pk<1, 1>;
+            if (sh.ipl == 4) return (const void*)&nb::nb_force_pk<2, 1>;
+            return (const void*)&nb::nb_force_pk<4, 1>;
+        }
+    }
+    if (sh.ls == 1) {
+        if (sh.ipl == 1) return (const void*)&nb::nb_force<T, 1, 1>;
+        if (sh.ipl == 2) return (const void*)&nb::nb_force<T, 2, 1>;
+        return (const void*)&nb::nb_force<T, 4, 1>;
+    }
+    if (sh.ls == 4) return (const void*)&nb::nb_force<T, 1, 4>;
+    if (sh.ls == 16) return (const void*)&nb::nb_force<T, 1, 16>;
+    return (const void*)&nb::nb_force<T, 1, 64>;
+}
+
+const void* force_kernel_of(const nb_sim* s, const Shape& sh)
+{
+    return s->f64 ? force_kernel<double>(sh) : force_kernel<float>(sh);
+}
+
+// Launch-shape model (inputs measured on MI355X: profiles/r01/sweep_*.txt).
+//   grid = (i-blocks, jsplit) workgroups of 4 waves, all with the same amount of work,
+//   so a launch runs in rounds of `slots` resident workgroups.  For every kernel shape
+//   and every split count the model estimates
+//     t = sum over rounds [ max(compute, latency) + prologue ] / balance + K2 time
+//       compute  = (split length / 256) * resident workgroups per CU * cycles per tile
+//                  (the waves of a SIMD share its issue port)
+//       latency  = tiles per split * ~3000 cycles (global load + LDS store + barrier; what
+//                  bounds small systems: N = 4,096 with 64 lanes per body is all latency)
+//       balance  = 1 - 0.04 / rounds (more rounds even out DVFS/tail: +4 % from 1 to 4)
+//   and keeps the minimum.  It reproduces the measured optimum at the aligned sizes
+//   (N = 262,144: 8 bodies/lane, 4 rounds of 1024) and removes the round-quantisation
+//   loss at the others (N = 40,002, the reference's default: 1,580 workgroups on 1,024
+//   slots = 0.77 -> 1,020 = 0.996).  A split is any multiple of 8 bodies >= 128 -- not a
+//   multiple of the 256-body tile: the kernels run an exact trip count on the last,
+//   partial tile -- and there are at most 128 splits.
 void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
 {
     const uint32_t sc = s->sc, n = s->n;
-    const uint32_t tiles = ceil_div(n, nb::kTile);
-    const uint32_t kMaxSplit = 128;   // 1/8-shard shape: +2.7 % over 64 (profiles/r01/sweep_jsplit_cap.txt)
-    const uint32_t js_cap = tiles < kMaxSplit ? (tiles ? tiles : 1) : kMaxSplit;
-    const uint32_t want_blocks = (uint32_t)n_cu * 16, min_blocks = (uint32_t)n_cu * 4;
-    auto iblocks_of = [&](const Shape& sh) { return ceil_div(sc, (uint32_t)(nb::kBlock / sh.ls) * sh.ipl); };
+    const uint32_t kMaxSplit = 128, kMinSplitLen = 128;
+    const double kTileLatency = 3000.0, kPrologue = 3000.0, kClock = 2.3e9;
+    auto ipb_of = [](const Shape& sh) { return (uint32_t)(nb::kBlock / sh.ls) * sh.ipl; };
+    auto split_len = [&](uint32_t js) { return ceil_div(ceil_div(n, js), 8u) * 8u; };
+
+    struct Cand { Shape sh; double tile_cycles; };   // SIMD cycles one wave needs for a full 256-body tile
+    const Cand f32c[] = {{{8, 1, true}, 65536}, {{4, 1, true}, 33600}, {{2, 1, true}, 17600},
+                         {{1, 4, false}, 2400}, {{1, 16, false}, 800}, {{1, 64, false}, 280}};
+    const Cand f64c[] = {{{2, 1, false}, 51200}, {{1, 1, false}, 26400},
+                         {{1, 4, false}, 6400}, {{1, 16, false}, 1600}, {{1, 64, false}, 400}};
+    const Cand* cands = s->f64 ? f64c : f32c;
+    const int ncand = s->f64 ? 5 : 6;
 
     Shape sh{2, 1, false};
+    uint32_t js = cfg.jsplit;
     const uint32_t variant = cfg.force_variant;
-    if (variant == 0) {
-        const Shape f32_order[] = {{8, 1, true}, {4, 1, true}, {2, 1, true}, {1, 4, false}, {1, 16, false}, {1, 64, false}};
-        const Shape f64_order[] = {{2, 1, false}, {1, 1, false}, {1, 4, false}, {1, 16, false}, {1, 64, false}};
-        const Shape* order = s->f64 ? f64_order : f32_order;
-        const int cnt = s->f64 ? 5 : 6;
-        sh = order[cnt - 1];
-        for (int k = 0; k < cnt; ++k)
-            if ((uint64_t)iblocks_of(order[k]) * js_cap >= min_blocks) { sh = order[k]; break; }
-    } else {
+    if (variant != 0) {
         switch (variant) {
             case 1: sh = {1, 1, false}; break;
             case 2: sh = {2, 1, false}; break;
@@ -131,18 +166,51 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         }
         if (s->f64) sh.pk = false;
     }
-    s->ipl = sh.ipl; s->ls = sh.ls; s->packed = sh.pk;
-    uint32_t js = cfg.jsplit;
-    if (js == 0) {
-        js = ceil_div(want_blocks, iblocks_of(sh));
-        if (js > js_cap) js = js_cap;
+    if (variant == 0 || js == 0) {
+        double best_t = 1e300;
+        for (int k = 0; k < ncand; ++k) {
+            const Cand& c = cands[k];
+            if (variant != 0 && !(c.sh.ipl == sh.ipl && c.sh.ls == sh.ls && c.sh.pk == sh.pk)) continue;
+            int occ = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, force_kernel_of(s, c.sh), nb::kBlock, 0) != hipSuccess || occ < 1) {
+                (void)hipGetLastError();
+                occ = 4;
+            }
+            if (occ > 8) occ = 8;
+            const uint64_t slots = (uint64_t)occ * n_cu;
+            const uint32_t iblocks = ceil_div(sc, ipb_of(c.sh));
+            uint32_t js_hi = n / kMinSplitLen;
+            if (js_hi < 1) js_hi = 1;
+            if (js_hi > kMaxSplit) js_hi = kMaxSplit;
+            const uint32_t js_lo = cfg.jsplit ? cfg.jsplit : 1, js_top = cfg.jsplit ? cfg.jsplit : js_hi;
+            for (uint32_t q = js_lo; q <= js_top; ++q) {
+                const uint32_t len = split_len(q), used = ceil_div(n, len);
+                const uint64_t blocks = (uint64_t)iblocks * used;
+                const uint64_t full = blocks / slots, rem = blocks % slots;
+                const double tiles = std::ceil(len / 256.0), frac = len / 256.0;
+                // a SIMD with fewer than 4 resident waves cannot keep its issue port full
+                // (measured with the pure-ALU loop, profiles/r01/ubench2_mfma_coexec.txt and ubench_run1.txt)
+                auto round_cycles = [&](double per_cu) {
+                    const double fill = per_cu >= 4 ? 1.0 : per_cu >= 3 ? 0.92 : per_cu >= 2 ? 0.82 : 0.62;
+                    return std::max(frac * per_cu * c.tile_cycles / fill, tiles * kTileLatency) + kPrologue;
+                };
+                double cyc = full * round_cycles(occ);
+                if (rem) cyc += round_cycles((double)ceil_div((uint32_t)rem, (uint32_t)n_cu));
+                const double rounds = (double)full + (rem ? 1 : 0);
+                const double t = cyc / kClock / (1.0 - 0.04 / rounds) + (double)used * sc * 4 * s->esz / 3.0e12 + 3e-6;
+                if (t < best_t) { best_t = t; sh = c.sh; js = q; }
+            }
+        }
+    }
+    if (js < 1) {   // pinned shape outside the model's candidate list: fill ~4096 workgroups
+        js = ceil_div((uint32_t)n_cu * 16, ceil_div(sc, ipb_of(sh)));
+        const uint32_t hi = n / kMinSplitLen < 1 ? 1 : (n / kMinSplitLen > kMaxSplit ? kMaxSplit : n / kMinSplitLen);
+        if (js > hi) js = hi;
         if (js < 1) js = 1;
     }
-    if (js > tiles) js = tiles ? tiles : 1;
-    s->jsplit = js;
-    s->j_per_split = ceil_div(tiles, js) * nb::kTile;
-    // a split may end up empty after rounding: shrink jsplit to what is used
-    s->jsplit = ceil_div(n, s->j_per_split);
+    s->ipl = sh.ipl; s->ls = sh.ls; s->packed = sh.pk;
+    s->j_per_split = split_len(js);
+    s->jsplit = ceil_div(n, s->j_per_split);   // a split may end up empty after rounding
     // j-splits that lie entirely inside this shard's own rows (overlapped exchange)
     s->own_split0 = 0; s->own_splits = 0;
     if (sc < n && s->sb % s->j_per_split == 0) {
@@ -164,6 +232,7 @@ template <typename T>
 void launch_force(nb_sim* s, int part = 0)
 {
     using V4 = typename nb::vec4<T>::type;
+    const Shape sh{s->ipl, s->ls, s->packed};
     const uint32_t ipb = (nb::kBlock / s->ls) * s->ipl;
     nb::SplitWindow win{0, 0xffffffffu, 0};
     uint32_t ny = s->jsplit;
@@ -173,30 +242,10 @@ void launch_force(nb_sim* s, int part = 0)
     dim3 grid(ceil_div(s->sc, ipb), ny), block(nb::kBlock);
     const V4* b = (const V4*)s->bodies;
     V4* p = (V4*)s->partial;
-    const T G = (T)s->G, e2 = (T)s->eps2;
-    if constexpr (std::is_same<T, float>::value) {
-        if (s->packed) {
-#define NB_LAUNCH_PK(NG)                                                                                            \
-    hipLaunchKernelGGL((nb::nb_force_pk<NG, 1>), grid, block, 0, s->stream, b, p, s->n, s->sb, s->sc, G, e2,       \
-                       s->j_per_split, win)
-            if (s->ipl == 2) NB_LAUNCH_PK(1);
-            else if (s->ipl == 4) NB_LAUNCH_PK(2);
-            else NB_LAUNCH_PK(4);
-#undef NB_LAUNCH_PK
-            return;
-        }
-    }
-#define NB_LAUNCH(IPL, LS)                                                                                      \
-    hipLaunchKernelGGL((nb::nb_force<T, IPL, LS>), grid, block, 0, s->stream, b, p, s->n, s->sb, s->sc, G, e2, \
-                       s->j_per_split, win)
-    if (s->ls == 1) {
-        if (s->ipl == 1) NB_LAUNCH(1, 1);
-        else if (s->ipl == 2) NB_LAUNCH(2, 1);
-        else NB_LAUNCH(4, 1);
-    } else if (s->ls == 4) NB_LAUNCH(1, 4);
-    else if (s->ls == 16) NB_LAUNCH(1, 16);
-    else NB_LAUNCH(1, 64);
-#undef NB_LAUNCH
+    T G = (T)s->G, e2 = (T)s->eps2;
+    uint32_t n = s->n, sb = s->sb, sc = s->sc, jps = s->j_per_split;
+    void* args[] = {&b, &p, &n, &sb, &sc, &G, &e2, &jps, &win};
+    (void)hipLaunchKernel(force_kernel<T>(sh), grid, block, args, 0, s->stream);   // error picked up by hipGetLastError
 }
 
 template <typename T>

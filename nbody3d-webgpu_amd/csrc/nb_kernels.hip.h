@@ -136,11 +136,20 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
         V4 nxt;
         const bool more = (t + 1 < ntiles);
         if (more) nxt = stage(t + 1);        // global load in flight under the tile's compute
-#pragma unroll 8
-        for (int jj = 0; jj < kTile / LS; ++jj) {
-            const V4 b = tile[cur][jj * LS + js];
+        // j-bodies of this tile that are inside the split (the last tile of a split is
+        // usually partial: splits are not tile multiples, see choose_shape); the loop runs
+        // in chunks of CH iterations, entries past the range are staged zero-mass bodies
+        const uint32_t left = j1 - (j0 + t * kTile);
+        const int cnt = left < (uint32_t)kTile ? (int)left : kTile;
+        constexpr int CH = (kTile / LS) < 8 ? (kTile / LS) : 8;   // iterations per chunk (LS = 64: 4 per tile)
+        const int chunks = ((cnt + LS - 1) / LS + CH - 1) / CH;
+        for (int c = 0; c < chunks; ++c) {
 #pragma unroll
-            for (int k = 0; k < IPL; ++k) pair<T>(b.x, b.y, b.z, b.w, xi[k], yi[k], zi[k], eps2, ax[k], ay[k], az[k]);
+            for (int u = 0; u < CH; ++u) {
+                const V4 b = tile[cur][(c * CH + u) * LS + js];
+#pragma unroll
+                for (int k = 0; k < IPL; ++k) pair<T>(b.x, b.y, b.z, b.w, xi[k], yi[k], zi[k], eps2, ax[k], ay[k], az[k]);
+            }
         }
         if (more) tile[cur ^ 1][tid] = nxt;
         __syncthreads();
@@ -239,8 +248,14 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
         constexpr int JB = NG >= 4 ? 1 : 4 / NG;
         constexpr int NC = JB * NG;
         constexpr int UNR = 8 / JB;
-#pragma unroll UNR
-        for (int jj = 0; jj < kTile / LS; jj += JB) {
+        // exact trip count on a partial last tile (see nb_force), in chunks of 8 j-bodies
+        const uint32_t left = j1 - (j0 + t * kTile);
+        const int cnt = left < (uint32_t)kTile ? (int)left : kTile;
+        const int chunks = ((cnt + LS - 1) / LS + 7) / 8;
+        for (int ch = 0; ch < chunks; ++ch) {
+#pragma unroll
+        for (int uu = 0; uu < UNR; ++uu) {
+            const int jj = ch * 8 + uu * JB;
             nb_f2 bx[JB], by[JB], bz[JB], bm[JB];
 #pragma unroll
             for (int u = 0; u < JB; ++u) {
@@ -275,6 +290,7 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
             for (int c = 0; c < NC; ++c) ay[c % NG] = __builtin_elementwise_fma(r[c], dy[c], ay[c % NG]);
 #pragma unroll
             for (int c = 0; c < NC; ++c) az[c % NG] = __builtin_elementwise_fma(r[c], dz[c], az[c % NG]);
+        }
         }
         if (more) tile[cur ^ 1][tid] = nxt;
         __syncthreads();
