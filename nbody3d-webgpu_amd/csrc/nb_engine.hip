@@ -125,7 +125,7 @@ const void* force_kernel_of(const nb_sim* s, const Shape& sh)
 //                  (the waves of a SIMD share its issue port)
 //       latency  = tiles per split * ~3000 cycles (global load + LDS store + barrier; what
 //                  bounds small systems: N = 4,096 with 64 lanes per body is all latency)
-//       balance  = 1 - 0.04 / rounds (more rounds even out DVFS/tail: +4 % from 1 to 4)
+//       balance  = 1 - 0.03 / rounds (more rounds even out DVFS/tail: +3..4 % from 1 to 4)
 //   and keeps the minimum.  It reproduces the measured optimum at the aligned sizes
 //   (N = 262,144: 8 bodies/lane, 4 rounds of 1024) and removes the round-quantisation
 //   loss at the others (N = 40,002, the reference's default: 1,580 workgroups on 1,024
@@ -197,7 +197,9 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 double cyc = full * round_cycles(occ);
                 if (rem) cyc += round_cycles((double)ceil_div((uint32_t)rem, (uint32_t)n_cu));
                 const double rounds = (double)full + (rem ? 1 : 0);
-                const double t = cyc / kClock / (1.0 - 0.04 / rounds) + (double)used * sc * 4 * s->esz / 3.0e12 + 3e-6;
+                // K2 reads every split's partial back (and K1 writes it): priced at 2 TB/s so that, when the
+                // balance gain is a wash (N = 262,144: 32 vs 64 splits), the smaller HBM footprint wins
+                const double t = cyc / kClock / (1.0 - 0.03 / rounds) + (double)used * sc * 4 * s->esz / 2.0e12 + 3e-6;
                 if (t < best_t) { best_t = t; sh = c.sh; js = q; }
             }
         }
