@@ -78,10 +78,24 @@ def cpu_baseline(bodies, G, seconds):
     t0 = time.perf_counter()
     _, used = oracle.accel_f32_mt(bodies, G, i0=0, i1=rows)
     dt = time.perf_counter() - t0
-    return {"value": rows * (n - 1) / dt, "unit": "pair-interactions/s", "cores": int(used), "kind": "port",
-            "sample": "oracle/nb_oracle.c nbo_accel_f32_mt (f32, AVX clones, OpenMP over i): rows [0,%d) of the "
-                      "N=%d workload against all N, %.1f s" % (rows, n, dt),
-            "host_cpus": os.cpu_count()}
+    out = {"value": rows * (n - 1) / dt, "unit": "pair-interactions/s", "cores": int(used), "kind": "port",
+           "sample": "oracle/nb_oracle.c nbo_accel_f32_mt (f32, AVX clones, OpenMP over i): rows [0,%d) of the "
+                     "N=%d workload against all N, %.1f s" % (rows, n, dt),
+           "host_cpus": os.cpu_count()}
+    # BASELINE.md §4 'CPU-JS': the single-thread JavaScript restatement on config 1 (N=1,024)
+    try:
+        import shutil
+        import subprocess
+        node = shutil.which("node")
+        if node:
+            p = subprocess.run([node, os.path.join(ROOT, "oracle", "js_baseline.js"), "40"], capture_output=True,
+                               text=True, timeout=120)
+            line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+            if p.returncode == 0 and line:
+                out["js_single_thread"] = json.loads(line[-1])
+    except Exception as e:  # the JS figure is informative; never fail the bench over it
+        out["js_single_thread"] = {"error": str(e)}
+    return out
 
 
 def fixture_check():
