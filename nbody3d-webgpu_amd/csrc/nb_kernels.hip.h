@@ -21,14 +21,20 @@
 //     at LS consecutive addresses when LS lanes share one i-body (small N);
 //   * each lane keeps IPL i-bodies in VGPRs (register blocking: 1 LDS read per
 //     IPL*64 pairs), loaded with coalesced 16-B accesses (lane stride 16 B);
-//   * the pair body is 13 VALU instructions: 3 v_sub, 3 v_fma (r^2 + eps2),
-//     2 v_mul (cube), 1 v_rsq_f32, 1 v_mul (G*m_j), 3 v_fma (accumulate);
-//     no branch: with eps2 > 0 the self term is exactly 0*finite = 0 and
-//     bodies past N are staged as zero-mass;
+//   * f32 default, nb_force_pk: the arithmetic is packed across TWO i-bodies of
+//     the lane (v_pk_add/fma/mul_f32): per two pairs 3 v_pk_add, 3 v_pk_fma
+//     (r^2 + eps2), 2 v_pk_mul (cube), 2 v_rsq_f32, 1 v_pk_mul (G*m_j), 3 v_pk_fma
+//     (accumulate) = 12 packed (4 cycles each) + 2 transcendental (8 cycles each)
+//     = 64 issue cycles per 128 pairs, issued stage-major over 4 independent
+//     chains so no hazard s_nop is needed.  nb_force is the scalar template
+//     (13 VALU per pair) used for f64 and for the LS > 1 shapes;
+//   * no branch in the loop: with eps2 > 0 the self term is exactly 0*finite = 0
+//     and bodies past the split are staged as zero-mass;
 //   * when LS > 1 the LS partial sums of a body are reduced with wavefront
-//     shuffles (DPP row ops / ds_bpermute) before one lane stores;
-//   * grid = (i-blocks, jsplit): j is also partitioned over blockIdx.y so small
-//     i-counts (N = 65,536, or a 1/8 shard) still put >= 2 waves on every SIMD;
+//     shuffles before one lane stores;
+//   * grid = (i-blocks, jsplit): j is also partitioned over blockIdx.y (any
+//     multiple of 8 bodies per split, exact trip count on the last partial tile)
+//     so that small i-counts (N = 65,536, or a 1/8 shard) still fill every SIMD;
 //     K2 sums the jsplit partials in ascending order (deterministic, no atomics).
 #pragma once
 #include <hip/hip_runtime.h>
