@@ -51,6 +51,7 @@ struct nb_sim {
     bool params_set = false, uploaded = false;
     int ipl = 1, ls = 1;
     bool packed = false;   // nb_force_pk (f32 only)
+    bool sgpr = false;     // nb_force_pk_sgpr: j broadcast from SGPRs instead of the LDS tile
     uint32_t jsplit = 1, j_per_split = 0;
     std::string variant, err;
     nb_exchange_fn xfn = nullptr;
@@ -87,7 +88,7 @@ int fail(nb_sim* s, int code, const std::string& msg)
 
 uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-struct Shape { int ipl, ls; bool pk; };
+struct Shape { int ipl, ls; bool pk; bool sgpr = false; };
 
 // The force kernel instantiation for a shape (used for launching and for the
 // occupancy query of the launch-shape model).
@@ -95,6 +96,10 @@ template <typename T>
 const void* force_kernel(const Shape& sh)
 {
     if constexpr (std::is_same<T, float>::value) {
+        if (sh.pk && sh.sgpr) {
+            if (sh.ipl == 4) return (const void*)&nb::nb_force_pk_sgpr<2>;
+            return (const void*)&nb::nb_force_pk_sgpr<4>;
+        }
         if (sh.pk) {
             if (sh.ipl == 2) return (const void*)&nb::nb_force_pk<1, 1>;
             if (sh.ipl == 4) return (const void*)&nb::nb_force_pk<2, 1>;
@@ -162,9 +167,11 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
             case 22: sh = {2, 1, true}; break;     // packed across 2 i-bodies
             case 24: sh = {4, 1, true}; break;
             case 28: sh = {8, 1, true}; break;
+            case 34: sh = {4, 1, true, true}; break;   // packed, j broadcast from SGPRs (no LDS)
+            case 38: sh = {8, 1, true, true}; break;
             default: sh = {2, 1, false}; break;
         }
-        if (s->f64) sh.pk = false;
+        if (s->f64) { sh.pk = false; sh.sgpr = false; }
     }
     if (variant == 0 || js == 0) {
         double best_t = 1e300;
@@ -200,7 +207,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 // K2 reads every split's partial back (and K1 writes it): priced at 2 TB/s so that, when the
                 // balance gain is a wash (N = 262,144: 32 vs 64 splits), the smaller HBM footprint wins
                 const double t = cyc / kClock / (1.0 - 0.03 / rounds) + (double)used * sc * 4 * s->esz / 2.0e12 + 3e-6;
-                if (t < best_t) { best_t = t; sh = c.sh; js = q; }
+                if (t < best_t) { best_t = t; if (variant == 0) sh = c.sh; js = q; }
             }
         }
     }
@@ -210,7 +217,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         if (js > hi) js = hi;
         if (js < 1) js = 1;
     }
-    s->ipl = sh.ipl; s->ls = sh.ls; s->packed = sh.pk;
+    s->ipl = sh.ipl; s->ls = sh.ls; s->packed = sh.pk; s->sgpr = sh.sgpr;
     s->j_per_split = split_len(js);
     s->jsplit = ceil_div(n, s->j_per_split);   // a split may end up empty after rounding
     // j-splits that lie entirely inside this shard's own rows (overlapped exchange)
@@ -223,8 +230,11 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         }
     }
     char buf[96];
-    snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.pk ? "pk" : "", nb::kTile, sh.ipl,
-             sh.ls, s->jsplit);
+    if (sh.sgpr)
+        snprintf(buf, sizeof buf, "f32pk_sgpr_ipl%d_js%u", sh.ipl, s->jsplit);
+    else
+        snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.pk ? "pk" : "", nb::kTile,
+                 sh.ipl, sh.ls, s->jsplit);
     s->variant = buf;
 }
 
@@ -234,7 +244,7 @@ template <typename T>
 void launch_force(nb_sim* s, int part = 0)
 {
     using V4 = typename nb::vec4<T>::type;
-    const Shape sh{s->ipl, s->ls, s->packed};
+    const Shape sh{s->ipl, s->ls, s->packed, s->sgpr};
     const uint32_t ipb = (nb::kBlock / s->ls) * s->ipl;
     nb::SplitWindow win{0, 0xffffffffu, 0};
     uint32_t ny = s->jsplit;

@@ -325,6 +325,109 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
     }
 }
 
+// K1, packed form with the j-bodies broadcast from SGPRs instead of LDS (SURVEY.md §8 f3
+// "scalar-load (SGPR) j-broadcast A/B against the LDS tile").  j is wave-uniform, so
+// bodies[j] is fetched with s_load_dwordx4 through the scalar cache and the packed ops
+// take the (x,y | z,m) SGPR pairs directly (op_sel broadcast): no LDS, no barrier, no
+// v_mov for the mass, workgroups need no tile synchronisation.  8 bodies live in SGPRs;
+// each half is reloaded for the next batch as soon as it has been consumed.  G is applied
+// once to the finished sums (G * sum(m r^-3 d) instead of sum((G m) r^-3 d): rounding only).
+// Opt-in (variant 34/38); the LDS kernel stays the default -- measurement in DESIGN.md.
+template <int NG>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NG >= 4 ? 4 : 6, NG >= 4 ? 4 : 6)))
+void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ partial, uint32_t n, uint32_t i_begin,
+                      uint32_t i_count, float G, float eps2, uint32_t j_per_split, SplitWindow win)
+{
+    constexpr int IPL = 2 * NG;
+    constexpr int IPB = kBlock * IPL;
+    const uint32_t by = win.split(blockIdx.y);
+    const int tid = threadIdx.x;
+
+    nb_f2 xi[NG], yi[NG], zi[NG], ax[NG], ay[NG], az[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        float4 b0 = float4{0, 0, 0, 0}, b1 = float4{0, 0, 0, 0};
+        const uint32_t il0 = blockIdx.x * IPB + (2 * g) * kBlock + tid;
+        const uint32_t il1 = il0 + kBlock;
+        if (il0 < i_count) b0 = bodies[i_begin + il0];
+        if (il1 < i_count) b1 = bodies[i_begin + il1];
+        xi[g] = nb_f2{b0.x, b1.x}; yi[g] = nb_f2{b0.y, b1.y}; zi[g] = nb_f2{b0.z, b1.z};
+        ax[g] = nb_f2{0, 0}; ay[g] = nb_f2{0, 0}; az[g] = nb_f2{0, 0};
+    }
+    const nb_f2 e2 = nb_f2{eps2, eps2};
+    const uint32_t j0 = by * j_per_split;
+    uint32_t j1 = j0 + j_per_split;
+    if (j1 > n) j1 = n;
+
+    auto eval4 = [&](const float4 q0, const float4 q1, const float4 q2, const float4 q3) {
+        const float4 q[4] = {q0, q1, q2, q3};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float4 b = q[u];
+            const nb_f2 bx = nb_f2{b.x, b.x}, by2 = nb_f2{b.y, b.y}, bz = nb_f2{b.z, b.z}, bm = nb_f2{b.w, b.w};
+            nb_f2 dx[NG], dy[NG], dz[NG], d2[NG], r[NG];
+#pragma unroll
+            for (int c = 0; c < NG; ++c) dx[c] = bx - xi[c];
+#pragma unroll
+            for (int c = 0; c < NG; ++c) dy[c] = by2 - yi[c];
+#pragma unroll
+            for (int c = 0; c < NG; ++c) dz[c] = bz - zi[c];
+#pragma unroll
+            for (int c = 0; c < NG; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);
+#pragma unroll
+            for (int c = 0; c < NG; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+            for (int c = 0; c < NG; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+            for (int c = 0; c < NG; ++c) r[c] = d2[c] * d2[c];
+#pragma unroll
+            for (int c = 0; c < NG; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+            for (int c = 0; c < NG; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+#pragma unroll
+            for (int c = 0; c < NG; ++c) r[c] = bm * r[c];
+#pragma unroll
+            for (int c = 0; c < NG; ++c) ax[c] = __builtin_elementwise_fma(r[c], dx[c], ax[c]);
+#pragma unroll
+            for (int c = 0; c < NG; ++c) ay[c] = __builtin_elementwise_fma(r[c], dy[c], ay[c]);
+#pragma unroll
+            for (int c = 0; c < NG; ++c) az[c] = __builtin_elementwise_fma(r[c], dz[c], az[c]);
+        }
+    };
+
+    const uint32_t nb8 = j1 > j0 ? (j1 - j0) / 8 : 0;
+    float4 Q[8];
+    uint32_t j = j0;
+    if (nb8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) Q[u] = bodies[j + u];
+        for (uint32_t it = 0; it < nb8; ++it, j += 8) {
+            const bool more = it + 1 < nb8;
+            eval4(Q[0], Q[1], Q[2], Q[3]);
+            if (more) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) Q[u] = bodies[j + 8 + u];
+            }
+            eval4(Q[4], Q[5], Q[6], Q[7]);
+            if (more) {
+#pragma unroll
+                for (int u = 4; u < 8; ++u) Q[u] = bodies[j + 8 + u];
+            }
+        }
+    }
+    for (; j < j1; ++j)      // < 8 bodies left (only when n is not a multiple of 8): one at a time
+        eval4(bodies[j], float4{0, 0, 0, 0}, float4{0, 0, 0, 0}, float4{0, 0, 0, 0});
+
+    float4* out = partial + (size_t)by * i_count;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const uint32_t il0 = blockIdx.x * IPB + (2 * g) * kBlock + tid;
+        const uint32_t il1 = il0 + kBlock;
+        if (il0 < i_count) out[il0] = float4{G * ax[g].x, G * ay[g].x, G * az[g].x, 0};
+        if (il1 < i_count) out[il1] = float4{G * ax[g].y, G * ay[g].y, G * az[g].y, 0};
+    }
+}
+
 // K2.  nbody3d.js:274-290 on all four components (the .w lane is integrated
 // too, exactly as the reference does; mass stays constant because vel.w = 0).
 // R lanes cooperate on one body: lane r sums partials r, r+R, r+2R, ... (ascending,

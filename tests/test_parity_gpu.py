@@ -22,7 +22,7 @@ TOL_POS, TOL_TIGHT, TOL_ACC = 1e-4, 2e-5, 2e-5
 
 # (force_variant, jsplit): every kernel instantiation, with and without a j-split
 VARIANTS = [(0, 0), (1, 1), (1, 3), (2, 1), (2, 2), (4, 1), (4, 4), (14, 1), (14, 2), (116, 1), (164, 1), (164, 2),
-            (22, 1), (22, 3), (24, 1), (24, 2), (28, 1), (28, 2)]
+            (22, 1), (22, 3), (24, 1), (24, 2), (28, 1), (28, 2), (34, 1), (34, 3), (38, 1), (38, 2)]
 
 
 def run_engine(b, v, dt, G, steps, a=None, **kw):
@@ -52,7 +52,7 @@ def test_single_step_matches_oracle_acceleration(variant, jsplit):
 
 
 @pytest.mark.parametrize("name,steps", [("plummer1024", 100), ("cube1000", 20), ("disk771", 50), ("galaxy_ref", 30)])
-@pytest.mark.parametrize("variant,jsplit", [(0, 0), (2, 1), (1, 2), (164, 1), (22, 1), (24, 2), (28, 1)])
+@pytest.mark.parametrize("variant,jsplit", [(0, 0), (2, 1), (1, 2), (164, 1), (22, 1), (24, 2), (28, 1), (38, 2)])
 def test_golden_trajectories(manifest, name, steps, variant, jsplit):
     """BASELINE.json config 1 (Plummer N=1024, dt=1e-3, 100 steps) and the
     ragged-N / harsh-mass-ratio fixtures, against fp64 and fp32 oracle vectors."""
