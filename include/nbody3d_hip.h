@@ -56,6 +56,9 @@ typedef enum nb_precision { NB_F32 = 0, NB_F64 = 1 } nb_precision;
 /* nb_config.flags */
 #define NB_FLAG_EXT_STREAM 1u /* ext_stream is meaningful even when NULL (the
                                  HIP null stream, e.g. torch's default stream) */
+#define NB_FLAG_XCD_REMAP 2u /* tuning/A-B: XCD-aware workgroup -> (i-block, j-split)
+                                mapping (measured: no gain for a VALU-bound kernel) */
+#define NB_FLAG_LDS_ONLY 4u  /* tuning/A-B: never pick the SGPR-broadcast force kernel */
 
 /* nb_array: selector for nb_device_ptr */
 typedef enum nb_array { NB_BODIES = 0, NB_VEL = 1, NB_ACCEL = 2 } nb_array;

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -52,6 +53,7 @@ struct nb_sim {
     int ipl = 1, ls = 1;
     bool packed = false;   // nb_force_pk (f32 only)
     bool sgpr = false;     // nb_force_pk_sgpr: j broadcast from SGPRs instead of the LDS tile
+    bool xcd_remap = false;
     uint32_t jsplit = 1, j_per_split = 0;
     std::string variant, err;
     nb_exchange_fn xfn = nullptr;
@@ -217,6 +219,11 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         if (js > hi) js = hi;
         if (js < 1) js = 1;
     }
+    // Long splits of the packed shapes run the SGPR-broadcast kernel: measured +4.0 % at
+    // N=262,144 and +1.8 % on the 1/8-shard shape, -1.2 % on 785-body splits (N=40,002), where
+    // the LDS tile's prefetch hides the first loads better (profiles/r01/sweep_sgpr_vs_lds.txt)
+    if (variant == 0 && sh.pk && sh.ipl >= 4 && !s->f64 && !(cfg.flags & NB_FLAG_LDS_ONLY) && split_len(js) >= 2048)
+        sh.sgpr = true;
     s->ipl = sh.ipl; s->ls = sh.ls; s->packed = sh.pk; s->sgpr = sh.sgpr;
     s->j_per_split = split_len(js);
     s->jsplit = ceil_div(n, s->j_per_split);   // a split may end up empty after rounding
@@ -246,7 +253,7 @@ void launch_force(nb_sim* s, int part = 0)
     using V4 = typename nb::vec4<T>::type;
     const Shape sh{s->ipl, s->ls, s->packed, s->sgpr};
     const uint32_t ipb = (nb::kBlock / s->ls) * s->ipl;
-    nb::SplitWindow win{0, 0xffffffffu, 0};
+    nb::SplitWindow win{0, 0xffffffffu, 0, s->xcd_remap ? 1u : 0u};
     uint32_t ny = s->jsplit;
     if (part == 1) { win.base = s->own_split0; ny = s->own_splits; }
     else if (part == 2) { win.hole_begin = s->own_split0; win.hole_count = s->own_splits; ny = s->jsplit - s->own_splits; }
@@ -379,6 +386,7 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     s->esz = s->f64 ? 8 : 4;
     s->eps2 = eps2;
     s->device = dev;
+    s->xcd_remap = (cfg.flags & NB_FLAG_XCD_REMAP) != 0;
 
     auto bail = [&](int code, const std::string& msg) {
         std::string m = msg;

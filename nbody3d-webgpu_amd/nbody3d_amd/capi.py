@@ -19,6 +19,8 @@ _LIB_PATH = os.path.normpath(os.path.join(_PKG, "..", "csrc", "libnbody3d_hip.so
 
 NB_F32, NB_F64 = 0, 1
 NB_FLAG_EXT_STREAM = 1
+NB_FLAG_XCD_REMAP = 2
+NB_FLAG_LDS_ONLY = 4
 STATUS = {0: "NB_OK", 1: "NB_ERR_INVALID", 2: "NB_ERR_NO_DEVICE", 3: "NB_ERR_HIP",
           4: "NB_ERR_STATE", 5: "NB_ERR_NOMEM", 6: "NB_ERR_COMM"}
 
@@ -119,7 +121,7 @@ class Simulation:
     uniforms, compute pipeline) bundle, nbody3d.js:13,179-204,296-311."""
 
     def __init__(self, n, precision="f32", eps2=None, device=-1, shard=None, stream=None, ext_bodies=None,
-                 force_variant=0, jsplit=0, tile=0):
+                 force_variant=0, jsplit=0, tile=0, flags=0):
         L = load_library()
         self._L = L
         self.n = int(n)
@@ -140,6 +142,7 @@ class Simulation:
             cfg.ext_bodies = ext_bodies
         cfg.force_variant = force_variant
         cfg.jsplit = jsplit
+        cfg.flags |= int(flags)
         h = C.c_void_p()
         rc = L.nb_create(C.byref(cfg), C.byref(h))
         if rc != 0:

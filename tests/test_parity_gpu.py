@@ -158,6 +158,23 @@ def test_ragged_sizes(n):
     assert np.abs(aa - ra).max() <= 2e-5 * max(np.abs(ra).max(), 1e-30), name
 
 
+@pytest.mark.parametrize("n", [9, 263, 1001, 4099])
+@pytest.mark.parametrize("variant", [34, 38])
+def test_ragged_sizes_on_the_sgpr_kernel(n, variant):
+    """The SGPR-broadcast kernel walks j in batches of 8 with a scalar remainder loop:
+    N not a multiple of 8 (and splits that end mid-batch) must still match the oracle."""
+    rng = np.random.default_rng(n)
+    b = np.zeros((n, 4), np.float32)
+    b[:, :3] = rng.random((n, 3)) * 2 - 1
+    b[:, 3] = rng.random(n) + 0.5
+    v = np.zeros((n, 4), np.float32)
+    bb, vv, aa, name = run_engine(b, v, 1e-3, 0.01, 2, force_variant=variant, jsplit=3)
+    assert "sgpr" in name
+    rb, rv, ra = oracle.run_f32(b, v, None, 1e-3, 0.01, 2)
+    assert rel_pos_err(bb, rb, 1.0) < 1e-6, name
+    assert np.abs(aa - ra).max() <= 2e-5 * max(np.abs(ra).max(), 1e-30), name
+
+
 def test_coincident_bodies_and_zero_mass():
     """Self term / coincident pairs contribute exactly 0 (eps2 > 0); zero-mass
     bodies exert nothing but still move."""

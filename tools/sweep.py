@@ -25,10 +25,10 @@ n = args.n
 b, v = ic.plummer(n, seed=1)
 if args.precision == "f64":
     b, v = b.astype(np.float64), v.astype(np.float64)
-cfgs = [tuple(int(x) for x in c.split(":")) for c in args.configs.split(",")]
+cfgs = [tuple(int(x) for x in (c.split(":") + ["0"])[:3]) for c in args.configs.split(",")]   # variant:jsplit[:flags]
 sims = []
-for var, js in cfgs:
-    s = Simulation(n, precision=args.precision, force_variant=var, jsplit=js,
+for var, js, fl in cfgs:
+    s = Simulation(n, precision=args.precision, force_variant=var, jsplit=js, flags=fl,
                    shard=None if args.shard == 1 else (0, n // args.shard))
     s.init(b, v)
     s.set_params(1e-3, 1.0)
@@ -51,5 +51,5 @@ for i, s in enumerate(sims):
     pairs = rows * (n - 1)
     rate = pairs / (f[0] * 1e-3)
     roof = 157.3e12 / 20 * (0.5 if args.precision == "f64" else 1.0)
-    print("%-34s %10.3f %10.3f %12.4e %8.2f %10.1f" % (s.variant, f[0], f[len(f) // 2], rate, 100 * rate / roof, 1e3 * g[0]))
+    print("%-34s %10.3f %10.3f %12.4e %8.2f %10.1f" % (s.variant + ("" if not cfgs[i][2] else "_flags%d" % cfgs[i][2]), f[0], f[len(f) // 2], rate, 100 * rate / roof, 1e3 * g[0]))
     s.close()
