@@ -219,10 +219,11 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         if (js > hi) js = hi;
         if (js < 1) js = 1;
     }
-    // Long splits of the packed shapes run the SGPR-broadcast kernel: measured +4.0 % at
-    // N=262,144 and +1.8 % on the 1/8-shard shape, -1.2 % on 785-body splits (N=40,002), where
-    // the LDS tile's prefetch hides the first loads better (profiles/r01/sweep_sgpr_vs_lds.txt)
-    if (variant == 0 && sh.pk && sh.ipl >= 4 && !s->f64 && !(cfg.flags & NB_FLAG_LDS_ONLY) && split_len(js) >= 2048)
+    // The packed shapes with 4 or 8 bodies per lane run the SGPR-broadcast kernel: measured
+    // +3..4 % at N=262,144, +2 % on the 1/8-shard shape, +3.5 % on the 785-body splits of
+    // N=40,002 (profiles/r01/sweep_sgpr_vs_lds.txt); the LDS-tile kernel keeps the short
+    // splits, the 2-bodies-per-lane shape, f64 and the LS shapes
+    if (variant == 0 && sh.pk && sh.ipl >= 4 && !s->f64 && !(cfg.flags & NB_FLAG_LDS_ONLY) && split_len(js) >= 512)
         sh.sgpr = true;
     s->ipl = sh.ipl; s->ls = sh.ls; s->packed = sh.pk; s->sgpr = sh.sgpr;
     s->j_per_split = split_len(js);

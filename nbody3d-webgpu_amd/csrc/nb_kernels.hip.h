@@ -353,8 +353,7 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
 // "scalar-load (SGPR) j-broadcast A/B against the LDS tile").  j is wave-uniform, so
 // bodies[j] is fetched with s_load_dwordx4 through the scalar cache and the packed ops
 // take the (x,y | z,m) SGPR pairs directly (op_sel broadcast): no LDS, no barrier, no
-// v_mov for the mass, workgroups need no tile synchronisation.  8 bodies live in SGPRs;
-// each half is reloaded for the next batch as soon as it has been consumed.  G is applied
+// v_mov for the mass, workgroups need no tile synchronisation.  G is applied
 // once to the finished sums (G * sum(m r^-3 d) instead of sum((G m) r^-3 d): rounding only).
 // Opt-in (variant 34/38); the LDS kernel stays the default -- measurement in DESIGN.md.
 template <int NG>
@@ -421,25 +420,51 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
         }
     };
 
+    // 2 x 4 bodies live in SGPRs, fetched with hand-placed s_load_dwordx16 (hipcc sinks a
+    // plain scalar load next to its first use, which exposes the whole latency).  SMEM
+    // returns out of order, so lgkmcnt(0) is the only usable wait; every wait sits BEFORE
+    // the next request, so it only drains a load issued one whole eval (4 bodies x NG groups
+    // = 1024 issue cycles at NG = 4) earlier.  The accumulators are threaded through every
+    // asm statement ("+v") so the packed math cannot drift across a wait or a request;
+    // nothing else in the loop uses lgkmcnt (no LDS), so hipcc inserts no waits of its own.
+    typedef float nb_f16 __attribute__((ext_vector_type(16)));
+    auto eval16 = [&](const nb_f16& q) {
+        eval4(float4{q[0], q[1], q[2], q[3]}, float4{q[4], q[5], q[6], q[7]}, float4{q[8], q[9], q[10], q[11]},
+              float4{q[12], q[13], q[14], q[15]});
+    };
+#define NB_ACC2 "+v"(ax[0]), "+v"(ax[1]), "+v"(ay[0]), "+v"(ay[1]), "+v"(az[0]), "+v"(az[1])
+#define NB_ACC4 "+v"(ax[0]), "+v"(ax[1]), "+v"(ax[2]), "+v"(ax[3]), "+v"(ay[0]), "+v"(ay[1]), "+v"(ay[2]), "+v"(ay[3]), \
+                "+v"(az[0]), "+v"(az[1]), "+v"(az[2]), "+v"(az[3])
+    auto wait_for = [&](nb_f16& q) {
+        if constexpr (NG == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q), NB_ACC4 : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q), NB_ACC2 : : "memory");
+    };
+    auto request_lo = [&](nb_f16& q, const float4* p) {   // bodies p[0..3]
+        if constexpr (NG == 4) asm volatile("s_load_dwordx16 %0, %13, 0x0" : "=s"(q), NB_ACC4 : "s"(p) : "memory");
+        else asm volatile("s_load_dwordx16 %0, %7, 0x0" : "=s"(q), NB_ACC2 : "s"(p) : "memory");
+    };
+    auto request_hi = [&](nb_f16& q, const float4* p) {   // bodies p[4..7]
+        if constexpr (NG == 4) asm volatile("s_load_dwordx16 %0, %13, 0x40" : "=s"(q), NB_ACC4 : "s"(p) : "memory");
+        else asm volatile("s_load_dwordx16 %0, %7, 0x40" : "=s"(q), NB_ACC2 : "s"(p) : "memory");
+    };
+#undef NB_ACC2
+#undef NB_ACC4
     const uint32_t nb8 = j1 > j0 ? (j1 - j0) / 8 : 0;
-    float4 Q[8];
+    const float4* pj = bodies + j0;
     uint32_t j = j0;
     if (nb8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) Q[u] = bodies[j + u];
-        for (uint32_t it = 0; it < nb8; ++it, j += 8) {
-            const bool more = it + 1 < nb8;
-            eval4(Q[0], Q[1], Q[2], Q[3]);
-            if (more) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u) Q[u] = bodies[j + 8 + u];
-            }
-            eval4(Q[4], Q[5], Q[6], Q[7]);
-            if (more) {
-#pragma unroll
-                for (int u = 4; u < 8; ++u) Q[u] = bodies[j + 8 + u];
-            }
+        nb_f16 A, B;
+        request_lo(A, pj);
+        for (uint32_t it = 0; it < nb8; ++it) {
+            wait_for(A);
+            request_hi(B, pj);
+            eval16(A);
+            wait_for(B);
+            pj += 8;
+            if (it + 1 < nb8) request_lo(A, pj);
+            eval16(B);
         }
+        j += nb8 * 8;
     }
     for (; j < j1; ++j)      // < 8 bodies left (only when n is not a multiple of 8): one at a time
         eval4(bodies[j], float4{0, 0, 0, 0}, float4{0, 0, 0, 0}, float4{0, 0, 0, 0});
