@@ -420,49 +420,46 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
         }
     };
 
-    // 2 x 4 bodies live in SGPRs, fetched with hand-placed s_load_dwordx16 (hipcc sinks a
+    // 2 x 4 bodies live in SGPRs, fetched with hand-placed s_load_dwordx4 (hipcc sinks a
     // plain scalar load next to its first use, which exposes the whole latency).  SMEM
     // returns out of order, so lgkmcnt(0) is the only usable wait; every wait sits BEFORE
     // the next request, so it only drains a load issued one whole eval (4 bodies x NG groups
     // = 1024 issue cycles at NG = 4) earlier.  The accumulators are threaded through every
     // asm statement ("+v") so the packed math cannot drift across a wait or a request;
     // nothing else in the loop uses lgkmcnt (no LDS), so hipcc inserts no waits of its own.
-    typedef float nb_f16 __attribute__((ext_vector_type(16)));
-    auto eval16 = [&](const nb_f16& q) {
-        eval4(float4{q[0], q[1], q[2], q[3]}, float4{q[4], q[5], q[6], q[7]}, float4{q[8], q[9], q[10], q[11]},
-              float4{q[12], q[13], q[14], q[15]});
-    };
+    typedef float nb_f4 __attribute__((ext_vector_type(4)));   // native vector: usable as an "s" asm operand
+    struct Quad { nb_f4 q0, q1, q2, q3; };   // 4 bodies = 16 SGPRs
+    auto f4 = [](const nb_f4& v) { return float4{v.x, v.y, v.z, v.w}; };
 #define NB_ACC2 "+v"(ax[0]), "+v"(ax[1]), "+v"(ay[0]), "+v"(ay[1]), "+v"(az[0]), "+v"(az[1])
 #define NB_ACC4 "+v"(ax[0]), "+v"(ax[1]), "+v"(ax[2]), "+v"(ax[3]), "+v"(ay[0]), "+v"(ay[1]), "+v"(ay[2]), "+v"(ay[3]), \
                 "+v"(az[0]), "+v"(az[1]), "+v"(az[2]), "+v"(az[3])
-    auto wait_for = [&](nb_f16& q) {
-        if constexpr (NG == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q), NB_ACC4 : : "memory");
-        else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q), NB_ACC2 : : "memory");
+#define NB_LOAD4(o) "s_load_dwordx4 %0, %" #o ", 0x0\n\ts_load_dwordx4 %1, %" #o ", 0x10\n\t" \
+                    "s_load_dwordx4 %2, %" #o ", 0x20\n\ts_load_dwordx4 %3, %" #o ", 0x30"
+    auto wait_for = [&](Quad& q) {
+        if constexpr (NG == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.q0), "+s"(q.q1), "+s"(q.q2), "+s"(q.q3), NB_ACC4 : : "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.q0), "+s"(q.q1), "+s"(q.q2), "+s"(q.q3), NB_ACC2 : : "memory");
     };
-    auto request_lo = [&](nb_f16& q, const float4* p) {   // bodies p[0..3]
-        if constexpr (NG == 4) asm volatile("s_load_dwordx16 %0, %13, 0x0" : "=s"(q), NB_ACC4 : "s"(p) : "memory");
-        else asm volatile("s_load_dwordx16 %0, %7, 0x0" : "=s"(q), NB_ACC2 : "s"(p) : "memory");
+    auto request = [&](Quad& q, const float4* p) {   // bodies p[0..3]
+        if constexpr (NG == 4) asm volatile(NB_LOAD4(16) : "=s"(q.q0), "=s"(q.q1), "=s"(q.q2), "=s"(q.q3), NB_ACC4 : "s"(p) : "memory");
+        else asm volatile(NB_LOAD4(10) : "=s"(q.q0), "=s"(q.q1), "=s"(q.q2), "=s"(q.q3), NB_ACC2 : "s"(p) : "memory");
     };
-    auto request_hi = [&](nb_f16& q, const float4* p) {   // bodies p[4..7]
-        if constexpr (NG == 4) asm volatile("s_load_dwordx16 %0, %13, 0x40" : "=s"(q), NB_ACC4 : "s"(p) : "memory");
-        else asm volatile("s_load_dwordx16 %0, %7, 0x40" : "=s"(q), NB_ACC2 : "s"(p) : "memory");
-    };
+#undef NB_LOAD4
 #undef NB_ACC2
 #undef NB_ACC4
     const uint32_t nb8 = j1 > j0 ? (j1 - j0) / 8 : 0;
     const float4* pj = bodies + j0;
     uint32_t j = j0;
     if (nb8) {
-        nb_f16 A, B;
-        request_lo(A, pj);
+        Quad A, B;
+        request(A, pj);
         for (uint32_t it = 0; it < nb8; ++it) {
             wait_for(A);
-            request_hi(B, pj);
-            eval16(A);
+            request(B, pj + 4);
+            eval4(f4(A.q0), f4(A.q1), f4(A.q2), f4(A.q3));
             wait_for(B);
             pj += 8;
-            if (it + 1 < nb8) request_lo(A, pj);
-            eval16(B);
+            if (it + 1 < nb8) request(A, pj);
+            eval4(f4(B.q0), f4(B.q1), f4(B.q2), f4(B.q3));
         }
         j += nb8 * 8;
     }
