@@ -42,7 +42,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=0, help="override N (default 262144)")
+    ap.add_argument("--nbodies", dest="n", type=int, default=0,
+                    help="override N (default 262144); not spelled --n: torch.distributed.run would claim it")
     ap.add_argument("--workload", default="plummer", choices=["plummer", "cube"])
     ap.add_argument("--precision", default="f32", choices=["f32", "f64"])
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
@@ -51,6 +52,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-check", action="store_true")
+    ap.add_argument("--exchange", default="nccl", choices=["nccl", "host"],
+                    help="host: REHEARSAL ONLY -- gloo group + host staging so several ranks can share one GPU "
+                         "(all ranks use device 0); the JSON line is marked and must not be quoted as a result")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the torch.distributed/RCCL exchange path even with one rank (plumbing test)")
     return ap.parse_args()
@@ -139,17 +143,24 @@ def main():
     if not os.path.exists(capi.library_path()) and rank == 0:
         import __graft_entry__
         __graft_entry__.build()       # fresh checkout: compile the engine (never a CPU fallback)
-    from nbody3d_amd.shard import ShardPlan, torch_allgather_hook, torch_allgather_overlapped_hooks
+    from nbody3d_amd.shard import (ShardPlan, torch_allgather_hook, torch_allgather_overlapped_hooks,
+                                   torch_allgather_via_host_hook)
 
     if not torch.cuda.is_available() or capi.device_count() < 1:
         sys.exit("bench.py: no GPU visible -- the engine has no CPU fallback")
+    rehearsal = args.exchange == "host"
+    if rehearsal:
+        local_rank = 0          # every rank shares device 0 (1-GPU development box)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:      # --force-dist without a launcher
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     n = args.n or (N_HEADLINE if args.scaling == "strong" or world == 1 else weak_n(world))
     G, dt = 1.0, 1e-3
@@ -166,7 +177,9 @@ def main():
                                dtype=torch.float64 if args.precision == "f64" else torch.float32)
         sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count), stream=stream.cuda_stream,
                          ext_bodies=t_bodies.data_ptr(), **kw)
-        if os.environ.get("NB_OVERLAP") == "1":
+        if rehearsal:
+            sim.set_exchange(torch_allgather_via_host_hook(t_bodies, plan))
+        elif os.environ.get("NB_OVERLAP") == "1":
             # opt-in: all-gather of step n issued async, waited for only after the own-rows force
             # splits of step n+1 (bit-identical results; not measurable on the 1-GPU dev box, so off by default)
             sim.set_exchange_overlapped(*torch_allgather_overlapped_hooks(t_bodies, plan))
@@ -198,7 +211,7 @@ def main():
     sim.enable_timing(False)
 
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -216,6 +229,16 @@ def main():
                    if world > 1 else "1gpu"},
         "frac_of_fp32_roofline": value / (roof_pairs * world),
     }
+    if rehearsal:
+        out["REHEARSAL"] = "ranks share one GPU, exchange staged through host memory over gloo: not a result"
+        if rank == 0:   # the sharded state must equal an unsharded run of the same number of steps
+            got = sim.read(vel=False, accel=False)[0][:n]
+            with Simulation(n, precision=args.precision, device=local_rank) as ref:
+                ref.init(bodies.astype(np_dtype), vel.astype(np_dtype))
+                ref.simulate(args.warmup + args.steps, dt, G)
+                want = ref.read(vel=False, accel=False)[0]
+            out["rehearsal_max_rel_diff_vs_unsharded"] = float(
+                np.abs(got[:, :3] - want[:, :3]).max() / np.abs(want[:, :3]).max())
     if launches:
         # K1 on THIS rank: algorithmic flops of one launch / measured launch time
         flops_launch = FLOPS_PER_PAIR * plan.count * (n - 1) if world > 1 else FLOPS_PER_PAIR * pairs_step

@@ -59,9 +59,15 @@ def torch_allgather_hook(bodies_tensor, plan, group=None):
     import torch.distributed as dist
 
     mine = bodies_tensor[plan.begin: plan.begin + plan.count]
+    # The send buffer is a separate 16*N/world-byte tensor refreshed by a device copy per step
+    # (microseconds) instead of an alias of the receive buffer: in-place all-gather is legal
+    # for RCCL itself, but nothing in torch.distributed's contract promises it for
+    # all_gather_into_tensor, and this path cannot be exercised with >1 rank on the dev box.
+    send = mine.clone()
 
     def hook(bodies_ptr, esz, n, sb, sc, stream):
-        dist.all_gather_into_tensor(bodies_tensor, mine, group=group)
+        send.copy_(mine)
+        dist.all_gather_into_tensor(bodies_tensor, send, group=group)
         return 0
 
     return hook
@@ -77,10 +83,12 @@ def torch_allgather_overlapped_hooks(bodies_tensor, plan, group=None):
     import torch.distributed as dist
 
     mine = bodies_tensor[plan.begin: plan.begin + plan.count]
+    send = mine.clone()          # see torch_allgather_hook
     state = {"work": None}
 
     def begin(bodies_ptr, esz, n, sb, sc, stream):
-        state["work"] = dist.all_gather_into_tensor(bodies_tensor, mine, group=group, async_op=True)
+        send.copy_(mine)
+        state["work"] = dist.all_gather_into_tensor(bodies_tensor, send, group=group, async_op=True)
         return 0
 
     def wait(stream):
@@ -90,3 +98,26 @@ def torch_allgather_overlapped_hooks(bodies_tensor, plan, group=None):
         return 0
 
     return begin, wait
+
+
+def torch_allgather_via_host_hook(bodies_tensor, plan, group=None):
+    """REHEARSAL ONLY (bench.py --exchange host): same exchange as torch_allgather_hook but
+    staged through host memory over a gloo group, so that several ranks can share ONE GPU
+    (RCCL refuses two ranks on one device).  Used to walk the whole multi-rank control flow
+    -- shard plan, engine on torch's stream with a torch-owned bodies buffer, hook, barrier,
+    max-over-ranks timing -- on the 1-GPU development box.  Never the measured path."""
+    import torch
+    import torch.distributed as dist
+
+    mine = bodies_tensor[plan.begin: plan.begin + plan.count]
+    host_all = torch.empty((plan.padded_n, 4), dtype=bodies_tensor.dtype).pin_memory()
+    host_mine = torch.empty((plan.count, 4), dtype=bodies_tensor.dtype).pin_memory()
+
+    def hook(bodies_ptr, esz, n, sb, sc, stream):
+        host_mine.copy_(mine)                       # D2H on the current stream, synchronous for pageable->pinned
+        torch.cuda.current_stream().synchronize()
+        dist.all_gather_into_tensor(host_all, host_mine, group=group)
+        bodies_tensor.copy_(host_all, non_blocking=False)
+        return 0
+
+    return hook
