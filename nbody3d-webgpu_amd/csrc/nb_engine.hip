@@ -150,7 +150,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
     struct Cand { Shape sh; double tile_cycles; };   // SIMD cycles one wave needs for a full 256-body tile
     const Cand f32c[] = {{{8, 1, true}, 65536}, {{4, 1, true}, 33600}, {{2, 1, true}, 17600},
                          {{1, 4, false}, 2400}, {{1, 16, false}, 800}, {{1, 64, false}, 280}};
-    const Cand f64c[] = {{{2, 1, false}, 51200}, {{1, 1, false}, 26400},
+    const Cand f64c[] = {{{2, 1, false}, 45000}, {{1, 1, false}, 23200},
                          {{1, 4, false}, 6400}, {{1, 16, false}, 1600}, {{1, 64, false}, 400}};
     const Cand* cands = s->f64 ? f64c : f32c;
     const int ncand = s->f64 ? 5 : 6;
@@ -206,9 +206,12 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 double cyc = full * round_cycles(occ);
                 if (rem) cyc += round_cycles((double)ceil_div((uint32_t)rem, (uint32_t)n_cu));
                 const double rounds = (double)full + (rem ? 1 : 0);
+                // every i-block streams all n rows through L2 once per step: what rules out many
+                // lanes per body at large N (f64, 64 lanes per body, N=262,144: 550 GB per step)
+                const double stream_s = (double)iblocks * n * 4 * s->esz / 8.0e12;
                 // K2 reads every split's partial back (and K1 writes it): priced at 2 TB/s so that, when the
                 // balance gain is a wash (N = 262,144: 32 vs 64 splits), the smaller HBM footprint wins
-                const double t = cyc / kClock / (1.0 - 0.03 / rounds) + (double)used * sc * 4 * s->esz / 2.0e12 + 3e-6;
+                const double t = std::max(cyc / kClock, stream_s) / (1.0 - 0.03 / rounds) + (double)used * sc * 4 * s->esz / 2.0e12 + 3e-6;
                 if (t < best_t) { best_t = t; if (variant == 0) sh = c.sh; js = q; }
             }
         }
