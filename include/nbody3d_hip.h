@@ -189,6 +189,8 @@ int nb_multi_step(nb_multi *m, uint32_t nsteps);
 int nb_multi_download(nb_multi *m, void *bodies, void *vel, void *accel);
 int nb_multi_sync(nb_multi *m);
 const char *nb_multi_last_error(nb_multi *m);
+/* Energy / momentum of the whole system: sum of the shards' nb_diagnostics (same out[5]). */
+int nb_multi_diagnostics(nb_multi *m, double out[5]);
 /* Name of shard 0's force-kernel variant (all shards resolve to the same shape). */
 const char *nb_multi_variant_name(nb_multi *m);
 

@@ -805,6 +805,20 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
     return NB_OK;
 }
 
+int nb_multi_diagnostics(nb_multi* m, double out[5])
+{
+    if (!m || !out) return NB_ERR_INVALID;
+    if (int rc = nb_multi_sync(m)) return rc;
+    for (int q = 0; q < 5; ++q) out[q] = 0.0;
+    for (nb_sim* s : m->shard) {
+        double part[5];
+        int rc = nb_diagnostics(s, part);      // zero-mass padding rows contribute exactly 0
+        if (rc != NB_OK) return mfail(m, rc, s->err);
+        for (int q = 0; q < 5; ++q) out[q] += part[q];
+    }
+    return NB_OK;
+}
+
 int nb_multi_download(nb_multi* m, void* bodies, void* vel, void* accel)
 {
     if (!m) return NB_ERR_INVALID;

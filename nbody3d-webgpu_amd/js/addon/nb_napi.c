@@ -48,6 +48,7 @@ static int (*p_multi_download)(nb_multi *, void *, void *, void *);
 static int (*p_multi_sync)(nb_multi *);
 static const char *(*p_multi_last_error)(nb_multi *);
 static const char *(*p_multi_variant_name)(nb_multi *);
+static int (*p_multi_diagnostics)(nb_multi *, double *);
 
 /* one JS handle = a single-device nb_sim or a single-process multi-device nb_multi */
 typedef struct { nb_sim *sim; nb_multi *multi; uint32_t n; int f64; } handle_t;
@@ -119,7 +120,7 @@ static napi_value js_load(napi_env env, napi_callback_info info)
         SYM(p_multi_upload, "nb_multi_upload"); SYM(p_multi_set_params, "nb_multi_set_params");
         SYM(p_multi_step, "nb_multi_step"); SYM(p_multi_download, "nb_multi_download");
         SYM(p_multi_sync, "nb_multi_sync"); SYM(p_multi_last_error, "nb_multi_last_error");
-        SYM(p_multi_variant_name, "nb_multi_variant_name");
+        SYM(p_multi_variant_name, "nb_multi_variant_name"); SYM(p_multi_diagnostics, "nb_multi_diagnostics");
 #undef SYM
         g_lib = h;
     }
@@ -392,10 +393,14 @@ static napi_value js_diagnostics(napi_env env, napi_callback_info info)
     size_t argc = 1; napi_value argv[1];
     CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
-    if (h->multi) { napi_throw_error(env, "NB_1", "diagnostics are not available on a multi-device handle"); return NULL; }
     double out[5];
-    int rc = p_diagnostics(h->sim, out);
-    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_diagnostics");
+    if (h->multi) {
+        int rcm = p_multi_diagnostics(h->multi, out);
+        if (rcm != NB_OK) return throw_msg(env, rcm, p_multi_last_error(h->multi), "nb_multi_diagnostics");
+    } else {
+        int rc = p_diagnostics(h->sim, out);
+        if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_diagnostics");
+    }
     napi_value o, v, arr;
     CHECK_NAPI(env, napi_create_object(env, &o));
     napi_create_double(env, out[0], &v); napi_set_named_property(env, o, "kinetic", v);

@@ -49,7 +49,8 @@ SYMBOLS = ["nb_abi_version", "nb_device_count", "nb_create", "nb_destroy", "nb_u
            "nb_set_exchange_overlapped", "nb_enable_timing",
            "nb_kernel_times", "nb_variant_name", "nb_diagnostics",
            "nb_multi_create", "nb_multi_destroy", "nb_multi_upload", "nb_multi_set_params", "nb_multi_step",
-           "nb_multi_download", "nb_multi_sync", "nb_multi_last_error", "nb_multi_variant_name"]
+           "nb_multi_download", "nb_multi_sync", "nb_multi_last_error", "nb_multi_variant_name",
+           "nb_multi_diagnostics"]
 
 _lib = None
 
@@ -100,6 +101,7 @@ def load_library():
     L.nb_multi_last_error.restype = C.c_char_p
     L.nb_multi_variant_name.argtypes = [vp]
     L.nb_multi_variant_name.restype = C.c_char_p
+    L.nb_multi_diagnostics.argtypes = [vp, C.POINTER(C.c_double)]
     _lib = L
     return L
 
@@ -365,6 +367,11 @@ class MultiSimulation:
         out = [np.zeros((self.n, 4), self.dtype) if f else None for f in (bodies, vel, accel)]
         self._check(self._L.nb_multi_download(self._h, _ptr(out[0]), _ptr(out[1]), _ptr(out[2])))
         return tuple(out)
+
+    def diagnostics(self):
+        out = (C.c_double * 5)()
+        self._check(self._L.nb_multi_diagnostics(self._h, out))
+        return out[0], out[1], np.array(out[2:5])
 
     @property
     def variant(self):

@@ -84,7 +84,9 @@ if (mode === 'cpu') {
   sm.simulate(100);
   const em = relPosErr(sm.read().bodies, loadF64('plummer1024_s100_bodies'), m.r_scale);
   check('gpu_multi_shard_handle_vs_f64_oracle', em < 2e-5, { err: em, variant: sm.variant() });
-  check('multi_has_no_diagnostics', throws(function () { sm.diagnostics(); }, /not available/));
+  const dm = sm.diagnostics();
+  check('multi_diagnostics_match_single', Math.abs(dm.kinetic - d.kinetic) < 1e-3 * Math.abs(d.kinetic) && dm.potential < 0, dm);
+  check('multi_has_no_kernel_timing', throws(function () { sm.kernelTimes(); }, /not available/));
   sm.destroy();
   // f64 simulation takes Float64Array
   const s64 = new nb.Simulation({ f64: true, G: m.G, dt: m.dt }).init([Float64Array.from(b0), Float64Array.from(v0)]);

@@ -381,6 +381,9 @@ def test_multi_handle_default_shape_and_noop():
         assert ms.read()[0].tobytes() == b.tobytes()
         ms.simulate(5, 1e-3, 1.0)
         got = ms.read()
+        ke, pe, mom = ms.diagnostics()
+    rke, rpe, _ = oracle.energy(got[0], got[1], 1.0)
+    assert abs(ke - rke) < 1e-9 * abs(rke) and abs(pe - rpe) < 1e-6 * abs(rpe)
     rb, _, _ = oracle.run_f64(b, v, None, 1e-3, 1.0, 5)
     assert rel_pos_err(got[0], rb, 1.0) < TOL_TIGHT
 
