@@ -61,9 +61,11 @@ def parse():
 
 
 def weak_n(g):
-    """Constant pairs per GPU: N_g = N_1 * sqrt(g), rounded to 256*g rows."""
+    """BASELINE.json config 4 weak-scaling series: constant pairs per GPU,
+    anchored at N = 1,048,576 on 8 GPUs: N_g = 1,048,576 * sqrt(g/8), rounded to 256*g rows
+    -> 370,688 / 524,288 / 741,376 / 1,048,576 for g = 1 / 2 / 4 / 8."""
     q = 256 * g
-    return int(round(N_HEADLINE * math.sqrt(g) / q)) * q
+    return int(round(1048576 * math.sqrt(g / 8.0) / q)) * q
 
 
 def cpu_baseline(bodies, G, seconds):
@@ -162,7 +164,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    n = args.n or (N_HEADLINE if args.scaling == "strong" or world == 1 else weak_n(world))
+    n = args.n or (N_HEADLINE if args.scaling == "strong" else weak_n(world))
     G, dt = 1.0, 1e-3
     bodies, vel = (ic.plummer(n, seed=1) if args.workload == "plummer" else ic.uniform_cube(n, seed=2))
     np_dtype = np.float64 if args.precision == "f64" else np.float32
