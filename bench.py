@@ -223,7 +223,7 @@ def main():
     out = {
         "metric": "pair-interactions/s", "value": value, "unit": "pair-interactions/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": args.scaling if world > 1 else "strong", "vs_baseline": None,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "N=%d %s, dt=1e-3, G=1, eps2=1e-4, i-sharded over %d GPU(s)" % (
             n, "Plummer sphere" if args.workload == "plummer" else "uniform cube", world),
