@@ -284,8 +284,8 @@ def test_shards_on_one_device_compose_to_the_single_handle_result():
     assert vel.tobytes() == ref[1].tobytes() and acc.tobytes() == ref[2].tobytes()
 
 
-@pytest.mark.parametrize("g", [2, 4])
-def test_overlapped_exchange_with_virtual_shards(g):
+@pytest.mark.parametrize("g,variant", [(2, 22), (4, 22), (2, 38), (4, 28)])
+def test_overlapped_exchange_with_virtual_shards(g, variant):
     """nb_set_exchange_overlapped on ONE GPU: g shard handles, each with its own
     torch-owned bodies buffer; wait() copies the other shards' rows (as they
     were before this step) on the engine's stream -- what the all-gather does.
@@ -295,7 +295,7 @@ def test_overlapped_exchange_with_virtual_shards(g):
     n, steps = 4096, 6
     per = n // g
     b, v = ic.plummer(n, seed=22)
-    kw = dict(force_variant=22, jsplit=8)             # j_per_split = 512 divides the shard rows
+    kw = dict(force_variant=variant, jsplit=8)        # j_per_split = 512 divides the shard rows
     with Simulation(n, **kw) as one:
         one.init(b, v)
         one.simulate(steps, 1e-3, 1.0)
