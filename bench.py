@@ -68,6 +68,16 @@ def weak_n(g):
     return int(round(1048576 * math.sqrt(g / 8.0) / q)) * q
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(bodies, G, seconds):
     """The oracle's threaded f32 kernel (kind 'port': the reference has no CPU
     path) on a bounded i-slice of the SAME workload."""
@@ -87,7 +97,7 @@ def cpu_baseline(bodies, G, seconds):
     out = {"value": rows * (n - 1) / dt, "unit": "pair-interactions/s", "cores": int(used), "kind": "port",
            "sample": "oracle/nb_oracle.c nbo_accel_f32_mt (f32, AVX clones, OpenMP over i): rows [0,%d) of the "
                      "N=%d workload against all N, %.1f s" % (rows, n, dt),
-           "host_cpus": os.cpu_count()}
+           "host_cpus": os.cpu_count(), "cpu_model": _cpu_model()}
     # BASELINE.md §4 'CPU-JS': the single-thread JavaScript restatement on config 1 (N=1,024)
     try:
         import shutil
