@@ -75,6 +75,16 @@ if (mode === 'cpu') {
   check('json_roundtrip_G', Math.abs(sim2.G - 1.0) < 1e-12 && sim2.nBodies === 1024);
   sim.step(); sim2.step();
   check('json_roundtrip_continues_identically', bitsEqual(sim.read().bodies, sim2.read().bodies));
+  // a checkpoint in the reference's full schema (camera block, plain arrays, G as a
+  // log10 string, util.js:186-201) restores and steps; the camera block is ignored
+  const refJson = JSON.parse(json);
+  refJson.camera = { target: [0, 0, 0], position: [0, 0, 10], radius: 10, azimuth: 0, elevation: 0, fov: 60, near: 0.1, far: 1e5 };
+  refJson.G = '-4.00';
+  const sim3 = new nb.Simulation({ dt: 1e-4 }).importJSON(JSON.stringify(refJson));
+  check('reference_schema_import', Math.abs(sim3.G - 1e-4) < 1e-18 && sim3.nBodies === 1024);
+  sim3.step(); const after = sim3.read();
+  check('reference_schema_steps', isFinite(after.bodies[0]) && after.accel[3] === 0);
+  sim3.destroy();
   // wrong array length is an error, not a crash
   check('bad_length_throws', throws(function () { sim.restore({ bodies: new Float32Array(8), vel: new Float32Array(8) }); }, /expected/));
   const d = sim.diagnostics();
