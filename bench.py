@@ -68,6 +68,13 @@ def weak_n(g):
     return int(round(1048576 * math.sqrt(g / 8.0) / q)) * q
 
 
+def _jsplit(variant_name):
+    try:
+        return int(variant_name.rsplit("_js", 1)[1])
+    except (IndexError, ValueError):
+        return 1
+
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -269,7 +276,10 @@ def main():
                            "note": "compute-bound on the fp32 vector-FMA rate (157.3 TFLOP/s spec, equal to the "
                                    "dense f32 MFMA peak); not HBM and not MFMA: rsqrt-bound scalar FMA",
                            "integrate_kernel_avg_ms": i_ms,
-                           "integrate_kernel_GBps": 96.0 * plan.count / (i_ms * 1e-3) / 1e9 if i_ms > 0 else None}
+                           # algorithmic 96 B per body; "moved" adds the jsplit partials K2 sums
+                           "integrate_kernel_GBps": 96.0 * plan.count / (i_ms * 1e-3) / 1e9 if i_ms > 0 else None,
+                           "integrate_kernel_GBps_moved": (96.0 + 16.0 * _jsplit(sim.variant)) * plan.count /
+                                                          (i_ms * 1e-3) / 1e9 if i_ms > 0 else None}
     if e_start is not None:
         # total-energy drift of THIS run (north_star: "with total-energy drift reported"): one extra
         # untimed step so that KE(vel after call n) pairs with PE(positions before call n)
