@@ -148,7 +148,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
     auto split_len = [&](uint32_t js) { return ceil_div(ceil_div(n, js), 8u) * 8u; };
 
     struct Cand { Shape sh; double tile_cycles; };   // SIMD cycles one wave needs for a full 256-body tile
-    const Cand f32c[] = {{{8, 1, true}, 65536}, {{4, 1, true}, 33600}, {{2, 1, true}, 17600},
+    const Cand f32c[] = {{{8, 1, true}, 65536}, {{4, 1, true}, 34600}, {{2, 1, true}, 17900},
                          {{1, 4, false}, 2400}, {{1, 16, false}, 800}, {{1, 64, false}, 280}};
     const Cand f64c[] = {{{2, 1, false}, 45000}, {{1, 1, false}, 23200},
                          {{1, 4, false}, 6400}, {{1, 16, false}, 1600}, {{1, 64, false}, 400}};
