@@ -3,8 +3,12 @@
 // Two kernels replace the reference's single WGSL compute pass
 // (/root/reference nbody3d.js:219-292):
 //
-//   K1 nb_force<T,IPL,LS>   tiled O(N^2) softened-gravity accumulation
-//                           (nbody3d.js:232-237 pair force, :255-272 tile loop)
+//   K1 nb_force*            tiled O(N^2) softened-gravity accumulation
+//                           (nbody3d.js:232-237 pair force, :255-272 tile loop), three forms:
+//                             nb_force_pk_sgpr<NG>   f32, packed math, j broadcast from SGPRs (default for
+//                                                    large systems: +3..4 % over the LDS tile)
+//                             nb_force_pk<NG,LS>     f32, packed math, j-tile staged in LDS
+//                             nb_force<T,IPL,LS>     scalar template: f64, and LS lanes per body (small N)
 //   K2 nb_integrate<T>      the "velocity verlet with frame shift" update
 //                           (nbody3d.js:274-290)
 //
@@ -21,7 +25,7 @@
 //     at LS consecutive addresses when LS lanes share one i-body (small N);
 //   * each lane keeps IPL i-bodies in VGPRs (register blocking: 1 LDS read per
 //     IPL*64 pairs), loaded with coalesced 16-B accesses (lane stride 16 B);
-//   * f32 default, nb_force_pk: the arithmetic is packed across TWO i-bodies of
+//   * f32, nb_force_pk / nb_force_pk_sgpr: the arithmetic is packed across TWO i-bodies of
 //     the lane (v_pk_add/fma/mul_f32): per two pairs 3 v_pk_add, 3 v_pk_fma
 //     (r^2 + eps2), 2 v_pk_mul (cube), 2 v_rsq_f32, 1 v_pk_mul (G*m_j), 3 v_pk_fma
 //     (accumulate) = 12 packed (4 cycles each) + 2 transcendental (8 cycles each)
