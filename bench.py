@@ -8,19 +8,29 @@ N>1 the position all-gather) over the whole particle set, inputs already
 resident in HBM.  Prints ONE JSON line on rank 0.
 
     python bench.py                      # 1 GPU, N=262,144 Plummer sphere
+    python bench.py --gpus 8             # starts its own 8 ranks (torch.distributed.run child)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
-        --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8
+        --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8     # or under a launcher
 
 Multi-GPU: one process per GPU; the i-bodies are sharded (rank r owns a
 contiguous row block); every rank keeps the full bodies array
-in HBM and the ranks all-gather their new rows each step through
-torch.distributed (backend nccl = RCCL over xGMI).  Default --scaling strong:
-the metric is quoted at N=262,144 for every GPU count.
+in HBM and the ranks all-gather their new rows each step: the engine's own
+in-place ncclAllGather (RCCL over xGMI) enqueued right after the integrate
+kernel (--exchange native, default), or torch.distributed's all-gather through
+the exchange hook (--exchange torch).  Default --scaling strong: the metric is
+quoted at N=262,144 for every GPU count.
+
+The line is only printed with a value when the run's own correctness checks
+pass (a sampled row of the benchmarked launch shape against an fp64 direct sum,
+replica agreement across ranks, the N=1,024 golden fixture); otherwise the
+value is null and the exit code 1.
 """
 import argparse
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +45,7 @@ for p in (ROOT, PKG):
 FLOPS_PER_PAIR = 20            # literal op count of nbody3d.js:233-236,266
 PEAK_FP32_TFLOPS = 157.3       # MI355X_MICROARCH.md:41 'Peak FP32 (vector)' (spec)
 N_HEADLINE = 262144            # BASELINE.json metric / configs[2]
+EPS2 = 1e-4                    # nbody3d.js:234
 
 
 def parse():
@@ -49,14 +60,19 @@ def parse():
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"])
     ap.add_argument("--variant", type=int, default=0)
     ap.add_argument("--jsplit", type=int, default=0)
+    ap.add_argument("--flags", type=int, default=0, help="nb_config.flags (NB_FLAG_LDS_ONLY = 4, NB_FLAG_NO_FUSE = 8)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
-    ap.add_argument("--no-check", action="store_true")
-    ap.add_argument("--exchange", default="nccl", choices=["nccl", "host"],
-                    help="host: REHEARSAL ONLY -- gloo group + host staging so several ranks can share one GPU "
-                         "(all ranks use device 0); the JSON line is marked and must not be quoted as a result")
+    ap.add_argument("--no-check", action="store_true", help="skip the N=1,024 fixture check (the sampled-row check of "
+                                                            "the benchmarked shape always runs)")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch", "host"],
+                    help="native: the engine's own in-place ncclAllGather; torch: torch.distributed all-gather through "
+                         "the exchange hook; host: REHEARSAL ONLY -- gloo group + host staging so several ranks can "
+                         "share one GPU (all ranks use device 0); the JSON line is marked and must not be quoted")
+    ap.add_argument("--overlap", action="store_true",
+                    help="start the all-gather asynchronously and hide it behind the next step's own-row force work")
     ap.add_argument("--force-dist", action="store_true",
-                    help="run the torch.distributed/RCCL exchange path even with one rank (plumbing test)")
+                    help="run the distributed exchange path even with one rank (plumbing test)")
     return ap.parse_args()
 
 
@@ -75,6 +91,23 @@ def _jsplit(variant_name):
         return 1
 
 
+def spawn_ranks(args):
+    """`bench.py --gpus N` without a launcher: this process stays GPU-free (no HIP call, no torch
+    import) and starts the N ranks as a child `python -m torch.distributed.run`; it exits with
+    the child's code.  Never exec()s: a process that has touched the GPU must not be replaced."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    return subprocess.call(cmd, env=env)
+
+
+# ---- CPU baseline -------------------------------------------------------------------------------
+
 def _cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -85,30 +118,73 @@ def _cpu_model():
     return "unknown"
 
 
+def usable_cpus():
+    """CPUs this process may really use: the affinity mask, cut by the cgroup CPU quota."""
+    info = {"os_cpu_count": os.cpu_count()}
+    try:
+        aff = len(os.sched_getaffinity(0))
+    except AttributeError:
+        aff = os.cpu_count() or 1
+    info["sched_affinity"] = aff
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                info["cgroup_cpu_max"] = " ".join(txt)
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                info["cgroup_cfs_quota"] = "%g/%g" % (q, per)
+                if q > 0:
+                    quota = q / per
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    use = aff if quota is None else max(1, min(aff, int(quota + 0.5)))
+    info["usable"] = use
+    for k in ("OMP_NUM_THREADS", "OMP_PROC_BIND", "OMP_PLACES"):
+        info[k] = os.environ.get(k)
+    return info
+
+
 def cpu_baseline(bodies, G, seconds):
     """The oracle's threaded f32 kernel (kind 'port': the reference has no CPU
-    path) on a bounded i-slice of the SAME workload."""
+    path) on a bounded i-slice of the SAME workload: once on one thread, once on
+    every CPU this process can use (affinity mask and cgroup quota, not the host's core count)."""
     from oracle import oracle
     n = bodies.shape[0]
-    t0 = time.perf_counter()
-    _, used = oracle.accel_f32_mt(bodies, G, i0=0, i1=min(256, n))
-    t_probe = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    _, used = oracle.accel_f32_mt(bodies, G, i0=0, i1=min(256, n))   # warm
-    t_probe = min(t_probe, time.perf_counter() - t0)
-    rows = int(min(n, max(256, 256 * seconds / max(t_probe, 1e-6))))
+    cpus = usable_cpus()
+    nthreads = cpus["usable"]
+
+    def timed(rows, threads):
+        t0 = time.perf_counter()
+        _, used = oracle.accel_f32_mt(bodies, G, i0=0, i1=rows, nthreads=threads)
+        return time.perf_counter() - t0, used
+
+    probe = min(256, n)
+    timed(probe, 1)
+    t1, _ = timed(probe, 1)                                             # warm, one thread
+    rows1 = int(min(n, max(probe, probe * 0.25 * seconds / max(t1, 1e-6))))
+    d1, _ = timed(rows1, 1)
+    one = rows1 * (n - 1) / d1
+    timed(probe, nthreads)
+    tm, _ = timed(min(n, probe * nthreads), nthreads)
+    rows = int(min(n, max(probe, probe * nthreads * 0.75 * seconds / max(tm, 1e-6))))
     rows = max(256, (rows // 256) * 256) if n >= 256 else n
-    t0 = time.perf_counter()
-    _, used = oracle.accel_f32_mt(bodies, G, i0=0, i1=rows)
-    dt = time.perf_counter() - t0
-    out = {"value": rows * (n - 1) / dt, "unit": "pair-interactions/s", "cores": int(used), "kind": "port",
+    dm, used = timed(rows, nthreads)
+    allv = rows * (n - 1) / dm
+    out = {"value": allv, "unit": "pair-interactions/s", "cores": int(used), "kind": "port",
            "sample": "oracle/nb_oracle.c nbo_accel_f32_mt (f32, AVX clones, OpenMP over i): rows [0,%d) of the "
-                     "N=%d workload against all N, %.1f s" % (rows, n, dt),
-           "host_cpus": os.cpu_count(), "cpu_model": _cpu_model()}
+                     "N=%d workload against all N on %d threads, %.1f s; one thread: rows [0,%d), %.1f s"
+                     % (rows, n, used, dm, rows1, d1),
+           "one_thread_value": one, "threads_x_one_thread": used * one, "parallel_efficiency": allv / (used * one),
+           "cpus": cpus, "cpu_model": _cpu_model()}
     # BASELINE.md §4 'CPU-JS': the single-thread JavaScript restatement on config 1 (N=1,024)
     try:
         import shutil
-        import subprocess
         node = shutil.which("node")
         if node:
             p = subprocess.run([node, os.path.join(ROOT, "oracle", "js_baseline.js"), "40"], capture_output=True,
@@ -121,10 +197,11 @@ def cpu_baseline(bodies, G, seconds):
     return out
 
 
+# ---- correctness gates ----------------------------------------------------------------------------
+
 def fixture_check():
-    """Correctness gate in the same run: the N=1,024 Plummer
-    fixture, 100 steps, against the committed fp64 golden vector (data files
-    only -- the oracle is not imported here)."""
+    """The N=1,024 Plummer fixture, 100 steps, against the committed fp64 golden vector (data
+    files only -- the oracle is not imported here)."""
     from nbody3d_amd import Simulation
     g = os.path.join(ROOT, "tests", "golden")
     man = json.load(open(os.path.join(g, "manifest.json")))["plummer1024"]
@@ -140,22 +217,40 @@ def fixture_check():
         sim.step()
         ke, _, _ = sim.diagnostics()           # KE of vel after it
         b = sim.read(vel=False, accel=False)[0]
+        name = sim.variant
     d = np.abs(b[:, :3].astype(np.float64) - ref[:, :3]).max(1)
     err = float((d / np.maximum(np.sqrt((ref[:, :3] ** 2).sum(1)), man["r_scale"])).max())
     e0 = ke0 + pe0
-    return {"fixture": "plummer1024 dt=1e-3 100 steps", "max_rel_pos_err_vs_f64_oracle": err, "tolerance": 1e-4,
-            "energy_drift": abs((ke + pe_prev - e0) / e0), "pass": bool(err < 1e-4)}
+    return {"fixture": "plummer1024 dt=1e-3 100 steps", "kernel_variant": name, "max_rel_pos_err_vs_f64_oracle": err,
+            "tolerance": 1e-4, "energy_drift": abs((ke + pe_prev - e0) / e0), "pass": bool(err < 1e-4)}
+
+
+def sampled_rows_check(bodies64, accel, rows, G, tol):
+    """Accelerations of a few rows of the BENCHMARKED launch shape against an fp64 direct sum
+    over all N bodies done here in numpy (nbody3d.js:232-237 arithmetic, j != i)."""
+    worst = 0.0
+    x = bodies64[:, :3]
+    gm = G * bodies64[:, 3]
+    for i in rows:
+        d = x - x[i]
+        r2 = (d * d).sum(1) + EPS2
+        w = gm / (r2 * np.sqrt(r2))
+        w[i] = 0.0
+        ref = (w[:, None] * d).sum(0)
+        err = np.abs(accel[i, :3].astype(np.float64) - ref).max() / max(np.abs(ref).max(), 1e-3)
+        worst = max(worst, float(err))
+    return {"rows": [int(r) for r in rows], "max_rel_err_vs_fp64_direct_sum": worst, "tolerance": tol,
+            "pass": bool(worst < tol)}
 
 
 def main():
     args = parse()
+    if "RANK" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py: --gpus %d needs a torch.distributed.run launch (one process per GPU)" % args.gpus)
-        args.gpus = world
+    args.gpus = world
 
     import torch
     from nbody3d_amd import Simulation, capi, ic
@@ -165,9 +260,14 @@ def main():
     from nbody3d_amd.shard import (ShardPlan, torch_allgather_hook, torch_allgather_overlapped_hooks,
                                    torch_allgather_via_host_hook)
 
+    rehearsal = args.exchange == "host"
+    ndev = torch.cuda.device_count()          # counting devices does not initialise the GPU
+    if ndev < 1:
+        sys.exit("bench.py: no GPU visible -- the engine has no CPU fallback")
+    if world > ndev and not rehearsal:
+        sys.exit("bench.py: %d ranks need %d GPUs, %d visible (one process per GPU)" % (world, world, ndev))
     if not torch.cuda.is_available() or capi.device_count() < 1:
         sys.exit("bench.py: no GPU visible -- the engine has no CPU fallback")
-    rehearsal = args.exchange == "host"
     if rehearsal:
         local_rank = 0          # every rank shares device 0 (1-GPU development box)
     torch.cuda.set_device(local_rank)
@@ -188,24 +288,49 @@ def main():
     plan = ShardPlan(n, world, rank)
     bodies_p, vel_p = plan.pad(bodies.astype(np_dtype)), plan.pad(vel.astype(np_dtype))
 
-    stream = torch.cuda.current_stream()
-    kw = dict(precision=args.precision, device=local_rank, force_variant=args.variant, jsplit=args.jsplit)
+    overlap = args.overlap or os.environ.get("NB_OVERLAP") == "1"
+    kw = dict(precision=args.precision, device=local_rank, force_variant=args.variant, jsplit=args.jsplit,
+              flags=args.flags)
+    exchange = {"kind": "none"}
+    t_bodies = None
     if dist is not None:
-        # torch owns the replicated bodies array so the collective runs on it directly
-        t_bodies = torch.empty((plan.padded_n, 4), device="cuda",
-                               dtype=torch.float64 if args.precision == "f64" else torch.float32)
-        sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count), stream=stream.cuda_stream,
-                         ext_bodies=t_bodies.data_ptr(), **kw)
-        if rehearsal:
-            sim.set_exchange(torch_allgather_via_host_hook(t_bodies, plan))
-        elif os.environ.get("NB_OVERLAP") == "1":
-            # opt-in: all-gather of step n issued async, waited for only after the own-rows force
-            # splits of step n+1 (bit-identical results; not measurable on the 1-GPU dev box, so off by default)
-            sim.set_exchange_overlapped(*torch_allgather_overlapped_hooks(t_bodies, plan))
-        else:
-            sim.set_exchange(torch_allgather_hook(t_bodies, plan))
+        sim = None
+        if args.exchange == "native":
+            # the engine owns stream and buffers; the only thing the host moves is the ncclUniqueId
+            try:
+                uid = torch.zeros(capi.NB_RCCL_ID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(capi.rccl_unique_id()), dtype=torch.uint8))
+                dist.broadcast(uid, src=0)
+                sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count), **kw)
+                sim.rccl_attach(bytes(uid.cpu().numpy().tobytes()), world, rank, overlap=overlap)
+                nr, rk, ver = sim.rccl_info()
+                exchange = {"kind": "rccl-native in-place ncclAllGather on the engine stream" +
+                                    (" (overlapped: own-row force work first)" if overlap else ""),
+                            "rccl_nranks": nr, "rccl_rank": rk, "rccl_version": ver}
+            except Exception as e:     # keep the run alive on torch's collective, and say so
+                if sim is not None:
+                    sim.close()
+                sim = None
+                exchange = {"native_attach_failed": str(e)}
+        if sim is None:
+            # torch owns the replicated bodies array so its collective runs on it directly
+            stream = torch.cuda.current_stream()
+            t_bodies = torch.empty((plan.padded_n, 4), device="cuda",
+                                   dtype=torch.float64 if args.precision == "f64" else torch.float32)
+            sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count), stream=stream.cuda_stream,
+                             ext_bodies=t_bodies.data_ptr(), **kw)
+            if rehearsal:
+                sim.set_exchange(torch_allgather_via_host_hook(t_bodies, plan))
+                exchange["kind"] = "REHEARSAL host-staged gloo"
+            elif overlap:
+                sim.set_exchange_overlapped(*torch_allgather_overlapped_hooks(t_bodies, plan))
+                exchange["kind"] = "torch.distributed all_gather_into_tensor (nccl = RCCL), async, via exchange hooks"
+            else:
+                sim.set_exchange(torch_allgather_hook(t_bodies, plan))
+                exchange["kind"] = "torch.distributed all_gather_into_tensor (nccl = RCCL) via exchange hook"
     else:
-        sim = Simulation(plan.padded_n, stream=stream.cuda_stream, **kw)
+        sim = Simulation(plan.padded_n, **kw)
     sim.init(bodies_p, vel_p)
     sim.set_params(dt, G)
 
@@ -215,24 +340,54 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def all_ranks(flag):
+        if dist is None:
+            return bool(flag)
+        t = torch.tensor([1 if flag else 0], device="cpu" if rehearsal else "cuda", dtype=torch.int32)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
     e_start = None
-    if world == 1 and dist is None and not args.no_check:
+    if world == 1 and dist is None:
         ke0, pe0, _ = sim.diagnostics()          # fp64 on the device; outside the timed region
         e_start = ke0 + pe0
-    sim.simulate(args.warmup)
+
+    # gate 1: the benchmarked launch shape itself -- accelerations of the first step, a few rows of
+    # this rank's shard, against an fp64 direct sum (done in numpy here; not the oracle)
+    sim.simulate(1)
+    acc = sim.read(bodies=False, vel=False)[2]
+    lo, hi = plan.begin, min(plan.begin + plan.count, n)
+    rows = np.unique(np.linspace(lo, hi - 1, 6).astype(np.int64)) if hi > lo else np.array([], np.int64)
+    shape_check = sampled_rows_check(bodies.astype(np.float64), acc, rows, G,
+                                     1e-11 if args.precision == "f64" else 2e-5)
+    shape_check["kernel_variant"] = sim.variant
+    shape_ok = all_ranks(shape_check["pass"])
+
+    sim.simulate(max(args.warmup - 1, 0))
     barrier()
     sim.enable_timing(True)
     t0 = time.perf_counter()
     sim.simulate(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    f_ms, i_ms, launches = sim.kernel_times()
+    f_ms, i_ms, x_ms, launches = sim.step_times()
     sim.enable_timing(False)
 
     if dist is not None:
         t = torch.tensor([elapsed], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # gate 2 (distributed runs): every rank must hold the same replicated position array
+    replicas_ok, replica_note = True, None
+    if dist is not None:
+        mine = sim.read(vel=False, accel=False)[0]
+        digest = float(np.abs(mine[:n, :3].astype(np.float64)).sum())
+        t = torch.tensor([digest, -digest], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        replicas_ok = bool(t[0].item() == -t[1].item()) and bool(np.isfinite(digest))
+        replica_note = {"abs_sum_of_positions_max_over_ranks": float(t[0].item()),
+                        "abs_sum_of_positions_min_over_ranks": float(-t[1].item()), "pass": replicas_ok}
 
     pairs_step = n * (n - 1)
     value = pairs_step * args.steps / elapsed
@@ -244,17 +399,25 @@ def main():
         "dtype": args.precision, "data": "synthetic",
         "config": {"workload": "N=%d %s, dt=1e-3, G=1, eps2=1e-4, i-sharded over %d GPU(s)" % (
             n, "Plummer sphere" if args.workload == "plummer" else "uniform cube", world),
-            "n": n, "kernel_variant": sim.variant, "parallelism": ("ishard%d+allgather%s" % (world, "(overlapped)" if os.environ.get("NB_OVERLAP") == "1" else ""))
-                   if world > 1 else "1gpu"},
+            "n": n, "kernel_variant": sim.variant,
+            "parallelism": ("ishard%d+allgather%s" % (world, "(overlapped)" if overlap else "")) if world > 1 else "1gpu"},
         "frac_of_fp32_roofline": value / (roof_pairs * world),
+        "shape_check": shape_check,
     }
+    if dist is not None:
+        exchange["avg_ms"] = x_ms
+        exchange["bytes_sent_per_rank"] = int(plan.count * 4 * (8 if args.precision == "f64" else 4))
+        out["exchange"] = exchange
+        out["per_rank"] = {"rank": rank, "rows": plan.count, "force_kernel_avg_ms": f_ms, "integrate_kernel_avg_ms": i_ms,
+                           "exchange_avg_ms": x_ms}
+        out["replica_check"] = replica_note
     if rehearsal:
         out["REHEARSAL"] = "ranks share one GPU, exchange staged through host memory over gloo: not a result"
         if rank == 0:   # the sharded state must equal an unsharded run of the same number of steps
             got = sim.read(vel=False, accel=False)[0][:n]
             with Simulation(n, precision=args.precision, device=local_rank) as ref:
                 ref.init(bodies.astype(np_dtype), vel.astype(np_dtype))
-                ref.simulate(args.warmup + args.steps, dt, G)
+                ref.simulate(max(args.warmup, 1) + args.steps, dt, G)
                 want = ref.read(vel=False, accel=False)[0]
             out["rehearsal_max_rel_diff_vs_unsharded"] = float(
                 np.abs(got[:, :3] - want[:, :3]).max() / np.abs(want[:, :3]).max())
@@ -263,41 +426,57 @@ def main():
         flops_launch = FLOPS_PER_PAIR * plan.count * (n - 1) if world > 1 else FLOPS_PER_PAIR * pairs_step
         peak = PEAK_FP32_TFLOPS * (0.5 if args.precision == "f64" else 1.0)
         achieved = flops_launch / (f_ms * 1e-3) / 1e12
-        traffic = None
+        # HBM bytes per launch come from the PMC profile of the SAME kernel variant (separate
+        # rocprofv3 --pmc passes, tools/gpu_prof.sh); any other shape reports null
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "k1_hbm_traffic.json")
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
-            if tj.get("n") == n and tj.get("n_gpus", 1) == world and tj.get("dtype") == args.precision:
-                traffic = tj.get("bytes_per_launch")
-        out["roofline"] = {"kernel": "nb_force<%s> (%s)" % (args.precision, sim.variant), "bound": "valu",
+            if (tj.get("n") == n and tj.get("n_gpus", 1) == world and tj.get("dtype") == args.precision and
+                    tj.get("kernel_variant") == sim.variant):
+                traffic, traffic_src = tj.get("bytes_per_launch"), "profiles/k1_hbm_traffic.json (" + tj.get("source", "") + ")"
+        fused = "fused" in sim.variant
+        out["roofline"] = {"kernel": ("nb_step_fused" if fused else "nb_force") + "<%s> (%s)" % (args.precision, sim.variant),
+                           "bound": "valu",
                            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                           "traffic": traffic, "avg_launch_ms": f_ms, "launches": launches,
+                           "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": f_ms, "launches": launches,
                            "flops_per_pair": FLOPS_PER_PAIR,
                            "note": "compute-bound on the fp32 vector-FMA rate (157.3 TFLOP/s spec, equal to the "
                                    "dense f32 MFMA peak); not HBM and not MFMA: rsqrt-bound scalar FMA",
-                           "integrate_kernel_avg_ms": i_ms,
-                           # algorithmic 96 B per body; "moved" adds the jsplit partials K2 sums
-                           "integrate_kernel_GBps": 96.0 * plan.count / (i_ms * 1e-3) / 1e9 if i_ms > 0 else None,
-                           "integrate_kernel_GBps_moved": (96.0 + 16.0 * _jsplit(sim.variant)) * plan.count /
-                                                          (i_ms * 1e-3) / 1e9 if i_ms > 0 else None}
+                           "integrate_kernel_avg_ms": i_ms}
+        if i_ms > 0:
+            # algorithmic 96 B per body; "moved" adds the jsplit partials K2 sums.
+            # At this size the state is cache-resident: the HBM figure of K2 is tools/k2_hbm.py (N >= 4M)
+            js = _jsplit(sim.variant)
+            moved = 96.0 if js == 1 else 96.0 + 16.0 * js
+            out["roofline"]["integrate_kernel_GBps"] = 96.0 * plan.count / (i_ms * 1e-3) / 1e9
+            out["roofline"]["integrate_kernel_GBps_moved"] = moved * plan.count / (i_ms * 1e-3) / 1e9
+            out["roofline"]["integrate_bytes_moved_over_algorithmic"] = moved / 96.0
     if e_start is not None:
         # total-energy drift of THIS run (north_star: "with total-energy drift reported"): one extra
         # untimed step so that KE(vel after call n) pairs with PE(positions before call n)
         _, pe_prev, _ = sim.diagnostics()
         sim.step()
         ke, _, _ = sim.diagnostics()
-        out["energy_drift_over_run"] = {"steps": args.warmup + args.steps + 1,
+        out["energy_drift_over_run"] = {"steps": max(args.warmup, 1) + args.steps + 1,
                                         "dE_rel": abs((ke + pe_prev - e_start) / e_start)}
-    if rank == 0 and world == 1 and not args.no_check:
-        out["check"] = fixture_check()
     sim.close()
+    ok = shape_ok and replicas_ok
+    if rank == 0 and not args.no_check:
+        out["check"] = fixture_check()
+        ok = ok and out["check"]["pass"]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(bodies, G, args.cpu_seconds)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if not ok:
+        out["invalid"] = "a correctness check failed in this run: the throughput is withheld"
+        out["withheld_value"] = out["value"]
+        out["value"] = None
     if rank == 0:
         print(json.dumps(out))
+    sys.exit(0 if ok else 1)
 
 
 if __name__ == "__main__":

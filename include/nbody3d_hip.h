@@ -37,7 +37,7 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built -fvisibility=hidden */
 #endif
 
-#define NB_ABI_VERSION 1u
+#define NB_ABI_VERSION 2u
 
 typedef struct nb_sim nb_sim; /* opaque */
 
@@ -48,7 +48,8 @@ typedef enum nb_status {
     NB_ERR_HIP = 3,       /* a HIP runtime call failed                       */
     NB_ERR_STATE = 4,     /* call out of order (e.g. step before upload)     */
     NB_ERR_NOMEM = 5,
-    NB_ERR_COMM = 6       /* the exchange hook / collective failed           */
+    NB_ERR_COMM = 6,      /* the exchange hook / collective failed           */
+    NB_NOT_READY = 7      /* nb_frame_acquire(wait = 0): no finished frame yet */
 } nb_status;
 
 typedef enum nb_precision { NB_F32 = 0, NB_F64 = 1 } nb_precision;
@@ -56,9 +57,11 @@ typedef enum nb_precision { NB_F32 = 0, NB_F64 = 1 } nb_precision;
 /* nb_config.flags */
 #define NB_FLAG_EXT_STREAM 1u /* ext_stream is meaningful even when NULL (the
                                  HIP null stream, e.g. torch's default stream) */
-#define NB_FLAG_XCD_REMAP 2u /* tuning/A-B: XCD-aware workgroup -> (i-block, j-split)
-                                mapping (measured: no gain for a VALU-bound kernel) */
+/* 2u was NB_FLAG_XCD_REMAP in ABI 1 (an XCD-aware workgroup mapping, measured useless for this
+ * VALU-bound kernel -- profiles/r01/xcd_remap_ab.txt -- and removed); the bit is ignored. */
 #define NB_FLAG_LDS_ONLY 4u  /* tuning/A-B: never pick the SGPR-broadcast force kernel */
+#define NB_FLAG_NO_FUSE 8u   /* tuning/A-B: never pick the fused one-launch step (force kernel +
+                                integrate kernel instead; bit-identical results) */
 
 /* nb_array: selector for nb_device_ptr */
 typedef enum nb_array { NB_BODIES = 0, NB_VEL = 1, NB_ACCEL = 2 } nb_array;
@@ -92,7 +95,12 @@ typedef struct nb_config {
      * directly on it).  NULL -> engine allocates.                              */
     void *ext_bodies;
     /* Force-kernel launch shape overrides for tuning; 0 -> engine heuristics.  */
-    uint32_t force_variant; /* see nb_variant_name()                            */
+    uint32_t force_variant; /* 6 decimal digits K II LL X: K = 1 scalar loop, 2 packed f32 with
+                               the j-tile in LDS, 3 packed f32 with j broadcast from SGPRs,
+                               4 fused one-launch step (packed, LDS tile); II = bodies per
+                               lane (01..08); LL = lanes sharing a body (01..64); X = tile
+                               units staged at once (K = 2, 4: 1 or 4) or waves splitting j
+                               (K = 3: 1 or 4).  E.g. 402644.  See nb_variant_name().    */
     uint32_t jsplit;        /* number of j-partitions (grid.y)                  */
     uint32_t flags;         /* NB_FLAG_*                                        */
     uint32_t reserved[5];
@@ -142,7 +150,8 @@ const char *nb_last_error(nb_sim *s);
 /* ---- multi-GPU support (no reference analogue) ----------- */
 
 /* Device address of a state array (bodies: 4*n elements, replicated;
- * vel/accel: 4*shard_count elements). */
+ * vel/accel: 4*shard_count elements).  Valid until the next nb_step: a fused handle
+ * ping-pongs between two position buffers, a jsplit = 1 handle swaps accel buffers. */
 int nb_device_ptr(nb_sim *s, int which /* nb_array */, void **out);
 
 /* Exchange hook: called on the calling thread once per step, after the
@@ -167,6 +176,24 @@ int nb_set_exchange(nb_sim *s, nb_exchange_fn fn, void *user);
  * not line up with the shard boundaries.  Replaces any one-phase hook. */
 typedef int (*nb_exchange_wait_fn)(void *user, void *hip_stream);
 int nb_set_exchange_overlapped(nb_sim *s, nb_exchange_fn begin, nb_exchange_wait_fn wait, void *user);
+
+/* ---- native RCCL collective, one process per GPU (SURVEY.md §8(e) "Collective") -----------
+ * Instead of an exchange hook the engine itself issues the per-step all-gather of position
+ * rows: ncclAllGather, in place (send pointer = bodies + rank * rows), on the engine's stream
+ * right after the integrate kernel -- no host code between the kernels of a step.  The host
+ * only transports the 128-byte ncclUniqueId from rank 0 to the other ranks (any channel).
+ * Every rank owns the same number of rows: n == nranks * shard_count and
+ * shard_begin == rank * shard_count (pad with zero-mass rows).  librccl is loaded on first
+ * use (dlopen; a copy already loaded into the process -- e.g. PyTorch's -- is reused). */
+#define NB_RCCL_ID_BYTES 128
+#define NB_RCCL_OVERLAP 1u /* all-gather on its own stream, hidden behind the next step's force
+                              work on the rank's OWN j-range (see nb_set_exchange_overlapped) */
+int nb_rccl_unique_id(void *id_out /* NB_RCCL_ID_BYTES */);
+int nb_rccl_attach(nb_sim *s, const void *id, int nranks, int rank, uint32_t flags);
+int nb_rccl_detach(nb_sim *s);
+/* Communicator facts for reports: ncclCommCount / ncclCommUserRank and RCCL's version code
+ * (0 when no communicator is attached). */
+int nb_rccl_info(nb_sim *s, int *nranks, int *rank, int *rccl_version);
 
 /* ---- single-process multi-device (for hosts that cannot run one process per
  *      GPU, e.g. Node; no reference analogue) --------------------------------
@@ -193,6 +220,16 @@ const char *nb_multi_last_error(nb_multi *m);
 int nb_multi_diagnostics(nb_multi *m, double out[5]);
 /* Name of shard 0's force-kernel variant (all shards resolve to the same shape). */
 const char *nb_multi_variant_name(nb_multi *m);
+/* How the shards exchange their new rows after a step:
+ *   NB_MULTI_PEER  g*(g-1) hipMemcpyAsync device-to-device copies ordered by HIP events (default);
+ *   NB_MULTI_RCCL  ncclCommInitAll over the shards' devices once, then per step
+ *                  ncclGroupStart / in-place ncclAllGather on every shard's stream / ncclGroupEnd
+ *                  (SURVEY.md §8(e)).  Needs every shard on its own device.
+ * Results are bit-identical; the choice is a measured A/B. */
+typedef enum nb_multi_collective { NB_MULTI_PEER = 0, NB_MULTI_RCCL = 1 } nb_multi_collective;
+int nb_multi_set_collective(nb_multi *m, int mode /* nb_multi_collective */);
+/* mode in use, communicator size (0 for NB_MULTI_PEER), RCCL version code. */
+int nb_multi_collective_info(nb_multi *m, int *mode, int *nranks, int *rccl_version);
 
 /* ---- measurement (role of TimingHelper, util.js:297-423) ------------------- */
 
@@ -203,10 +240,34 @@ const char *nb_multi_variant_name(nb_multi *m);
 int nb_enable_timing(nb_sim *s, int on);
 int nb_kernel_times(nb_sim *s, double *force_ms, double *integrate_ms,
                     uint32_t *launches);
+/* Same, plus the average time of the native RCCL all-gather (0 when none ran).  A fused
+ * one-launch step reports its whole kernel as force_ms and 0 for integrate_ms. */
+int nb_step_times(nb_sim *s, double *force_ms, double *integrate_ms, double *exchange_ms,
+                  uint32_t *launches);
+/* Runs ONLY the integrate kernel `reps` times back to back on the state as it stands (the
+ * force sums are whatever the last force pass left; first zeroed if none ran) and returns
+ * the average launch time: the memory-bound kernel measured on its own at sizes where a
+ * full O(N^2) step would take minutes (N >= 4M: state no longer cache-resident).  The
+ * particle state is garbage afterwards -- measurement only; not available on a fused handle. */
+int nb_integrate_pass(nb_sim *s, uint32_t reps, double *avg_ms);
 
 /* Name of the force-kernel variant a handle resolved to (for reports), e.g.
- * "f32_lds256_ipl2_js4".  Valid until nb_destroy. */
+ * "f32pk_fused_lds1024_ipl2_ls64" or "f32pk_sgpr_ipl8_ws4_js8".  Valid until nb_destroy. */
 const char *nb_variant_name(nb_sim *s);
+
+/* ---- viewer frame feed ------------------------------------------------
+ * The reference's render pass reads bodyBuffer and velBuffer in place every frame
+ * (nbody3d.js:408-415,482-487: billboard position + radius from (x,y,z,mass), colour from
+ * length(vel.xyz), :380).  A host-side viewer gets the same two arrays without stalling the
+ * step stream: nb_frame_request enqueues a small pack kernel behind the steps issued so far
+ * (f32 bodies[4n] + speed[n] into a staging buffer) and the copy to pinned host memory runs
+ * on a second stream beside the following steps.  nb_frame_acquire returns the newest frame
+ * that has landed: pointers into engine-owned pinned memory, valid until the second
+ * nb_frame_request after the one that produced it (two slots).  On a shard handle speed[]
+ * is filled for the handle's own rows only. */
+int nb_frame_request(nb_sim *s);
+int nb_frame_acquire(nb_sim *s, int wait, const float **bodies, const float **speed,
+                     uint64_t *step_index);
 
 /* ---- on-device diagnostics (no reference analogue) ------- */
 

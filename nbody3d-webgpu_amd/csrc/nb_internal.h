@@ -1,0 +1,103 @@
+// nb_internal.h -- state shared by the translation units of libnbody3d_hip.so
+// (nb_engine.hip: single handle; nb_comm.hip: RCCL loader, per-process collective,
+// nb_multi).  Not part of the ABI.
+#pragma once
+#include "../../include/nbody3d_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+// e[0]..e[1]: force launch(es) issued before a pending gather is waited for (or the only
+// force launch, or the whole fused step); e[3]..e[4]: force launch issued after it;
+// e[1]/e[4]..e[2]: integrate; e[2]..e[5]: position exchange (RCCL all-gather on the engine stream).
+struct nb_events { hipEvent_t e[6]; bool two, xchg; };
+
+struct nb_rccl;   // nb_comm.hip
+
+struct nb_frame_slot {
+    float* h_bodies = nullptr;     // pinned host, 4*n floats
+    float* h_speed = nullptr;      // pinned host, n floats
+    float* d_bodies = nullptr;     // device staging
+    float* d_speed = nullptr;
+    hipEvent_t packed = nullptr;   // staging written (engine stream)
+    hipEvent_t landed = nullptr;   // host copy complete (frame stream)
+    uint64_t step = 0;
+    bool in_flight = false, valid = false;
+};
+
+struct nb_sim {
+    uint32_t n = 0, sb = 0, sc = 0;
+    bool f64 = false;
+    size_t esz = 4;
+    int device = 0;
+    double eps2 = 1e-4;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // bodies[cur] is the live position array.  The fused step (force + integrate in ONE launch)
+    // reads bodies[cur] and writes bodies[cur ^ 1] (ping-pong: removes the in-place race of the
+    // reference, nbody3d.js:283 vs :257); two-kernel steps stay in bodies[cur].
+    void* bodies[2] = {nullptr, nullptr};
+    int cur = 0;
+    bool own_bodies = false;
+    void* vel = nullptr;
+    void* acc = nullptr;
+    void* partial = nullptr;
+    double* diag = nullptr;
+    uint32_t diag_blocks = 0;
+    double dt = 0.0, G = 0.0;
+    bool params_set = false, uploaded = false;
+    uint64_t steps_done = 0;
+    // launch shape
+    int ipl = 1, ls = 1;
+    bool packed = false;   // nb_force_pk (f32 only)
+    bool sgpr = false;     // nb_force_pk_sgpr: j broadcast from SGPRs instead of the LDS tile
+    int ws = 1;            // SGPR kernel: waves of a workgroup that split the j-range (1 or 4)
+    int tl = 1;            // LDS kernels: 256-body tiles staged at once (1 or 4)
+    bool fused = false;    // nb_step_fused: K2 folded into K1's epilogue (jsplit == 1, whole system)
+    int acc_parity = 0;    // swap_acc: how often acc/partial have swapped roles (mod 2)
+    bool swap_acc = false; // two-kernel step with jsplit == 1: K2 reads the partial as a_new and the
+                           // acc/partial buffers swap roles (96 B per body)
+    uint32_t jsplit = 1, j_per_split = 0;
+    std::string variant, err;
+    nb_exchange_fn xfn = nullptr;
+    nb_exchange_wait_fn xwait = nullptr;   // non-null: two-phase (overlapped) exchange
+    void* xuser = nullptr;
+    bool gather_pending = false;           // begin() called, wait() not yet
+    uint32_t own_split0 = 0, own_splits = 0;   // j-splits lying entirely inside this shard's rows
+    nb_rccl* rccl = nullptr;               // per-process RCCL communicator (nb_rccl_attach)
+    bool timing = false;
+    // HIP-graph replay of multi-step calls (launch-bound small N): kGraphChunk steps captured
+    // once per (dt, G, buffer parity) and replayed
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    double graph_dt = 0.0, graph_G = 0.0;
+    int graph_cur = 0;
+    bool graphs_ok = true;           // cleared if capture ever fails: fall back to plain launches
+    std::vector<nb_events> pool;     // recycled events
+    std::vector<nb_events> pending;
+    size_t pool_next = 0;
+    // viewer frame feed
+    hipStream_t frame_stream = nullptr;
+    nb_frame_slot frame[2];
+    int frame_next = 0;              // slot the next request writes
+    int frame_latest = -1;           // most recently requested slot
+};
+
+namespace nbi {
+
+int fail(nb_sim* s, int code, const std::string& msg);
+void set_create_error(const std::string& msg);
+const std::string& create_error();
+
+// nb_comm.hip: called by nb_step after the integrate kernel when a communicator is attached.
+// begin: enqueue the in-place all-gather of this rank's rows (on the engine stream, or on the
+// communicator's own stream when overlapped); wait: make the engine stream wait for it.
+int rccl_exchange_begin(nb_sim* s);
+int rccl_exchange_wait(nb_sim* s);
+bool rccl_overlapped(const nb_sim* s);
+void rccl_release(nb_sim* s);
+
+}  // namespace nbi

@@ -1,45 +1,41 @@
 // nb_kernels.hip.h -- device code of the MI355X (gfx950) direct N-body engine.
 //
-// Two kernels replace the reference's single WGSL compute pass
-// (/root/reference nbody3d.js:219-292):
+// The reference runs ONE WGSL compute pass per frame (/root/reference nbody3d.js:219-292):
+// tiled O(N^2) softened-gravity accumulation (:232-237 pair force, :255-272 tile loop)
+// followed by the "velocity verlet with frame shift" update (:274-290), writing positions in
+// place (:283) while other workgroups still stage them (:257) -- a cross-workgroup race.
+// Here a step is well defined in both of its forms:
 //
-//   K1 nb_force*            tiled O(N^2) softened-gravity accumulation
-//                           (nbody3d.js:232-237 pair force, :255-272 tile loop), three forms:
-//                             nb_force_pk_sgpr<NG>   f32, packed math, j broadcast from SGPRs (default for
-//                                                    large systems: +3..4 % over the LDS tile)
-//                             nb_force_pk<NG,LS>     f32, packed math, j-tile staged in LDS
-//                             nb_force<T,IPL,LS>     scalar template: f64, and LS lanes per body (small N)
-//   K2 nb_integrate<T>      the "velocity verlet with frame shift" update
-//                           (nbody3d.js:274-290)
+//   two kernels   K1 nb_force*   (reads positions only)  ->  K2 nb_integrate (after all of K1)
+//   one kernel    nb_step_fused  (reads bodies_in, writes bodies_out: ping-pong buffers)
 //
-// The split is what makes a step well defined: the reference writes positions
-// in place (:283) while other workgroups still stage them (:257); here K1 only
-// reads positions and K2 only runs after every K1 block has finished.
+//   K1 forms:   nb_force_pk_sgpr<NG,WS>  f32, packed math, j broadcast from SGPRs (large systems)
+//               nb_force_pk<NG,LS,TL>    f32, packed math, j-tile staged in LDS
+//               nb_force<T,IPL,LS>       scalar template: f64, and the unpacked f32 shapes
+//   fused form: nb_step_fused<NG,LS,TL>  nb_force_pk's loop over ALL j + the integrator in the
+//                                        epilogue (no j-split across workgroups: LS lanes of a
+//                                        wave share an i-body instead) -- one launch per step,
+//                                        no partial sums through memory
 //
-// CDNA4 mapping of K1 (wave = 64 lanes, 4 SIMDs/CU, 160 KiB LDS/CU):
-//   * a 256-thread workgroup (4 waves, one per SIMD) stages a 256-body j-tile
-//     (x, y, z, G*m) in LDS, double buffered, ONE s_barrier per tile; the next
-//     tile's global_load_dwordx4 is in flight while the current tile computes;
+// CDNA4 mapping of the force loop (wave = 64 lanes, 4 SIMDs/CU, 160 KiB LDS/CU):
+//   * a 256-thread workgroup (4 waves, one per SIMD) stages a j-tile of 256*TL bodies
+//     (x, y, z, G*m) in LDS, double buffered, ONE s_barrier per tile; the next tile's
+//     global_load_dwordx4 is in flight while the current tile computes;
 //   * the inner loop reads the tile with ds_read_b128 at a wave-uniform address
 //     (LDS broadcast: one read feeds 64*IPL pair evaluations) -- LS == 1 -- or
-//     at LS consecutive addresses when LS lanes share one i-body (small N);
-//   * each lane keeps IPL i-bodies in VGPRs (register blocking: 1 LDS read per
-//     IPL*64 pairs), loaded with coalesced 16-B accesses (lane stride 16 B);
-//   * f32, nb_force_pk / nb_force_pk_sgpr: the arithmetic is packed across TWO i-bodies of
-//     the lane (v_pk_add/fma/mul_f32): per two pairs 3 v_pk_add, 3 v_pk_fma
-//     (r^2 + eps2), 2 v_pk_mul (cube), 2 v_rsq_f32, 1 v_pk_mul (G*m_j), 3 v_pk_fma
-//     (accumulate) = 12 packed (4 cycles each) + 2 transcendental (8 cycles each)
-//     = 64 issue cycles per 128 pairs, issued stage-major over 4 independent
-//     chains so no hazard s_nop is needed.  nb_force is the scalar template
-//     (13 VALU per pair) used for f64 and for the LS > 1 shapes;
-//   * no branch in the loop: with eps2 > 0 the self term is exactly 0*finite = 0
-//     and bodies past the split are staged as zero-mass;
-//   * when LS > 1 the LS partial sums of a body are reduced with wavefront
-//     shuffles before one lane stores;
-//   * grid = (i-blocks, jsplit): j is also partitioned over blockIdx.y (any
-//     multiple of 8 bodies per split, exact trip count on the last partial tile)
-//     so that small i-counts (N = 65,536, or a 1/8 shard) still fill every SIMD;
-//     K2 sums the jsplit partials in ascending order (deterministic, no atomics).
+//     at LS consecutive addresses when LS lanes share one i-body;
+//   * each lane keeps IPL i-bodies in VGPRs (register blocking), loaded with coalesced 16-B accesses;
+//   * f32: the arithmetic is packed across TWO i-bodies of the lane (v_pk_add/fma/mul_f32):
+//     per two pairs 3 v_pk_add, 3 v_pk_fma (r^2 + eps2), 2 v_pk_mul (cube), 2 v_rsq_f32,
+//     1 v_pk_mul (G*m_j), 3 v_pk_fma (accumulate) = 12 packed (4 cycles each) + 2 transcendental
+//     (8 cycles each) = 64 issue cycles per 128 pairs, issued stage-major over 4 independent
+//     chains so no hazard s_nop is needed;
+//   * no branch in the loop: with eps2 > 0 the self term is exactly 0*finite = 0 and bodies
+//     past the range are staged as zero-mass;
+//   * LS > 1: the LS partial sums of a body are reduced inside the wave (DPP row operations
+//     and row broadcasts for f32, wavefront shuffles for f64) before ONE lane stores/integrates;
+//   * grid = (i-blocks, jsplit): j may also be partitioned over blockIdx.y (any multiple of 8
+//     bodies per split); K2 sums the jsplit partials in ascending order (deterministic, no atomics).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -51,20 +47,8 @@ template <> struct vec4<float> { using type = float4; };
 template <> struct vec4<double> { using type = double4; };
 
 constexpr int kBlock = 256;  // threads per workgroup = reference TILE_SIZE (nbody3d.js:4,240)
-constexpr int kTile = 256;   // j-bodies per LDS tile (nbody3d.js:229)
+constexpr int kTile = 256;   // j-bodies per LDS tile unit (nbody3d.js:229); TL units are staged at once
 
-__device__ __forceinline__ float nb_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }  // bare v_rsq_f32 (1 ulp)
-// v_rsq_f64 seed (~2^-26) + one Newton step y(1 + e/2), e = 1 - x y^2: 4 DP ops
-// instead of ocml rsqrt()'s 5 + class test + 2 selects.  x is clamped so an
-// overflowed d^6 cannot turn into inf*0 = NaN (such pairs then contribute ~1e-150*m,
-// i.e. nothing; the f32 path gets the reference's exact 0 from v_rsq_f32(inf)).
-__device__ __forceinline__ double nb_rsqrt(double x)
-{
-    x = __builtin_fmin(x, 1e300);
-    const double y = __builtin_amdgcn_rsq(x);
-    const double e = __builtin_fma(-x * y, y, 1.0);
-    return __builtin_fma(y * e, 0.5, y);
-}
 __device__ __forceinline__ float nb_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double nb_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
@@ -74,7 +58,6 @@ __device__ __forceinline__ double nb_fma(double a, double b, double c) { return 
 // all-gather of the other ranks' rows has landed, the rest (hole = own splits).
 struct SplitWindow {
     uint32_t base, hole_begin, hole_count;
-    uint32_t xcd_remap;   // 1: XCD-aware workgroup mapping (see xcd_remap below)
     __device__ __forceinline__ uint32_t split(uint32_t y) const
     {
         uint32_t b = y + base;
@@ -83,41 +66,94 @@ struct SplitWindow {
     }
 };
 
-// XCD-aware workgroup -> (i-block, j-split) mapping.  MI355X deals workgroups round-robin
-// over its 8 XCDs in dispatch order (x fastest), and every XCD has its own 4 MiB L2.  With
-// the plain mapping each j-split (one 16-B row per body, streamed by all gridDim.x i-blocks)
-// is pulled into all 8 L2s; with this remap all workgroups that stream a given j-split sit
-// on ONE XCD (splits k, k+8, k+16, ... belong to XCD k), so the replicated bodies array is
-// fetched once per step instead of 8 times (FETCH_SIZE 33.7 MB -> 4.x MB at N=262,144).
-// Placement only changes speed/traffic, never results (MI355X_MICROARCH.md, XCD placement).
-__device__ __forceinline__ void xcd_remap(uint32_t& bx, uint32_t& by, uint32_t enable)
-{
-    const uint32_t gx = gridDim.x, gy = gridDim.y;
-    bx = blockIdx.x; by = blockIdx.y;
-    if (enable && (gy & 7u) == 0) {
-        const uint32_t lin = bx + by * gx;
-        const uint32_t xcd = lin & 7u, slot = lin >> 3;
-        by = xcd + 8u * (slot / gx);
-        bx = slot % gx;
-    }
-}
-
 // One pair: nbody3d.js:232-237 with b.w already multiplied by G at staging
 // time ((G*m)*inv is the reference's left-associated product, :236).
-template <typename T>
-__device__ __forceinline__ void pair(const T bx, const T by, const T bz, const T bgm, const T xi, const T yi, const T zi,
-                                     const T eps2, T& ax, T& ay, T& az)
+__device__ __forceinline__ void pair(const float bx, const float by, const float bz, const float bgm, const float xi,
+                                     const float yi, const float zi, const float eps2, float& ax, float& ay, float& az)
 {
-    const T dx = bx - xi, dy = by - yi, dz = bz - zi;                  // :233
-    const T d2 = nb_fma(dz, dz, nb_fma(dy, dy, nb_fma(dx, dx, eps2)));  // :234 (contracted; WGSL permits it)
-    const T d6 = d2 * d2 * d2;                                         // :235
-    const T s = bgm * nb_rsqrt(d6);                                    // :235-236
-    ax = nb_fma(s, dx, ax);                                            // :266
+    const float dx = bx - xi, dy = by - yi, dz = bz - zi;                    // :233
+    const float d2 = nb_fma(dz, dz, nb_fma(dy, dy, nb_fma(dx, dx, eps2)));    // :234 (contracted; WGSL permits it)
+    const float d6 = d2 * d2 * d2;                                           // :235
+    const float s = bgm * __builtin_amdgcn_rsqf(d6);                         // :235-236, bare v_rsq_f32 (1 ulp)
+    ax = nb_fma(s, dx, ax);                                                  // :266
     ay = nb_fma(s, dy, ay);
     az = nb_fma(s, dz, az);
 }
 
-// K1.  partial[by * i_count + il] = sum over this block's j-range.
+// f64 pair.  v_rsq_f64 costs 16 issue cycles and every other DP instruction 4 (measured,
+// profiles/r02/ubench3_*.txt), so the body is built to need the fewest DP instructions:
+//   y0 = v_rsq_f64(d2)  (relative error |e|/2, e = 1 - d2*y0^2, |e| <~ 2^-26)
+//   d2^(-3/2) = y0^3 (1 - e)^(-3/2) = y0^3 (1 + 3e/2 + 15e^2/8 + ...)   -> first order: error < 2 e^2 ~ 4e-16
+// = 15 DP instructions + the seed per pair (round 1: d2^3, seed, one Newton step = 16 + seed + a clamp).
+// d2 must stay finite (|x| < 1e150): an infinite d2 would give 0*inf in e.
+__device__ __forceinline__ void pair(const double bx, const double by, const double bz, const double bgm,
+                                     const double xi, const double yi, const double zi, const double eps2, double& ax,
+                                     double& ay, double& az)
+{
+    const double dx = bx - xi, dy = by - yi, dz = bz - zi;
+    const double d2 = nb_fma(dz, dz, nb_fma(dy, dy, nb_fma(dx, dx, eps2)));
+    const double y = __builtin_amdgcn_rsq(d2);
+    const double y2 = y * y;
+    const double e = nb_fma(-d2, y2, 1.0);
+    const double p3 = (bgm * y) * y2;
+    const double s = nb_fma(p3 * e, 1.5, p3);
+    ax = nb_fma(s, dx, ax);
+    ay = nb_fma(s, dy, ay);
+    az = nb_fma(s, dz, az);
+}
+
+// ---- sum over the LS consecutive lanes that share an i-body ------------------------------
+// f32: DPP row operations inside a 16-lane row (quad_perm xor 1, xor 2, row_half_mirror,
+// row_mirror: one v_add_f32 with a DPP operand per step, no LDS traffic), then row_bcast15 /
+// row_bcast31 across rows.  The full sum is valid in the LAST lane of the group (js == LS-1);
+// for LS <= 16 in every lane.  Fixed order: deterministic.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v)
+{
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false);
+    return v + __builtin_bit_cast(float, t);
+}
+template <int LS>
+__device__ __forceinline__ float group_sum(float v)
+{
+    if constexpr (LS >= 2) v = dpp_add<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+    if constexpr (LS >= 4) v = dpp_add<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+    if constexpr (LS >= 8) v = dpp_add<0x141, 0xF>(v);    // row_half_mirror
+    if constexpr (LS >= 16) v = dpp_add<0x140, 0xF>(v);   // row_mirror
+    if constexpr (LS >= 32) v = dpp_add<0x142, 0xA>(v);   // row_bcast15 into rows 1 and 3
+    if constexpr (LS >= 64) v = dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
+    return v;
+}
+template <int LS>
+__device__ __forceinline__ double group_sum(double v)
+{
+#pragma unroll
+    for (int m = 1; m < LS; m <<= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+// ---- the integrator: nbody3d.js:274-290 on all four components (the .w lane is integrated
+// too, exactly as the reference does; mass stays constant because vel.w = 0) -------------------
+template <typename T>
+__device__ __forceinline__ void leapfrog(const typename vec4<T>::type& x, const typename vec4<T>::type& v,
+                                         const typename vec4<T>::type& ao, const T ax, const T ay, const T az, const T dt,
+                                         typename vec4<T>::type& nx, typename vec4<T>::type& nv,
+                                         typename vec4<T>::type& na)
+{
+    na.x = ax; na.y = ay; na.z = az;
+    na.w = 0;                                                           // :274
+    const T h = dt * T(0.5);                                            // :276
+    nv.x = nb_fma(ao.x + na.x, h, v.x);                                 // :280
+    nv.y = nb_fma(ao.y + na.y, h, v.y);
+    nv.z = nb_fma(ao.z + na.z, h, v.z);
+    nv.w = nb_fma(ao.w + na.w, h, v.w);
+    nx.x = nb_fma(nb_fma(h, na.x, nv.x), dt, x.x);                      // :283
+    nx.y = nb_fma(nb_fma(h, na.y, nv.y), dt, x.y);
+    nx.z = nb_fma(nb_fma(h, na.z, nv.z), dt, x.z);
+    nx.w = nb_fma(nb_fma(h, na.w, nv.w), dt, x.w);
+}
+
+// K1, scalar template.  partial[by * i_count + il] = sum over this block's j-range.
 //   IPL: i-bodies per lane group; LS: lanes sharing one i-body (power of two, <= 64).
 template <typename T, int IPL, int LS>
 __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type* __restrict__ bodies,
@@ -127,9 +163,8 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
 {
     using V4 = typename vec4<T>::type;
     static_assert(LS >= 1 && LS <= 64 && (LS & (LS - 1)) == 0, "LS must be a power of two <= 64");
-    uint32_t bxi, byi;
-    xcd_remap(bxi, byi, win.xcd_remap);
-    const uint32_t by = win.split(byi);
+    const uint32_t bxi = blockIdx.x;
+    const uint32_t by = win.split(blockIdx.y);
     constexpr int GROUPS = kBlock / LS;    // i-groups per block per k
     constexpr int IPB = GROUPS * IPL;      // i-bodies per block
     __shared__ V4 tile[2][kTile];
@@ -180,26 +215,22 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
             for (int u = 0; u < CH; ++u) {
                 const V4 b = tile[cur][(c * CH + u) * LS + js];
 #pragma unroll
-                for (int k = 0; k < IPL; ++k) pair<T>(b.x, b.y, b.z, b.w, xi[k], yi[k], zi[k], eps2, ax[k], ay[k], az[k]);
+                for (int k = 0; k < IPL; ++k) pair(b.x, b.y, b.z, b.w, xi[k], yi[k], zi[k], eps2, ax[k], ay[k], az[k]);
             }
         }
         if (more) tile[cur ^ 1][tid] = nxt;
         __syncthreads();
     }
 
-    // wavefront-shuffle reduction of the LS partial sums that share a body
     if constexpr (LS > 1) {
 #pragma unroll
         for (int k = 0; k < IPL; ++k) {
-#pragma unroll
-            for (int m = LS / 2; m >= 1; m >>= 1) {
-                ax[k] += __shfl_xor(ax[k], m, 64);
-                ay[k] += __shfl_xor(ay[k], m, 64);
-                az[k] += __shfl_xor(az[k], m, 64);
-            }
+            ax[k] = group_sum<LS>(ax[k]);
+            ay[k] = group_sum<LS>(ay[k]);
+            az[k] = group_sum<LS>(az[k]);
         }
     }
-    if (js == 0) {
+    if (js == LS - 1) {
 #pragma unroll
         for (int k = 0; k < IPL; ++k) {
             const uint32_t il = bxi * IPB + k * GROUPS + grp;
@@ -208,36 +239,148 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
     }
 }
 
-// K1, packed form (f32 only).  Same algorithm as nb_force<float,...>, but the
-// arithmetic is vectorised ACROSS TWO i-BODIES of the lane with the CDNA packed
-// f32 instructions (v_pk_add_f32 / v_pk_fma_f32 / v_pk_mul_f32: two f32 lanes
-// per VGPR pair).  Measured on MI355X (profiles/r01/ubench_run1.txt): a wave
-// issues one VALU op per 4 cycles whether it is packed or not, so the packed
-// body (12 v_pk + 2 v_rsq per TWO pairs instead of 24 + 2) sustains ~25 % more
-// pairs/s than the scalar body at the same occupancy.  The j-body needs no
-// shuffles: the ds_read_b128 result quad (x,y | z,m) feeds the packed ops
-// through op_sel (lo/hi broadcast), which the backend folds from the splats.
-//   NG = packed groups per lane -> IPL = 2*NG i-bodies per lane.
+// ---- packed f32 force loop -----------------------------------------------------------------
+// Same algorithm as nb_force<float,...>, but the arithmetic is vectorised ACROSS TWO i-BODIES
+// of the lane with the CDNA packed f32 instructions (v_pk_add_f32 / v_pk_fma_f32 /
+// v_pk_mul_f32: two f32 lanes per VGPR pair).  Measured on MI355X (profiles/r01/ubench_run1.txt):
+// a wave issues one VALU op per 4 cycles whether it is packed or not, so the packed body
+// (12 v_pk + 2 v_rsq per TWO pairs instead of 24 + 2) sustains ~25 % more pairs/s than the
+// scalar body at the same occupancy.  The j-body needs no shuffles: the ds_read_b128 result
+// quad (x,y | z,m) feeds the packed ops through op_sel (lo/hi broadcast).
+//   NG = packed groups per lane -> IPL = 2*NG i-bodies per lane;  LS lanes share the IPL bodies;
+//   TL = 256-body tile units staged at once (TL = 4: one exposed load latency per 1024 bodies,
+//   what the short loops of small systems need).
 typedef float nb_f2 __attribute__((ext_vector_type(2)));
 
-// Occupancy target handed to the register allocator/scheduler: NG = 4 needs
-// ~118 VGPRs (4 waves/SIMD); telling the backend so keeps it from re-serialising
-// the stage-major order to chase an occupancy it cannot reach anyway.
-template <int NG, int LS>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NG >= 4 ? 4 : (NG == 2 ? 6 : 8), NG >= 4 ? 4 : (NG == 2 ? 6 : 8))))
-void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial,
-                                                     uint32_t n, uint32_t i_begin, uint32_t i_count, float G,
-                                                     float eps2, uint32_t j_per_split, SplitWindow win)
-{
+template <int NG, int LS, int TL>
+struct PkCore {
+    static constexpr int TILE = kTile * TL;
+    static constexpr int ITER = TILE / LS;              // loop iterations per full tile
+    static constexpr int U = ITER < 8 ? ITER : 8;       // iterations per unrolled chunk
+    static constexpr int JB0 = NG >= 4 ? 1 : 4 / NG;    // j-bodies per stage-major group
+    static constexpr int JB = JB0 < U ? JB0 : U;
+    static constexpr int NC = JB * NG;                  // independent dependency chains
+    static constexpr int UNR = U / JB;
+    // NG < 4: unrolling all UNR stages lets the scheduler interleave them until it spills
+    // (228 B/lane of scratch at NG = 2); two stages in flight are enough to cover the LDS reads
+    static constexpr int UNROLL = NG >= 4 ? UNR : (UNR < 2 ? UNR : 2);
     static_assert(LS >= 1 && LS <= 64 && (LS & (LS - 1)) == 0, "LS must be a power of two <= 64");
-    uint32_t bxi, byi;
-    xcd_remap(bxi, byi, win.xcd_remap);
-    const uint32_t by = win.split(byi);
-    constexpr int IPL = 2 * NG;
-    constexpr int GROUPS = kBlock / LS;
-    constexpr int IPB = GROUPS * IPL;
-    __shared__ float4 tile[2][kTile];
+    static_assert(TL == 1 || TL == 4, "TL is 1 or 4");
 
+    // Accumulates sum_{j in [j0, j1)} (G m_j) r_ij / (|r_ij|^2 + eps2)^{3/2} for the lane's 2*NG bodies
+    // over the lane's share of j (every LS-th body of each tile).
+    static __device__ __forceinline__ void run(const float4* __restrict__ bodies, const uint32_t j0, const uint32_t j1,
+                                               const float G, const float eps2, const nb_f2 (&xi)[NG],
+                                               const nb_f2 (&yi)[NG], const nb_f2 (&zi)[NG], nb_f2 (&ax)[NG],
+                                               nb_f2 (&ay)[NG], nb_f2 (&az)[NG])
+    {
+        __shared__ float4 tile[2][TILE];
+        const int tid = threadIdx.x;
+        const int js = tid % LS;
+        const nb_f2 e2 = nb_f2{eps2, eps2};
+        const uint32_t ntiles = (j1 > j0) ? (j1 - j0 + TILE - 1) / TILE : 0;
+
+        float4 nxt[TL];
+        auto load = [&](uint32_t t) {
+#pragma unroll
+            for (int q = 0; q < TL; ++q) {
+                const uint32_t j = j0 + t * TILE + q * kBlock + tid;
+                nxt[q] = float4{0, 0, 0, 0};              // past the range: zero mass, contributes exactly 0
+                if (j < j1) { nxt[q] = bodies[j]; nxt[q].w *= G; }
+            }
+        };
+        auto store = [&](int buf) {
+#pragma unroll
+            for (int q = 0; q < TL; ++q) tile[buf][q * kBlock + tid] = nxt[q];
+        };
+
+        if (ntiles) { load(0); store(0); }
+        __syncthreads();
+
+        for (uint32_t t = 0; t < ntiles; ++t) {
+            const int cur = t & 1;
+            const bool more = (t + 1 < ntiles);
+            if (more) load(t + 1);
+            // JB j-bodies x NG groups = 4 independent dependency chains, issued stage-major:
+            // consecutive packed ops never depend on each other, so the backend needs no s_nop
+            // between a v_pk_* / v_rsq result and its consumer (gfx950 VALU hazard) and one wave
+            // alone keeps the issue port busy.  Exact trip count on a partial last tile, in
+            // chunks of U iterations (entries past the range are zero-mass).
+            const uint32_t left = j1 - (j0 + t * TILE);
+            const int cnt = left < (uint32_t)TILE ? (int)left : TILE;
+            const int chunks = ((cnt + LS - 1) / LS + U - 1) / U;
+            for (int ch = 0; ch < chunks; ++ch) {
+#pragma unroll UNROLL
+                for (int uu = 0; uu < UNR; ++uu) {
+                    const int jj = ch * U + uu * JB;
+                    nb_f2 bx[JB], by[JB], bz[JB], bm[JB];
+#pragma unroll
+                    for (int u = 0; u < JB; ++u) {
+                        const float4 b = tile[cur][(jj + u) * LS + js];
+                        bx[u] = nb_f2{b.x, b.x}; by[u] = nb_f2{b.y, b.y}; bz[u] = nb_f2{b.z, b.z}; bm[u] = nb_f2{b.w, b.w};
+                    }
+                    nb_f2 dx[NC], dy[NC], dz[NC], d2[NC], r[NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) dx[c] = bx[c / NG] - xi[c % NG];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) dy[c] = by[c / NG] - yi[c % NG];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) dz[c] = bz[c / NG] - zi[c % NG];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) r[c] = d2[c] * d2[c];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) r[c] = bm[c / NG] * r[c];
+                    // accumulate in ascending j for every group (same order as the plain loop)
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) ax[c % NG] = __builtin_elementwise_fma(r[c], dx[c], ax[c % NG]);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) ay[c % NG] = __builtin_elementwise_fma(r[c], dy[c], ay[c % NG]);
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) az[c % NG] = __builtin_elementwise_fma(r[c], dz[c], az[c % NG]);
+                }
+            }
+            if (more) store(cur ^ 1);
+            __syncthreads();
+        }
+
+        if constexpr (LS > 1) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                ax[g].x = group_sum<LS>(ax[g].x); ax[g].y = group_sum<LS>(ax[g].y);
+                ay[g].x = group_sum<LS>(ay[g].x); ay[g].y = group_sum<LS>(ay[g].y);
+                az[g].x = group_sum<LS>(az[g].x); az[g].y = group_sum<LS>(az[g].y);
+            }
+        }
+    }
+};
+
+// Occupancy target handed to the register allocator/scheduler: NG = 4 needs ~118 VGPRs
+// (4 waves/SIMD); telling the backend so keeps it from re-serialising the stage-major order to
+// chase an occupancy it cannot reach anyway.  The NG = 1, 2 bodies get the same 128-VGPR budget:
+// at 8 (6) waves per SIMD the allocator spilled 10..64 VGPRs of the loop to scratch.
+// (TL = 4 stages 32 KiB of LDS per workgroup: at most 5 workgroups per CU, so the target is 4.)
+#define NB_PK_WAVES(NG, TL) 4
+
+// K1, packed, j-tile in LDS.
+template <int NG, int LS, int TL>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NB_PK_WAVES(NG, TL), NB_PK_WAVES(NG, TL))))
+void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial, uint32_t n, uint32_t i_begin,
+                 uint32_t i_count, float G, float eps2, uint32_t j_per_split, SplitWindow win)
+{
+    const uint32_t bxi = blockIdx.x;
+    const uint32_t by = win.split(blockIdx.y);
+    constexpr int GROUPS = kBlock / LS;
+    constexpr int IPB = GROUPS * 2 * NG;
     const int tid = threadIdx.x;
     const int grp = tid / LS;
     const int js = tid % LS;
@@ -253,102 +396,80 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
         xi[g] = nb_f2{b0.x, b1.x}; yi[g] = nb_f2{b0.y, b1.y}; zi[g] = nb_f2{b0.z, b1.z};
         ax[g] = nb_f2{0, 0}; ay[g] = nb_f2{0, 0}; az[g] = nb_f2{0, 0};
     }
-    const nb_f2 e2 = nb_f2{eps2, eps2};
-
     const uint32_t j0 = by * j_per_split;
     uint32_t j1 = j0 + j_per_split;
     if (j1 > n) j1 = n;
-    const uint32_t ntiles = (j1 > j0) ? (j1 - j0 + kTile - 1) / kTile : 0;
+    PkCore<NG, LS, TL>::run(bodies, j0, j1, G, eps2, xi, yi, zi, ax, ay, az);
 
-    auto stage = [&](uint32_t t) -> float4 {
-        const uint32_t j = j0 + t * kTile + tid;
-        float4 b = float4{0, 0, 0, 0};
-        if (j < j1) { b = bodies[j]; b.w *= G; }
-        return b;
-    };
-
-    if (ntiles) tile[0][tid] = stage(0);
-    __syncthreads();
-
-    for (uint32_t t = 0; t < ntiles; ++t) {
-        const int cur = t & 1;
-        float4 nxt;
-        const bool more = (t + 1 < ntiles);
-        if (more) nxt = stage(t + 1);
-        // JB j-bodies x NG groups = 4 independent dependency chains, issued
-        // stage-major: consecutive packed ops never depend on each other, so the
-        // backend needs no s_nop between a v_pk_* / v_rsq result and its consumer
-        // (gfx950 VALU hazard) and one wave alone keeps the issue port busy.
-        constexpr int JB = NG >= 4 ? 1 : 4 / NG;
-        constexpr int NC = JB * NG;
-        constexpr int UNR = 8 / JB;
-        // exact trip count on a partial last tile (see nb_force), in chunks of 8 j-bodies
-        const uint32_t left = j1 - (j0 + t * kTile);
-        const int cnt = left < (uint32_t)kTile ? (int)left : kTile;
-        const int chunks = ((cnt + LS - 1) / LS + 7) / 8;
-        for (int ch = 0; ch < chunks; ++ch) {
-#pragma unroll
-        for (int uu = 0; uu < UNR; ++uu) {
-            const int jj = ch * 8 + uu * JB;
-            nb_f2 bx[JB], by[JB], bz[JB], bm[JB];
-#pragma unroll
-            for (int u = 0; u < JB; ++u) {
-                const float4 b = tile[cur][(jj + u) * LS + js];
-                bx[u] = nb_f2{b.x, b.x}; by[u] = nb_f2{b.y, b.y}; bz[u] = nb_f2{b.z, b.z}; bm[u] = nb_f2{b.w, b.w};
-            }
-            nb_f2 dx[NC], dy[NC], dz[NC], d2[NC], r[NC];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) dx[c] = bx[c / NG] - xi[c % NG];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) dy[c] = by[c / NG] - yi[c % NG];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) dz[c] = bz[c / NG] - zi[c % NG];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) r[c] = d2[c] * d2[c];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) r[c] = r[c] * d2[c];
-#pragma unroll
-            for (int c = 0; c < NC; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
-#pragma unroll
-            for (int c = 0; c < NC; ++c) r[c] = bm[c / NG] * r[c];
-            // accumulate in ascending j for every group (same order as the plain loop)
-#pragma unroll
-            for (int c = 0; c < NC; ++c) ax[c % NG] = __builtin_elementwise_fma(r[c], dx[c], ax[c % NG]);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) ay[c % NG] = __builtin_elementwise_fma(r[c], dy[c], ay[c % NG]);
-#pragma unroll
-            for (int c = 0; c < NC; ++c) az[c % NG] = __builtin_elementwise_fma(r[c], dz[c], az[c % NG]);
-        }
-        }
-        if (more) tile[cur ^ 1][tid] = nxt;
-        __syncthreads();
-    }
-
-    if constexpr (LS > 1) {
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-#pragma unroll
-            for (int m = LS / 2; m >= 1; m >>= 1) {
-                ax[g].x += __shfl_xor(ax[g].x, m, 64); ax[g].y += __shfl_xor(ax[g].y, m, 64);
-                ay[g].x += __shfl_xor(ay[g].x, m, 64); ay[g].y += __shfl_xor(ay[g].y, m, 64);
-                az[g].x += __shfl_xor(az[g].x, m, 64); az[g].y += __shfl_xor(az[g].y, m, 64);
-            }
-        }
-    }
-    if (js == 0) {
+    if (js == LS - 1) {
+        float4* out = partial + (size_t)by * i_count;
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
             const uint32_t il0 = bxi * IPB + (2 * g) * GROUPS + grp;
             const uint32_t il1 = il0 + GROUPS;
-            float4* out = partial + (size_t)by * i_count;
             if (il0 < i_count) out[il0] = float4{ax[g].x, ay[g].x, az[g].x, 0};
             if (il1 < i_count) out[il1] = float4{ax[g].y, ay[g].y, az[g].y, 0};
+        }
+    }
+}
+
+// The whole step in ONE launch ("ping-pong position buffers to fuse K2 into
+// K1's epilogue without the race"): every workgroup accumulates its bodies against ALL n bodies
+// of bodies_in (the packed LDS-tile loop above), reduces the LS lane sums in the wave and the
+// group's last lane applies nbody3d.js:274-290, writing the new positions to bodies_out --
+// a different buffer, so no workgroup can stage a half-updated system (the reference's race,
+// nbody3d.js:283 vs :257).  vel/acc are only touched by their own lane: in place.
+// Bit-identical to nb_force_pk<NG,LS,TL> with jsplit = 1 followed by nb_integrate.
+template <int NG, int LS, int TL>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NB_PK_WAVES(NG, TL), NB_PK_WAVES(NG, TL))))
+void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bodies_out, float4* __restrict__ vel,
+                   float4* __restrict__ acc, uint32_t n, float G, float eps2, float dt)
+{
+    constexpr int GROUPS = kBlock / LS;
+    constexpr int IPB = GROUPS * 2 * NG;
+    constexpr int IPL = 2 * NG;
+    constexpr bool PREFETCH = NG == 1;     // vel/acc of the storing lane loaded before the loop (short loops)
+    const uint32_t bxi = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int grp = tid / LS;
+    const int js = tid % LS;
+    const bool owner = js == LS - 1;
+
+    nb_f2 xi[NG], yi[NG], zi[NG], ax[NG], ay[NG], az[NG];
+    float4 v0[PREFETCH ? IPL : 1], a0[PREFETCH ? IPL : 1];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        float4 b0 = float4{0, 0, 0, 0}, b1 = float4{0, 0, 0, 0};
+        const uint32_t il0 = bxi * IPB + (2 * g) * GROUPS + grp;
+        const uint32_t il1 = il0 + GROUPS;
+        if (il0 < n) b0 = bodies_in[il0];
+        if (il1 < n) b1 = bodies_in[il1];
+        xi[g] = nb_f2{b0.x, b1.x}; yi[g] = nb_f2{b0.y, b1.y}; zi[g] = nb_f2{b0.z, b1.z};
+        ax[g] = nb_f2{0, 0}; ay[g] = nb_f2{0, 0}; az[g] = nb_f2{0, 0};
+        if constexpr (PREFETCH) {
+            v0[2 * g] = v0[2 * g + 1] = a0[2 * g] = a0[2 * g + 1] = float4{0, 0, 0, 0};
+            if (owner && il0 < n) { v0[2 * g] = vel[il0]; a0[2 * g] = acc[il0]; }
+            if (owner && il1 < n) { v0[2 * g + 1] = vel[il1]; a0[2 * g + 1] = acc[il1]; }
+        }
+    }
+    PkCore<NG, LS, TL>::run(bodies_in, 0, n, G, eps2, xi, yi, zi, ax, ay, az);
+
+    if (owner) {
+#pragma unroll
+        for (int k = 0; k < IPL; ++k) {
+            const int g = k / 2;
+            const uint32_t il = bxi * IPB + k * GROUPS + grp;
+            if (il < n) {
+                float4 v, ao;
+                if constexpr (PREFETCH) { v = v0[k]; ao = a0[k]; } else { v = vel[il]; ao = acc[il]; }
+                const float4 x = bodies_in[il];      // all four components: .w is integrated like xyz (:283)
+                float4 nx, nv, na;
+                if (k & 1) leapfrog<float>(x, v, ao, ax[g].y, ay[g].y, az[g].y, dt, nx, nv, na);
+                else leapfrog<float>(x, v, ao, ax[g].x, ay[g].x, az[g].x, dt, nx, nv, na);
+                vel[il] = nv;                                              // :281
+                bodies_out[il] = nx;                                       // :283 (other buffer)
+                acc[il] = na;                                              // :290
+            }
         }
     }
 }
@@ -356,37 +477,54 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
 // K1, packed form with the j-bodies broadcast from SGPRs instead of LDS (SURVEY.md §8 f3
 // "scalar-load (SGPR) j-broadcast A/B against the LDS tile").  j is wave-uniform, so
 // bodies[j] is fetched with s_load_dwordx4 through the scalar cache and the packed ops
-// take the (x,y | z,m) SGPR pairs directly (op_sel broadcast): no LDS, no barrier, no
-// v_mov for the mass, workgroups need no tile synchronisation.  G is applied
-// once to the finished sums (G * sum(m r^-3 d) instead of sum((G m) r^-3 d): rounding only).
-// Opt-in (variant 34/38); the LDS kernel stays the default -- measurement in DESIGN.md.
-template <int NG>
+// take the (x,y | z,m) SGPR pairs directly (op_sel broadcast): no LDS tile, no barrier in the
+// loop, no v_mov for the mass.  G is applied once to the finished sums (G * sum(m r^-3 d)
+// instead of sum((G m) r^-3 d): rounding only).
+//   WS = 1: the 4 waves of a workgroup hold different i-bodies (256 lanes x 2*NG) and stream the
+//           same j-range;
+//   WS = 4: the 4 waves hold the SAME 64 x 2*NG i-bodies and each streams a quarter of the
+//           workgroup's j-range; their sums are added through LDS in wave order (deterministic)
+//           and ONE partial is stored: a quarter of the j-splits, partial arrays and K2 traffic
+//           for the same grid size and the same work per wave.
+template <int NG, int WS>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NG >= 4 ? 4 : 6, NG >= 4 ? 4 : 6)))
 void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ partial, uint32_t n, uint32_t i_begin,
                       uint32_t i_count, float G, float eps2, uint32_t j_per_split, SplitWindow win)
 {
+    static_assert(WS == 1 || WS == 4, "WS is 1 or 4");
     constexpr int IPL = 2 * NG;
-    constexpr int IPB = kBlock * IPL;
-    uint32_t bxi, byi;
-    xcd_remap(bxi, byi, win.xcd_remap);
-    const uint32_t by = win.split(byi);
+    constexpr int LANES = kBlock / WS;          // i-lanes per workgroup
+    constexpr int IPB = LANES * IPL;
+    const uint32_t bxi = blockIdx.x;
+    const uint32_t by = win.split(blockIdx.y);
     const int tid = threadIdx.x;
+    const int lane = tid % LANES;
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(tid / LANES);   // wave-uniform: which j-quarter (WS = 4)
 
     nb_f2 xi[NG], yi[NG], zi[NG], ax[NG], ay[NG], az[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
         float4 b0 = float4{0, 0, 0, 0}, b1 = float4{0, 0, 0, 0};
-        const uint32_t il0 = bxi * IPB + (2 * g) * kBlock + tid;
-        const uint32_t il1 = il0 + kBlock;
+        const uint32_t il0 = bxi * IPB + (2 * g) * LANES + lane;
+        const uint32_t il1 = il0 + LANES;
         if (il0 < i_count) b0 = bodies[i_begin + il0];
         if (il1 < i_count) b1 = bodies[i_begin + il1];
         xi[g] = nb_f2{b0.x, b1.x}; yi[g] = nb_f2{b0.y, b1.y}; zi[g] = nb_f2{b0.z, b1.z};
         ax[g] = nb_f2{0, 0}; ay[g] = nb_f2{0, 0}; az[g] = nb_f2{0, 0};
     }
     const nb_f2 e2 = nb_f2{eps2, eps2};
-    const uint32_t j0 = by * j_per_split;
+    uint32_t j0 = by * j_per_split;
     uint32_t j1 = j0 + j_per_split;
     if (j1 > n) j1 = n;
+    if constexpr (WS == 4) {
+        // quarter of the split, a multiple of 8 bodies (the split itself is one); the last wave takes the rest
+        const uint32_t len = j1 > j0 ? j1 - j0 : 0;
+        const uint32_t q = ((len / 4 + 7) / 8) * 8;
+        uint32_t a = j0 + wv * q, b = a + q;
+        if (wv == 3 || b > j1) b = j1;
+        if (a > j1) a = j1;
+        j0 = a; j1 = b;
+    }
 
     auto eval4 = [&](const float4 q0, const float4 q1, const float4 q2, const float4 q3) {
         const float4 q[4] = {q0, q1, q2, q3};
@@ -431,6 +569,8 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
     // = 1024 issue cycles at NG = 4) earlier.  The accumulators are threaded through every
     // asm statement ("+v") so the packed math cannot drift across a wait or a request;
     // nothing else in the loop uses lgkmcnt (no LDS), so hipcc inserts no waits of its own.
+    // The destination quads are early-clobber ("=&s"): none of them may be allocated on the
+    // base-address pair, which the later loads of the same statement still read.
     typedef float nb_f4 __attribute__((ext_vector_type(4)));   // native vector: usable as an "s" asm operand
     struct Quad { nb_f4 q0, q1, q2, q3; };   // 4 bodies = 16 SGPRs
     auto f4 = [](const nb_f4& v) { return float4{v.x, v.y, v.z, v.w}; };
@@ -444,8 +584,8 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.q0), "+s"(q.q1), "+s"(q.q2), "+s"(q.q3), NB_ACC2 : : "memory");
     };
     auto request = [&](Quad& q, const float4* p) {   // bodies p[0..3]
-        if constexpr (NG == 4) asm volatile(NB_LOAD4(16) : "=s"(q.q0), "=s"(q.q1), "=s"(q.q2), "=s"(q.q3), NB_ACC4 : "s"(p) : "memory");
-        else asm volatile(NB_LOAD4(10) : "=s"(q.q0), "=s"(q.q1), "=s"(q.q2), "=s"(q.q3), NB_ACC2 : "s"(p) : "memory");
+        if constexpr (NG == 4) asm volatile(NB_LOAD4(16) : "=&s"(q.q0), "=&s"(q.q1), "=&s"(q.q2), "=&s"(q.q3), NB_ACC4 : "s"(p) : "memory");
+        else asm volatile(NB_LOAD4(10) : "=&s"(q.q0), "=&s"(q.q1), "=&s"(q.q2), "=&s"(q.q3), NB_ACC2 : "s"(p) : "memory");
     };
 #undef NB_LOAD4
 #undef NB_ACC2
@@ -470,21 +610,43 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
     for (; j < j1; ++j)      // < 8 bodies left (only when n is not a multiple of 8): one at a time
         eval4(bodies[j], float4{0, 0, 0, 0}, float4{0, 0, 0, 0}, float4{0, 0, 0, 0});
 
+    if constexpr (WS == 4) {
+        // waves 1..3 hand their sums to wave 0 through LDS; added in wave order
+        __shared__ float red[3][3 * IPL][64];
+        if (wv > 0) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                red[wv - 1][6 * g + 0][lane] = ax[g].x; red[wv - 1][6 * g + 1][lane] = ax[g].y;
+                red[wv - 1][6 * g + 2][lane] = ay[g].x; red[wv - 1][6 * g + 3][lane] = ay[g].y;
+                red[wv - 1][6 * g + 4][lane] = az[g].x; red[wv - 1][6 * g + 5][lane] = az[g].y;
+            }
+        }
+        __syncthreads();
+        if (wv > 0) return;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                ax[g].x += red[w][6 * g + 0][lane]; ax[g].y += red[w][6 * g + 1][lane];
+                ay[g].x += red[w][6 * g + 2][lane]; ay[g].y += red[w][6 * g + 3][lane];
+                az[g].x += red[w][6 * g + 4][lane]; az[g].y += red[w][6 * g + 5][lane];
+            }
+        }
+    }
+
     float4* out = partial + (size_t)by * i_count;
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const uint32_t il0 = bxi * IPB + (2 * g) * kBlock + tid;
-        const uint32_t il1 = il0 + kBlock;
+        const uint32_t il0 = bxi * IPB + (2 * g) * LANES + lane;
+        const uint32_t il1 = il0 + LANES;
         if (il0 < i_count) out[il0] = float4{G * ax[g].x, G * ay[g].x, G * az[g].x, 0};
         if (il1 < i_count) out[il1] = float4{G * ax[g].y, G * ay[g].y, G * az[g].y, 0};
     }
 }
 
-// K2.  nbody3d.js:274-290 on all four components (the .w lane is integrated
-// too, exactly as the reference does; mass stays constant because vel.w = 0).
-// R lanes cooperate on one body: lane r sums partials r, r+R, r+2R, ... (ascending,
-// independent 16-B loads in flight), the R sums are combined by wavefront shuffles
-// in a fixed order (deterministic), and lane 0 of the group applies the update.
+// K2.  nbody3d.js:274-290.  R lanes cooperate on one body: lane r sums partials r, r+R,
+// r+2R, ... (ascending, independent 16-B loads in flight), the R sums are combined by wavefront
+// shuffles in a fixed order (deterministic), and lane 0 of the group applies the update.
 // With jsplit = 64 partials a single lane per body is latency-bound (20 us at
 // 16,384 rows); R = 8 brings it to the launch floor.
 template <typename T, int R>
@@ -527,25 +689,53 @@ __global__ __launch_bounds__(kBlock) void nb_integrate(typename vec4<T>::type* _
         }
     }
     if (!valid || r != 0) return;
-    V4 a;
-    a.x = sx; a.y = sy; a.z = sz;
-    a.w = 0;                                                            // :274
-    const T h = dt * T(0.5);                                            // :276
-    const V4 ao = acc[il];
-    const V4 v = vel[il];
-    const V4 x = bodies[i_begin + il];
-    V4 nv, nx;
-    nv.x = nb_fma(ao.x + a.x, h, v.x);                                  // :280
-    nv.y = nb_fma(ao.y + a.y, h, v.y);
-    nv.z = nb_fma(ao.z + a.z, h, v.z);
-    nv.w = nb_fma(ao.w + a.w, h, v.w);
-    nx.x = nb_fma(nb_fma(h, a.x, nv.x), dt, x.x);                       // :283
-    nx.y = nb_fma(nb_fma(h, a.y, nv.y), dt, x.y);
-    nx.z = nb_fma(nb_fma(h, a.z, nv.z), dt, x.z);
-    nx.w = nb_fma(nb_fma(h, a.w, nv.w), dt, x.w);
+    V4 nx, nv, na;
+    leapfrog<T>(bodies[i_begin + il], vel[il], acc[il], sx, sy, sz, dt, nx, nv, na);
     vel[il] = nv;                                                       // :281
     bodies[i_begin + il] = nx;                                          // :283
-    acc[il] = a;                                                        // :290
+    acc[il] = na;                                                       // :290
+}
+
+// K2 for jsplit == 1 with the a_old / a_new buffers swapped by pointer (SURVEY.md §8(d) "K2
+// roofline": read x, v, a_old, a_new = 64 B, write x, v = 32 B -> 96 B per body, nothing else):
+// `anew` is K1's single partial array and becomes the next step's `aold` on the host side.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_integrate_swap(typename vec4<T>::type* __restrict__ bodies,
+                                                           typename vec4<T>::type* __restrict__ vel,
+                                                           const typename vec4<T>::type* __restrict__ aold,
+                                                           const typename vec4<T>::type* __restrict__ anew,
+                                                           uint32_t i_begin, uint32_t i_count, T dt)
+{
+    using V4 = typename vec4<T>::type;
+    const uint32_t il = blockIdx.x * kBlock + threadIdx.x;
+    if (il >= i_count) return;
+    const V4 a = anew[il];
+    V4 nx, nv, na;
+    leapfrog<T>(bodies[i_begin + il], vel[il], aold[il], a.x, a.y, a.z, dt, nx, nv, na);
+    vel[il] = nv;
+    bodies[i_begin + il] = nx;
+}
+
+// Viewer frame: what the reference's render pass reads every frame -- bodies
+// (x, y, z, mass -> billboard position and radius, nbody3d.js:331,345) and the speed
+// length(vel.xyz) that feeds its colour map (:380) -- packed as f32 into a staging buffer the
+// step stream never writes again, so the copy to the host can run beside the next steps.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_frame_pack(const typename vec4<T>::type* __restrict__ bodies,
+                                                       const typename vec4<T>::type* __restrict__ vel, uint32_t n,
+                                                       uint32_t i_begin, uint32_t i_count, float4* __restrict__ out_b,
+                                                       float* __restrict__ out_speed)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < n) {
+        const auto b = bodies[i];
+        out_b[i] = float4{(float)b.x, (float)b.y, (float)b.z, (float)b.w};
+    }
+    if (i < i_count) {
+        const auto v = vel[i];
+        const float vx = (float)v.x, vy = (float)v.y, vz = (float)v.z;
+        out_speed[i_begin + i] = __builtin_sqrtf(vx * vx + vy * vy + vz * vz);
+    }
 }
 
 // Diagnostics (no reference analogue): per-block fp64 partial

@@ -49,6 +49,11 @@ static int (*p_multi_sync)(nb_multi *);
 static const char *(*p_multi_last_error)(nb_multi *);
 static const char *(*p_multi_variant_name)(nb_multi *);
 static int (*p_multi_diagnostics)(nb_multi *, double *);
+static int (*p_multi_set_collective)(nb_multi *, int);
+static int (*p_multi_collective_info)(nb_multi *, int *, int *, int *);
+static int (*p_step_times)(nb_sim *, double *, double *, double *, uint32_t *);
+static int (*p_frame_request)(nb_sim *);
+static int (*p_frame_acquire)(nb_sim *, int, const float **, const float **, uint64_t *);
 
 /* one JS handle = a single-device nb_sim or a single-process multi-device nb_multi */
 typedef struct { nb_sim *sim; nb_multi *multi; uint32_t n; int f64; } handle_t;
@@ -121,6 +126,8 @@ static napi_value js_load(napi_env env, napi_callback_info info)
         SYM(p_multi_step, "nb_multi_step"); SYM(p_multi_download, "nb_multi_download");
         SYM(p_multi_sync, "nb_multi_sync"); SYM(p_multi_last_error, "nb_multi_last_error");
         SYM(p_multi_variant_name, "nb_multi_variant_name"); SYM(p_multi_diagnostics, "nb_multi_diagnostics");
+        SYM(p_multi_set_collective, "nb_multi_set_collective"); SYM(p_multi_collective_info, "nb_multi_collective_info");
+        SYM(p_step_times, "nb_step_times"); SYM(p_frame_request, "nb_frame_request"); SYM(p_frame_acquire, "nb_frame_acquire");
 #undef SYM
         g_lib = h;
     }
@@ -167,7 +174,7 @@ static int get_f64_prop(napi_env env, napi_value obj, const char *name, double *
     napi_get_value_double(env, v, out); return 1;
 }
 
-/* create({n, f64, eps2, device, shardBegin, shardCount, variant, jsplit}) -> external */
+/* create({n, f64, eps2, device, shardBegin, shardCount, variant, jsplit, flags, shards, collective}) -> external */
 static napi_value js_create(napi_env env, napi_callback_info info)
 {
     if (!need_lib(env)) return NULL;
@@ -186,14 +193,24 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     if (get_u32_prop(env, argv[0], "variant", &u)) cfg.force_variant = u;
     if (get_u32_prop(env, argv[0], "jsplit", &u)) cfg.jsplit = u;
     if (get_u32_prop(env, argv[0], "tile", &u)) cfg.tile = u;
-    uint32_t shards = 0;
+    if (get_u32_prop(env, argv[0], "flags", &u)) cfg.flags = u;
+    uint32_t shards = 0, collective = 0;
     get_u32_prop(env, argv[0], "shards", &shards);
+    get_u32_prop(env, argv[0], "collective", &collective);   /* 0 peer copies, 1 RCCL (nb_multi_collective) */
     nb_sim *sim = NULL;
     nb_multi *multi = NULL;
     if (shards > 1) {   /* single-process multi-device: shards round-robin over the visible GPUs */
         cfg.device = -1; cfg.shard_begin = cfg.shard_count = 0;
         int rc = p_multi_create(&cfg, shards, NULL, &multi);
         if (rc != NB_OK) return throw_msg(env, rc, p_multi_last_error(NULL), "nb_multi_create");
+        if (collective) {
+            rc = p_multi_set_collective(multi, (int)collective);
+            if (rc != NB_OK) {
+                char msg[512]; snprintf(msg, sizeof msg, "%s", p_multi_last_error(multi));
+                p_multi_destroy(multi);
+                return throw_msg(env, rc, msg, "nb_multi_set_collective");
+            }
+        }
     } else {
         int rc = p_create(&cfg, &sim);
         if (rc != NB_OK) return throw_nb(env, rc, NULL, "nb_create");
@@ -411,13 +428,97 @@ static napi_value js_diagnostics(napi_env env, napi_callback_info info)
     return o;
 }
 
+
+/* stepTimes(handle) -> {forceMs, integrateMs, exchangeMs, launches} */
+static napi_value js_step_times(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    if (h->multi) { napi_throw_error(env, "NB_1", "per-kernel timing is not available on a multi-device handle"); return NULL; }
+    double f, g, x; uint32_t c;
+    int rc = p_step_times(h->sim, &f, &g, &x, &c);
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_step_times");
+    napi_value o, v;
+    CHECK_NAPI(env, napi_create_object(env, &o));
+    napi_create_double(env, f, &v); napi_set_named_property(env, o, "forceMs", v);
+    napi_create_double(env, g, &v); napi_set_named_property(env, o, "integrateMs", v);
+    napi_create_double(env, x, &v); napi_set_named_property(env, o, "exchangeMs", v);
+    napi_create_uint32(env, c, &v); napi_set_named_property(env, o, "launches", v);
+    return o;
+}
+
+/* collectiveInfo(handle) -> {mode: 'peer'|'rccl'|'none', nranks, rcclVersion} */
+static napi_value js_collective_info(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    int mode = -1, nranks = 0, ver = 0;
+    if (h->multi) {
+        int rc = p_multi_collective_info(h->multi, &mode, &nranks, &ver);
+        if (rc != NB_OK) return throw_msg(env, rc, p_multi_last_error(h->multi), "nb_multi_collective_info");
+    }
+    napi_value o, v;
+    CHECK_NAPI(env, napi_create_object(env, &o));
+    napi_create_string_utf8(env, mode == NB_MULTI_RCCL ? "rccl" : (mode == NB_MULTI_PEER ? "peer" : "none"), NAPI_AUTO_LENGTH, &v);
+    napi_set_named_property(env, o, "mode", v);
+    napi_create_int32(env, nranks, &v); napi_set_named_property(env, o, "nranks", v);
+    napi_create_int32(env, ver, &v); napi_set_named_property(env, o, "rcclVersion", v);
+    return o;
+}
+
+/* requestFrame(handle): enqueue a viewer snapshot behind the steps issued so far (returns at once) */
+static napi_value js_request_frame(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1; napi_value argv[1];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
+    if (h->multi) { napi_throw_error(env, "NB_1", "the frame feed is not available on a multi-device handle"); return NULL; }
+    int rc = p_frame_request(h->sim);
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_frame_request");
+    return undefined(env);
+}
+
+/* frame(handle, wait, bodiesOut Float32Array(4n), speedOut Float32Array(n)) -> step index, or -1 when
+ * wait is false and no frame has landed yet.  Copies out of the engine's pinned frame slot. */
+static napi_value js_frame(napi_env env, napi_callback_info info)
+{
+    size_t argc = 4; napi_value argv[4];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 4) { napi_throw_type_error(env, NULL, "frame(handle, wait, bodiesOut, speedOut)"); return NULL; }
+    handle_t *h = get_handle(env, argv[0]); if (!h) return NULL;
+    if (h->multi) { napi_throw_error(env, "NB_1", "the frame feed is not available on a multi-device handle"); return NULL; }
+    bool wait = true; napi_get_value_bool(env, argv[1], &wait);
+    void *dst[2]; const size_t want[2] = {(size_t)4 * h->n, (size_t)h->n};
+    for (int k = 0; k < 2; ++k) {
+        bool is_ta = false; napi_is_typedarray(env, argv[2 + k], &is_ta);
+        napi_typedarray_type tt; size_t len = 0; napi_value ab; size_t off;
+        if (!is_ta || napi_get_typedarray_info(env, argv[2 + k], &tt, &len, &dst[k], &ab, &off) != napi_ok ||
+            tt != napi_float32_array || len != want[k]) {
+            napi_throw_type_error(env, NULL, k ? "speedOut must be a Float32Array of n elements" : "bodiesOut must be a Float32Array of 4*n elements");
+            return NULL;
+        }
+    }
+    const float *b = NULL, *sp = NULL; uint64_t step = 0;
+    int rc = p_frame_acquire(h->sim, wait ? 1 : 0, &b, &sp, &step);
+    napi_value v;
+    if (rc == NB_NOT_READY) { napi_create_double(env, -1.0, &v); return v; }
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_frame_acquire");
+    memcpy(dst[0], b, sizeof(float) * want[0]);
+    memcpy(dst[1], sp, sizeof(float) * want[1]);
+    napi_create_double(env, (double)step, &v);
+    return v;
+}
+
 static napi_value init_module(napi_env env, napi_value exports)
 {
     static const struct { const char *name; napi_callback fn; } fns[] = {
         {"load", js_load}, {"deviceCount", js_device_count}, {"create", js_create}, {"upload", js_upload},
         {"setParams", js_set_params}, {"step", js_step}, {"download", js_download}, {"sync", js_sync},
         {"destroy", js_destroy}, {"enableTiming", js_enable_timing}, {"kernelTimes", js_kernel_times},
-        {"variant", js_variant}, {"diagnostics", js_diagnostics},
+        {"variant", js_variant}, {"diagnostics", js_diagnostics}, {"stepTimes", js_step_times},
+        {"collectiveInfo", js_collective_info}, {"requestFrame", js_request_frame}, {"frame", js_frame},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
         napi_value f;

@@ -16,6 +16,8 @@
  *   restore(state)         util.js:230-244     importSimulation's buffer writes
  *   G / dt / pause()       nbody3d.js:6-7, util.js:36-64 (dt and G are mutable
  *                          between frames; pause saves dt and sets it to 0)
+ *   requestFrame()/frame() nbody3d.js:408-415,482-487 what the render pass reads each frame
+ *                          (bodies + speed), delivered asynchronously to a host-side viewer
  *
  * Data convention is the reference's: Float32Array packed [x,y,z,m, ...] and
  * [vx,vy,vz,0, ...] (nbody3d.js:49,132).  Node >= 12 syntax only.
@@ -58,9 +60,11 @@ function asParticles(particles) {
 }
 
 class Simulation {
-  /** options: {G, dt, f64, eps2, device, shards, shardBegin, shardCount, variant, jsplit}
-   *  shards > 1: single-process multi-device (i-shards round-robin over the visible GPUs,
-   *  peer-copy all-gather of positions after every step; no reference analogue). */
+  /** options: {G, dt, f64, eps2, device, shards, collective, shardBegin, shardCount, variant, jsplit, flags}
+   *  shards > 1: single-process multi-device (i-shards round-robin over the visible GPUs; all-gather
+   *  of positions after every step through collective: 'peer' -- event-ordered device-to-device
+   *  copies, the default -- or 'rccl' -- ncclCommInitAll + grouped in-place ncclAllGather;
+   *  no reference analogue). */
   constructor(options) {
     const o = options || {};
     this.options = o;
@@ -98,7 +102,9 @@ class Simulation {
         n: n, f64: this.f64 ? 1 : 0, eps2: o.eps2 !== undefined ? o.eps2 : EPS2,
         device: o.device !== undefined ? o.device : -1, shardBegin: o.shardBegin || 0, shardCount: o.shardCount || 0,
         variant: o.variant || 0, jsplit: o.jsplit || 0, tile: o.tile || 0, shards: o.shards || 0,
+        flags: o.flags || 0, collective: o.collective === 'rccl' ? 1 : 0,
       });
+      this._frame = null;
     }
     addon.upload(this._h, this._coerce(p.bodies, 'bodies'), this._coerce(p.vel, 'vel'),
       p.accel ? this._coerce(p.accel, 'accel') : null);
@@ -183,13 +189,33 @@ class Simulation {
     return this;
   }
 
+  /** Viewer frame feed.  The reference's render pass reads bodyBuffer and velBuffer in place
+   *  every frame (nbody3d.js:408-415,482-487; colour from length(vel.xyz), :380).  requestFrame()
+   *  enqueues a snapshot behind the steps issued so far and returns at once: the copy to the host
+   *  runs on a second stream and does not stall later step() calls. */
+  requestFrame() { this._need(); addon.requestFrame(this._h); return this; }
+
+  /** Newest snapshot that has landed: {bodies: Float32Array(4n) x,y,z,m; speed: Float32Array(n)
+   *  |v|; step} -- the same two arrays refreshed on every call -- or null (wait === false and no
+   *  frame has landed yet). */
+  frame(wait) {
+    this._need();
+    if (!this._frame) this._frame = { bodies: new Float32Array(4 * this.nBodies), speed: new Float32Array(this.nBodies), step: 0 };
+    const step = addon.frame(this._h, wait !== false, this._frame.bodies, this._frame.speed);
+    if (step < 0) return null;
+    this._frame.step = step;
+    return this._frame;
+  }
+
   enableTiming(on) { this._need(); addon.enableTiming(this._h, on !== false); return this; }
+  stepTimes() { this._need(); return addon.stepTimes(this._h); }
+  collectiveInfo() { this._need(); return addon.collectiveInfo(this._h); }
   kernelTimes() { this._need(); return addon.kernelTimes(this._h); }
   variant() { this._need(); return addon.variant(this._h); }
   diagnostics() { this._need(); addon.setParams(this._h, this.dt, this.G); return addon.diagnostics(this._h); }
 
   destroy() {
-    if (this._h) { addon.destroy(this._h); this._h = null; }
+    if (this._h) { addon.destroy(this._h); this._h = null; this._frame = null; }
   }
 }
 

@@ -19,10 +19,15 @@ _LIB_PATH = os.path.normpath(os.path.join(_PKG, "..", "csrc", "libnbody3d_hip.so
 
 NB_F32, NB_F64 = 0, 1
 NB_FLAG_EXT_STREAM = 1
-NB_FLAG_XCD_REMAP = 2
 NB_FLAG_LDS_ONLY = 4
+NB_FLAG_NO_FUSE = 8
+NB_RCCL_ID_BYTES = 128
+NB_RCCL_OVERLAP = 1
+NB_MULTI_PEER, NB_MULTI_RCCL = 0, 1
+NB_NOT_READY = 7
 STATUS = {0: "NB_OK", 1: "NB_ERR_INVALID", 2: "NB_ERR_NO_DEVICE", 3: "NB_ERR_HIP",
-          4: "NB_ERR_STATE", 5: "NB_ERR_NOMEM", 6: "NB_ERR_COMM"}
+          4: "NB_ERR_STATE", 5: "NB_ERR_NOMEM", 6: "NB_ERR_COMM", 7: "NB_NOT_READY"}
+ABI_VERSION = 2
 
 
 class NBodyError(RuntimeError):
@@ -50,7 +55,9 @@ SYMBOLS = ["nb_abi_version", "nb_device_count", "nb_create", "nb_destroy", "nb_u
            "nb_kernel_times", "nb_variant_name", "nb_diagnostics",
            "nb_multi_create", "nb_multi_destroy", "nb_multi_upload", "nb_multi_set_params", "nb_multi_step",
            "nb_multi_download", "nb_multi_sync", "nb_multi_last_error", "nb_multi_variant_name",
-           "nb_multi_diagnostics"]
+           "nb_multi_diagnostics", "nb_multi_set_collective", "nb_multi_collective_info",
+           "nb_rccl_unique_id", "nb_rccl_attach", "nb_rccl_detach", "nb_rccl_info",
+           "nb_step_times", "nb_integrate_pass", "nb_frame_request", "nb_frame_acquire"]
 
 _lib = None
 
@@ -102,6 +109,18 @@ def load_library():
     L.nb_multi_variant_name.argtypes = [vp]
     L.nb_multi_variant_name.restype = C.c_char_p
     L.nb_multi_diagnostics.argtypes = [vp, C.POINTER(C.c_double)]
+    L.nb_multi_set_collective.argtypes = [vp, C.c_int]
+    L.nb_multi_collective_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.nb_rccl_unique_id.argtypes = [vp]
+    L.nb_rccl_attach.argtypes = [vp, vp, C.c_int, C.c_int, C.c_uint32]
+    L.nb_rccl_detach.argtypes = [vp]
+    L.nb_rccl_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.nb_step_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_uint32)]
+    L.nb_integrate_pass.argtypes = [vp, C.c_uint32, C.POINTER(C.c_double)]
+    L.nb_frame_request.argtypes = [vp]
+    L.nb_frame_acquire.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
+                                   C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -112,6 +131,16 @@ def abi_version():
 
 def device_count():
     return load_library().nb_device_count()
+
+
+def rccl_unique_id():
+    """ncclGetUniqueId through the engine: 128 bytes that rank 0 hands to every other rank."""
+    L = load_library()
+    buf = C.create_string_buffer(NB_RCCL_ID_BYTES)
+    rc = L.nb_rccl_unique_id(buf)
+    if rc != 0:
+        raise NBodyError(rc, L.nb_last_error(None).decode())
+    return buf.raw
 
 
 def _ptr(a):
@@ -136,7 +165,8 @@ class Simulation:
         cfg.eps2 = 0.0 if eps2 is None else float(eps2)
         cfg.device = device
         self.shard_begin, self.shard_count = (0, self.n) if shard is None else (int(shard[0]), int(shard[1]))
-        cfg.shard_begin, cfg.shard_count = self.shard_begin, self.shard_count
+        if shard is not None:      # shard_count = 0 means "whole system, not a shard" (eligible for the fused step)
+            cfg.shard_begin, cfg.shard_count = self.shard_begin, self.shard_count
         if stream is not None:
             cfg.ext_stream = stream if stream else None
             cfg.flags |= NB_FLAG_EXT_STREAM
@@ -273,6 +303,52 @@ class Simulation:
         self._check(self._L.nb_kernel_times(self._h, C.byref(f), C.byref(g), C.byref(c)))
         return f.value, g.value, c.value
 
+    def step_times(self):
+        """(force ms, integrate ms, native-RCCL exchange ms, launches) since last call."""
+        f, g, x, c = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()
+        self._check(self._L.nb_step_times(self._h, C.byref(f), C.byref(g), C.byref(x), C.byref(c)))
+        return f.value, g.value, x.value, c.value
+
+    def integrate_pass(self, reps):
+        """Average ms of the integrate kernel alone over ``reps`` launches (measurement only:
+        the particle state is garbage afterwards)."""
+        ms = C.c_double()
+        self._check(self._L.nb_integrate_pass(self._h, int(reps), C.byref(ms)))
+        return ms.value
+
+    # -- native RCCL collective (one process per GPU) ------------------------
+    def rccl_attach(self, unique_id, nranks, rank, overlap=False):
+        if len(unique_id) != NB_RCCL_ID_BYTES:
+            raise ValueError("unique_id must be %d bytes" % NB_RCCL_ID_BYTES)
+        buf = C.create_string_buffer(bytes(unique_id), NB_RCCL_ID_BYTES)
+        self._check(self._L.nb_rccl_attach(self._h, buf, int(nranks), int(rank), NB_RCCL_OVERLAP if overlap else 0))
+
+    def rccl_detach(self):
+        self._check(self._L.nb_rccl_detach(self._h))
+
+    def rccl_info(self):
+        """(nranks, rank, rccl version code) of the attached communicator; zeros when none."""
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._L.nb_rccl_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return a.value, b.value, c.value
+
+    # -- viewer frame feed (nbody3d.js:408-415,482-487; colour input :380) ----
+    def request_frame(self):
+        self._check(self._L.nb_frame_request(self._h))
+
+    def frame(self, wait=True):
+        """Newest finished frame: (bodies f32 (n,4), speed f32 (n,), step index) -- views of the
+        engine's pinned host memory, valid until the second request_frame() after the one that
+        produced them; None when wait=False and nothing has landed yet."""
+        pb, ps, st = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.c_uint64()
+        rc = self._L.nb_frame_acquire(self._h, 1 if wait else 0, C.byref(pb), C.byref(ps), C.byref(st))
+        if rc == NB_NOT_READY:
+            return None
+        self._check(rc)
+        b = np.ctypeslib.as_array(pb, shape=(self.n, 4))
+        sp = np.ctypeslib.as_array(ps, shape=(self.n,))
+        return b, sp, st.value
+
     @property
     def variant(self):
         return self._L.nb_variant_name(self._h).decode()
@@ -290,7 +366,8 @@ class MultiSimulation:
     shards may share a GPU), peer-copy all-gather after every step.  Same
     host-side surface as Simulation; arrays hold the unpadded n rows."""
 
-    def __init__(self, n, n_shards, devices=None, precision="f32", eps2=None, force_variant=0, jsplit=0):
+    def __init__(self, n, n_shards, devices=None, precision="f32", eps2=None, force_variant=0, jsplit=0,
+                 collective="peer"):
         L = load_library()
         self._L = L
         self.n, self.n_shards = int(n), int(n_shards)
@@ -312,6 +389,22 @@ class MultiSimulation:
             raise NBodyError(rc, L.nb_multi_last_error(None).decode())
         self._h = h
         self.dt = self.G = 0.0
+        if collective != "peer":
+            try:
+                self.set_collective(collective)
+            except Exception:
+                self.close()
+                raise
+
+    def set_collective(self, mode):
+        """'peer' (event-ordered device-to-device copies) or 'rccl' (ncclCommInitAll + grouped
+        in-place ncclAllGather); bit-identical results."""
+        self._check(self._L.nb_multi_set_collective(self._h, {"peer": NB_MULTI_PEER, "rccl": NB_MULTI_RCCL}[mode]))
+
+    def collective_info(self):
+        a, b, c = C.c_int(), C.c_int(), C.c_int()
+        self._check(self._L.nb_multi_collective_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
+        return {"mode": "rccl" if a.value == NB_MULTI_RCCL else "peer", "nranks": b.value, "rccl_version": c.value}
 
     def close(self):
         if getattr(self, "_h", None):

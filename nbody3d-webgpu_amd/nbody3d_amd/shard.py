@@ -76,19 +76,23 @@ def torch_allgather_hook(bodies_tensor, plan, group=None):
 def torch_allgather_overlapped_hooks(bodies_tensor, plan, group=None):
     """(begin, wait) for Simulation.set_exchange_overlapped: the all-gather is issued
     with async_op=True right after the integrate kernel; the engine then enqueues
-    the next step's force work on the j-range of its OWN rows (which the in-place
-    gather does not write) and only then calls wait(), which makes the current
-    stream wait for the collective.  Hides the collective behind 1/world of the
-    force pass ("hide it by starting K1 on the rank's own j-block")."""
+    the next step's force work on the j-range of its OWN rows and only then calls wait(),
+    which makes the current stream wait for the collective.  Hides the collective behind
+    1/world of the force pass ("hide it by starting K1 on the rank's own j-block").
+
+    The gather is IN PLACE: the input is the view of this rank's rows inside ``bodies_tensor``
+    (input pointer = output pointer + rank * rows, the form RCCL documents for ncclAllGather),
+    so the collective never writes the rank's own rows -- the rows the early force launch is
+    reading while the collective runs.  (A separate send buffer would make the collective copy
+    them back onto themselves: same values, but an unsynchronised write under a concurrent read.)
+    The native path (nb_rccl_attach with NB_RCCL_OVERLAP) does the same inside the engine."""
     import torch.distributed as dist
 
     mine = bodies_tensor[plan.begin: plan.begin + plan.count]
-    send = mine.clone()          # see torch_allgather_hook
     state = {"work": None}
 
     def begin(bodies_ptr, esz, n, sb, sc, stream):
-        send.copy_(mine)
-        state["work"] = dist.all_gather_into_tensor(bodies_tensor, send, group=group, async_op=True)
+        state["work"] = dist.all_gather_into_tensor(bodies_tensor, mine, group=group, async_op=True)
         return 0
 
     def wait(stream):

@@ -33,7 +33,7 @@ if (mode === 'cpu') {
   const d = oracle.runF32(loadF32('disk771_bodies0'), loadF32('disk771_vel0'), null, manifest.disk771.dt, manifest.disk771.G, 1);
   check('js_oracle_bit_exact_disk771_s1', bitsEqual(d.bodies, loadF32('disk771_s1_bodies')) && bitsEqual(d.accel, loadF32('disk771_s1_accel')));
   // 2. wrapper loads the addon + engine library, and reports a missing GPU as an Error
-  check('addon_loads', nb.load() === 1);
+  check('addon_loads', nb.load() === 2);   // NB_ABI_VERSION
   check('surface', ['init', 'step', 'simulate', 'read'].every(function (k) { return typeof nb[k] === 'function'; }) && typeof nb.Simulation === 'function');
   if (nb.deviceCount() === 0) {
     check('no_device_throws', throws(function () { nb.init([b0, v0]); }, /no HIP device.*NB_2|NB_2/));

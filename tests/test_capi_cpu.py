@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version_and_config_layout():
-    assert capi.abi_version() == 1
+    assert capi.abi_version() == capi.ABI_VERSION == 2
     # layout must match the C struct: 4*4 + 8 + 3*4 (+4 pad) + 2*8 + 3*4 + 5*4 = 88
     assert C.sizeof(capi.nb_config) == 88
 

@@ -27,8 +27,9 @@ def kernel_bodies():
     subprocess.check_call(["make", "-C", CSRC, "-s", "asm"])
     text = open(ASM).read()
     out = {}
-    for m in re.finditer(r"^(_ZN2nb16nb_force_pk_sgprILi(\d)EEE\w+):\s*;.*?$(.*?)s_endpgm", text, re.S | re.M):
-        out[int(m.group(2))] = m.group(3).splitlines()
+    # nb_force_pk_sgpr<NG, WS>: NG in {2, 4} packed groups, WS in {1, 4} j-splitting waves
+    for m in re.finditer(r"^(_ZN2nb16nb_force_pk_sgprILi(\d)ELi(\d)EEE\w+):\s*;.*?$(.*?)s_endpgm", text, re.S | re.M):
+        out[(int(m.group(2)), int(m.group(3)))] = m.group(4).splitlines()
     return out
 
 
@@ -44,7 +45,7 @@ def sregs(operand_text):
 
 def test_no_instruction_touches_a_requested_sgpr_before_its_wait():
     bodies = kernel_bodies()
-    assert set(bodies) == {2, 4}, "expected both nb_force_pk_sgpr instantiations in the disassembly"
+    assert set(bodies) == {(2, 1), (2, 4), (4, 1), (4, 4)}, "expected all four nb_force_pk_sgpr instantiations"
     for ng, lines in bodies.items():
         pending = set()
         requests = waits = 0
@@ -80,5 +81,5 @@ def test_no_instruction_touches_a_requested_sgpr_before_its_wait():
                 pending.clear()
                 continue
             touched = sregs(rest) & pending
-            assert not touched, "NG=%d: `%s` touches s%s before the wait" % (ng, code, sorted(touched))
+            assert not touched, "NG,WS=%s: `%s` touches s%s before the wait" % (ng, code, sorted(touched))
         assert requests >= 8 and waits >= 2, (ng, requests, waits)

@@ -20,9 +20,14 @@ pytestmark = pytest.mark.gpu
 
 TOL_POS, TOL_TIGHT, TOL_ACC = 1e-4, 2e-5, 2e-5
 
-# (force_variant, jsplit): every kernel instantiation, with and without a j-split
+# (force_variant, jsplit): every kernel family, with and without a j-split.  Short codes are the
+# ABI-1 names; 6-digit codes are K II LL X (include/nbody3d_hip.h): K = 2 packed LDS-tile force
+# kernel, 3 packed SGPR-broadcast force kernel (X = waves splitting j), 4 fused one-launch step.
 VARIANTS = [(0, 0), (1, 1), (1, 3), (2, 1), (2, 2), (4, 1), (4, 4), (14, 1), (14, 2), (116, 1), (164, 1), (164, 2),
-            (22, 1), (22, 3), (24, 1), (24, 2), (28, 1), (28, 2), (34, 1), (34, 3), (38, 1), (38, 2)]
+            (22, 1), (22, 3), (24, 1), (24, 2), (28, 1), (28, 2), (34, 1), (34, 3), (38, 1), (38, 2),
+            (202021, 1), (202164, 2), (202644, 1), (204081, 3), (204324, 1), (208161, 2), (208644, 1),
+            (304014, 1), (304014, 3), (308014, 1), (308014, 2),
+            (402011, 0), (402161, 0), (402644, 0), (404041, 0), (404324, 0), (408011, 0), (408161, 0), (408644, 0)]
 
 
 def run_engine(b, v, dt, G, steps, a=None, **kw):
@@ -52,7 +57,8 @@ def test_single_step_matches_oracle_acceleration(variant, jsplit):
 
 
 @pytest.mark.parametrize("name,steps", [("plummer1024", 100), ("cube1000", 20), ("disk771", 50), ("galaxy_ref", 30)])
-@pytest.mark.parametrize("variant,jsplit", [(0, 0), (2, 1), (1, 2), (164, 1), (22, 1), (24, 2), (28, 1), (38, 2)])
+@pytest.mark.parametrize("variant,jsplit", [(0, 0), (2, 1), (1, 2), (164, 1), (22, 1), (24, 2), (28, 1), (38, 2),
+                                            (308014, 2), (402644, 0), (404161, 0), (408041, 0)])
 def test_golden_trajectories(manifest, name, steps, variant, jsplit):
     """BASELINE.json config 1 (Plummer N=1024, dt=1e-3, 100 steps) and the
     ragged-N / harsh-mass-ratio fixtures, against fp64 and fp32 oracle vectors."""
@@ -159,7 +165,7 @@ def test_ragged_sizes(n):
 
 
 @pytest.mark.parametrize("n", [9, 263, 1001, 4099])
-@pytest.mark.parametrize("variant", [34, 38])
+@pytest.mark.parametrize("variant", [34, 38, 304014, 308014])
 def test_ragged_sizes_on_the_sgpr_kernel(n, variant):
     """The SGPR-broadcast kernel walks j in batches of 8 with a scalar remainder loop:
     N not a multiple of 8 (and splits that end mid-batch) must still match the oracle."""
@@ -442,18 +448,21 @@ def test_energy_drift_reported_and_small(manifest):
     assert drift < 5 * m["energy_drift"]["f64"] + 1e-6
 
 
-@pytest.mark.parametrize("n", [65536, 262144, 1048576])
-def test_full_size_properties(n):
+@pytest.mark.parametrize("n,variant", [(65536, 0), (65536, 28), (262144, 0), (262144, 208011), (1048576, 0)])
+def test_full_size_properties(n, variant):
     """BASELINE.json configs 2, 3 and 4 (N=1,048,576) at full size, through size-independent
     properties (the oracle would take minutes): a sampled i-slice against the
     fp64 oracle, Newton's third law, and shard-composition (row blocks of a
-    1/8 shard handle equal the full handle's rows)."""
+    1/8 shard handle equal the full handle's rows).  variant 28 / 208011 pin config 2's
+    "LDS tile=256" kernel (the default shape at these sizes streams j through SGPRs)."""
     b, v = (ic.uniform_cube(n, seed=2) if n == 65536 else ic.plummer(n, seed=1))
-    with Simulation(n) as sim:
+    with Simulation(n, force_variant=variant) as sim:
         sim.init(b, v)
         sim.simulate(1, 1e-3, 1.0)
         bb, vv, aa = sim.read()
         name = sim.variant
+    if variant:
+        assert "pk_lds256" in name, name
     rows = np.random.default_rng(0).choice(n, 96, replace=False)
     rows.sort()
     b64 = b.astype(np.float64)

@@ -1,0 +1,340 @@
+"""GPU tests of the round-2 paths, all through the C ABI:
+
+  * the fused one-launch step (ping-pong positions) against the two-kernel step, bit for bit;
+  * every fp64 launch shape against the fp64 oracle (BASELINE.json config 5), full size included;
+  * the native RCCL collective: nb_multi in RCCL mode and nb_rccl_attach with one rank
+    (one GPU is all a test box has; the partition/offset logic is covered by the
+    virtual-shard and gloo tests), and bench.py's distributed path;
+  * the viewer frame feed; the integrate kernel on its own.
+"""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden32, load_golden64, rel_pos_err
+from oracle import oracle
+from nbody3d_amd import MultiSimulation, Simulation, capi, ic
+
+pytestmark = pytest.mark.gpu
+
+TOL_ACC = 2e-5
+TOL_F64 = 1e-12
+
+
+def run(b, v, steps, dt=1e-3, G=1.0, **kw):
+    with Simulation(b.shape[0], **kw) as sim:
+        sim.init(b, v)
+        sim.simulate(steps, dt, G)
+        return sim.read() + (sim.variant,)
+
+
+# ---- fused step -------------------------------------------------------------------------------
+
+FUSED_SHAPES = [(2, 1, 1), (2, 16, 1), (2, 64, 1), (2, 64, 4), (2, 32, 4), (4, 4, 1), (4, 32, 1), (4, 16, 4),
+                (8, 1, 1), (8, 2, 1), (8, 8, 1), (8, 64, 1), (8, 64, 4)]
+
+
+@pytest.mark.parametrize("ipl,ls,tl", FUSED_SHAPES)
+@pytest.mark.parametrize("n", [1000, 4096])
+def test_fused_step_is_bit_identical_to_the_two_kernel_step(ipl, ls, tl, n):
+    """nb_step_fused<NG,LS,TL> == nb_force_pk<NG,LS,TL> (one j-split) + nb_integrate: same loop,
+    same in-wave reduction, same leapfrog -- 19 steps so that graph replay (16) and both
+    ping-pong parities are exercised."""
+    b, v = (ic.plummer(n, seed=31) if n % 256 == 0 else ic.uniform_cube(n, seed=31))
+    code = ipl * 1000 + ls * 10 + tl
+    fb, fv, fa, fname = run(b, v, 19, force_variant=400000 + code)
+    tb, tv, ta, tname = run(b, v, 19, force_variant=200000 + code, jsplit=1)
+    assert "fused" in fname and "fused" not in tname and tname.endswith("_js1"), (fname, tname)
+    assert fb.tobytes() == tb.tobytes() and fv.tobytes() == tv.tobytes() and fa.tobytes() == ta.tobytes(), (fname, tname)
+    rb, rv, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 19)
+    assert rel_pos_err(fb, rb, 1.0) < 2e-5, fname
+
+
+def test_default_small_system_takes_the_fused_path_and_flag_disables_it():
+    b, v = ic.plummer(4096, seed=32)
+    fb, fv, fa, fname = run(b, v, 5)
+    nb_, nv, na, nname = run(b, v, 5, flags=capi.NB_FLAG_NO_FUSE)
+    assert "fused" in fname and "fused" not in nname, (fname, nname)
+    rb, _, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 5)
+    for x, a, name in ((fb, fa, fname), (nb_, na, nname)):
+        assert rel_pos_err(x, rb, 1.0) < 2e-5, name
+        assert np.abs(a[:, :3] - ra[:, :3]).max() < TOL_ACC * np.abs(ra[:, :3]).max(), name
+
+
+def test_fused_handle_interleaves_steps_reads_restores_and_diagnostics():
+    """Positions live in one of two buffers; every entry point must follow the live one."""
+    n = 2048
+    b, v = ic.plummer(n, seed=33)
+    with Simulation(n, force_variant=402644) as f, Simulation(n, force_variant=202644, jsplit=1) as t:
+        for s in (f, t):
+            s.init(b, v)
+            s.set_params(1e-3, 1.0)
+        for k in (1, 2, 17, 3):                  # odd and even step counts, one graph replay
+            for s in (f, t):
+                s.simulate(k)
+            rf, rt = f.read(), t.read()
+            for x, y in zip(rf, rt):
+                assert x.tobytes() == y.tobytes(), k
+            kf, pf, mf = f.diagnostics()
+            kt, pt, mt = t.diagnostics()
+            assert kf == kt and pf == pt
+        state = f.read()
+        f.simulate(5); t.simulate(5)
+        want = t.read()
+        f.restore(*state)                        # mid-run restore on an odd ping-pong parity
+        f.simulate(5)
+        for x, y in zip(f.read(), want):
+            assert x.tobytes() == y.tobytes()
+        with pytest.raises(Exception) as e:
+            f.set_exchange(lambda *a: 0)
+        assert "NB_ERR_STATE" in str(e.value)
+
+
+# ---- fp64 (BASELINE.json config 5) ------------------------------------------------------------
+
+F64_SHAPES = [(1, 1), (1, 3), (2, 1), (2, 2), (4, 1), (4, 5), (14, 1), (14, 2), (116, 1), (116, 2), (164, 1), (164, 3), (0, 0)]
+
+
+@pytest.mark.parametrize("variant,jsplit", F64_SHAPES)
+def test_f64_single_step_matches_fp64_oracle(variant, jsplit):
+    n = 2048
+    b, v = ic.plummer(n, seed=41)
+    b, v = b.astype(np.float64), v.astype(np.float64)
+    bb, vv, aa, name = run(b, v, 1, precision="f64", force_variant=variant, jsplit=jsplit)
+    assert name.startswith("f64"), name
+    ref = oracle.accel_f64(b, 1.0)
+    assert np.abs(aa[:, :3] - ref[:, :3]).max() < TOL_F64 * np.abs(ref[:, :3]).max(), name
+    rb, rv, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 1)
+    assert rel_pos_err(bb, rb, 1.0) < TOL_F64, name
+
+
+@pytest.mark.parametrize("variant,jsplit", F64_SHAPES)
+@pytest.mark.parametrize("name,steps", [("plummer1024", 100), ("galaxy_ref", 30), ("disk771", 50)])
+def test_f64_golden_trajectories(manifest, name, steps, variant, jsplit):
+    m = manifest[name]
+    b0 = load_golden32(name + "_bodies0").astype(np.float64)
+    v0 = load_golden32(name + "_vel0").astype(np.float64)
+    bb, vv, aa, vname = run(b0, v0, steps, dt=m["dt"], G=m["G"], precision="f64", force_variant=variant, jsplit=jsplit)
+    ref = load_golden64("%s_s%d_bodies" % (name, steps))
+    assert rel_pos_err(bb, ref, m["r_scale"]) < TOL_F64, (vname, name)
+
+
+def test_f64_full_size_properties():
+    """Config 5 at N=262,144 with the launch shape the engine picks for it: sampled rows against
+    the fp64 oracle at 1e-12, Newton's third law, and agreement with the f32 engine."""
+    n = 262144
+    b, v = ic.plummer(n, seed=1)
+    b64, v64 = b.astype(np.float64), v.astype(np.float64)
+    bb, vv, aa, name = run(b64, v64, 1, precision="f64")
+    assert name.startswith("f64"), name
+    rows = np.sort(np.random.default_rng(1).choice(n, 24, replace=False))
+    for i in rows:
+        ref = oracle.accel_f64(b64, 1.0, i0=int(i), i1=int(i) + 1)[0, :3]
+        assert np.abs(aa[i, :3] - ref).max() < TOL_F64 * max(np.abs(ref).max(), 1e-3), (name, i)
+    f = (b64[:, 3:4] * aa[:, :3]).sum(0)
+    assert np.all(np.abs(f) < 1e-11 * np.abs(b64[:, 3:4] * aa[:, :3]).sum(0))
+    fb, fv, fa, fname = run(b, v, 1)
+    assert np.abs(fa[:, :3] - aa[:, :3]).max() < TOL_ACC * np.abs(aa[:, :3]).max(), fname
+
+
+# ---- native RCCL ------------------------------------------------------------------------------
+
+def test_multi_handle_rccl_mode_one_device():
+    """nb_multi in NB_MULTI_RCCL mode with one shard on the one GPU of the box: ncclCommInitAll,
+    ncclGroupStart / in-place ncclAllGather / ncclGroupEnd every step -- the calls an 8-GPU
+    node makes -- bit-identical to the peer-copy mode and to a plain handle."""
+    n, steps = 4096, 6
+    b, v = ic.plummer(n, seed=51)
+    kw = dict(force_variant=28, jsplit=4)
+    with Simulation(n, **kw) as one:
+        one.init(b, v)
+        one.simulate(steps, 1e-3, 1.0)
+        ref = one.read()
+    with MultiSimulation(n, 1, collective="rccl", **kw) as ms:
+        info = ms.collective_info()
+        assert info["mode"] == "rccl" and info["nranks"] == 1 and info["rccl_version"] > 20000, info
+        ms.init(b, v)
+        ms.simulate(steps, 1e-3, 1.0)
+        got = ms.read()
+        ms.set_collective("peer")
+        assert ms.collective_info() == {"mode": "peer", "nranks": 0, "rccl_version": 0}
+        ms.simulate(2)
+        ms.set_collective("rccl")
+        ms.simulate(2)
+        later = ms.read()
+    for x, y in zip(got, ref):
+        assert x.tobytes() == y.tobytes()
+    rb, _, _ = oracle.run_f32(b, v, None, 1e-3, 1.0, steps + 4)
+    assert rel_pos_err(later[0], rb, 1.0) < 1e-6
+
+
+def test_multi_handle_rccl_mode_refuses_shared_devices():
+    b, v = ic.plummer(1024, seed=52)
+    with MultiSimulation(1024, 2) as ms:             # two shards on the one GPU: fine for peer copies
+        with pytest.raises(Exception) as e:
+            ms.set_collective("rccl")
+        assert "own device" in str(e.value)
+        ms.init(b, v)
+        ms.simulate(3, 1e-3, 1.0)                    # still usable in peer mode
+        rb, _, _ = oracle.run_f32(b, v, None, 1e-3, 1.0, 3)
+        assert rel_pos_err(ms.read()[0], rb, 1.0) < 1e-6
+
+
+@pytest.mark.parametrize("overlap", [False, True])
+def test_rccl_attach_single_rank(overlap):
+    """nb_rccl_attach: the engine's own in-place ncclAllGather after every integrate kernel
+    (one process per GPU).  One rank here; results equal the handle without a communicator."""
+    n, steps = 8192, 5
+    b, v = ic.plummer(n, seed=53)
+    kw = dict(force_variant=308014, jsplit=4, flags=capi.NB_FLAG_NO_FUSE)
+    with Simulation(n, **kw) as one:
+        one.init(b, v)
+        one.simulate(steps, 1e-3, 1.0)
+        ref = one.read()
+    with Simulation(n, shard=(0, n), **kw) as sim:
+        uid = capi.rccl_unique_id()
+        assert len(uid) == 128 and any(uid)
+        sim.rccl_attach(uid, 1, 0, overlap=overlap)
+        nranks, rank, ver = sim.rccl_info()
+        assert (nranks, rank) == (1, 0) and ver > 20000
+        with pytest.raises(Exception):
+            sim.set_exchange(lambda *a: 0)           # hook and native collective are exclusive
+        sim.init(b, v)
+        sim.enable_timing(True)
+        sim.simulate(steps, 1e-3, 1.0)
+        f_ms, i_ms, x_ms, launches = sim.step_times()
+        got = sim.read()
+        assert launches == steps and f_ms > 0 and i_ms > 0
+        if not overlap:
+            assert x_ms > 0
+        sim.rccl_detach()
+        assert sim.rccl_info() == (0, 0, 0)
+    for x, y in zip(got, ref):
+        assert x.tobytes() == y.tobytes()
+
+
+def test_rccl_attach_checks_the_partition():
+    with Simulation(1024, shard=(256, 256)) as sim:
+        uid = capi.rccl_unique_id()
+        with pytest.raises(Exception) as e:
+            sim.rccl_attach(uid, 1, 0)               # 1 rank must own all rows
+        assert "NB_ERR_INVALID" in str(e.value)
+
+
+def _bench(*args, env=None, timeout=600):
+    e = dict(os.environ)
+    e.update(env or {})
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
+                       timeout=timeout, env=e)
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    return p, (json.loads(lines[-1]) if lines else None)
+
+
+@pytest.mark.parametrize("exchange", ["native", "torch"])
+def test_bench_distributed_path_with_one_rank(exchange):
+    """bench.py --force-dist: process group on the nccl (= RCCL) backend, sharded handle on torch's
+    stream, per-step all-gather (the engine's own ncclAllGather, or torch's through the hook)."""
+    p, out = _bench("--force-dist", "--exchange", exchange, "--nbodies", "16384", "--steps", "4", "--warmup", "1",
+                    "--no-cpu-baseline")
+    assert p.returncode == 0 and out, p.stderr[-2000:]
+    assert out["n_gpus"] == 1 and out["value"] > 0
+    assert out["exchange"]["kind"].startswith("rccl-native" if exchange == "native" else "torch"), out["exchange"]
+    if exchange == "native":
+        assert out["exchange"]["rccl_nranks"] == 1 and out["exchange"]["avg_ms"] > 0
+    assert out["check"]["pass"], out["check"]
+
+
+def test_bench_multi_gpu_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher: the GPU-free parent starts the two ranks
+    itself.  On a one-GPU box they must get as far as the device count and fail there."""
+    p, out = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", timeout=300)
+    if capi.device_count() >= 2:
+        assert p.returncode == 0 and out and out["n_gpus"] == 2
+    else:
+        assert p.returncode != 0 and out is None
+        assert "2 ranks need 2 GPUs" in (p.stderr + p.stdout), (p.stderr + p.stdout)[-1500:]
+
+
+# ---- frame feed, integrate pass ----------------------------------------------------------------
+
+@pytest.mark.parametrize("precision", ["f32", "f64"])
+def test_frame_feed_values_equal_read(precision):
+    """nb_frame_request / nb_frame_acquire: the snapshot taken after step k equals read() at
+    step k (f32 bodies + length(vel.xyz), nbody3d.js:380), however many steps follow it."""
+    n = 3000
+    b, v = ic.plummer(n, seed=61)
+    dt = np.float64 if precision == "f64" else np.float32
+    with Simulation(n, precision=precision) as sim:
+        sim.init(b.astype(dt), v.astype(dt))
+        sim.set_params(1e-3, 1.0)
+        with pytest.raises(Exception) as e:
+            sim.frame(wait=False)                          # nothing requested yet
+        assert "NB_ERR_STATE" in str(e.value)
+        done = 0
+        for k in (3, 1, 4):
+            sim.simulate(k)
+            done += k
+            sim.request_frame()
+            sim.simulate(2)                                # later steps must not disturb the snapshot
+            done += 2
+            fb, fs, step = sim.frame(wait=True)
+            assert step == done - 2
+            fb, fs = fb.copy(), fs.copy()
+    with Simulation(n, precision=precision) as ref:
+        ref.init(b.astype(dt), v.astype(dt))
+        ref.simulate(done - 2, 1e-3, 1.0)
+        rb, rv, _ = ref.read()
+    assert fb.dtype == np.float32 and fs.dtype == np.float32
+    assert np.array_equal(fb, rb.astype(np.float32))
+    rv32 = rv[:, :3].astype(np.float32)
+    want = np.sqrt(rv32[:, 0] * rv32[:, 0] + rv32[:, 1] * rv32[:, 1] + rv32[:, 2] * rv32[:, 2])
+    assert np.allclose(fs, want, rtol=2e-6, atol=0)
+
+
+def test_frame_feed_does_not_stall_the_step_stream():
+    """A snapshot every frame at the reference's default workload size (N=40,002, one step per
+    frame as render() does): throughput within 3 % of running without snapshots."""
+    n = 40002
+    b, v = ic.uniform_cube(n, seed=62)
+    frames = 300
+
+    def loop(with_frames):
+        with Simulation(n) as sim:
+            sim.init(b, v)
+            sim.set_params(1e-4, 1e-4)
+            for _ in range(20):
+                sim.step()
+            sim.sync()
+            t0 = time.perf_counter()
+            for _ in range(frames):
+                sim.step()
+                if with_frames:
+                    sim.request_frame()
+                    sim.frame(wait=False)
+            sim.sync()
+            return time.perf_counter() - t0
+
+    loop(False)
+    base = min(loop(False), loop(False))
+    feed = min(loop(True), loop(True))
+    assert feed < 1.03 * base, (feed, base)
+
+
+def test_integrate_pass_measures_the_integrator_alone():
+    n = 1 << 20
+    b, v = ic.uniform_cube(n, seed=63)
+    with Simulation(n, force_variant=208011, jsplit=1, flags=capi.NB_FLAG_NO_FUSE) as sim:
+        sim.init(b, v)
+        sim.set_params(1e-3, 1.0)
+        ms = sim.integrate_pass(20)
+        assert 0 < ms < 5.0                      # 100 MB of traffic: tens of microseconds
+    with Simulation(4096) as fused:
+        fused.init(*ic.plummer(4096, seed=1))
+        with pytest.raises(Exception) as e:
+            fused.integrate_pass(1)
+        assert "NB_ERR_STATE" in str(e.value)
