@@ -208,7 +208,9 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
             for (int ls : {1, 2, 4, 8, 16, 32, 64})
                 for (int tl : {1, 4}) {
                     if (tl == 4 && ls < 16) continue;
-                    const double cyc = 34.0 * ipl * (ipl == 2 ? 1.05 : 1.0);
+                    // LS > 1: measured 72-76 % of the issue rate at 2-4 waves per SIMD (the waves of a
+                    // workgroup wait on the next tile's global loads: profiles/r02/ubench4_*.txt)
+                    const double cyc = 34.0 * ipl * (ipl == 2 ? 1.05 : 1.0) * (ls > 1 ? 1.22 : 1.0);
                     cands.push_back({{kPkLds, ipl, ls, tl}, cyc});
                     if (may_fuse) cands.push_back({{kFused, ipl, ls, tl}, cyc});
                 }
@@ -252,7 +254,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
             if (c.sh.kind == kFused) { if (cfg.jsplit > 1) continue; js_lo = js_top = 1; }
             for (uint32_t q = js_lo; q <= js_top; ++q) {
                 const uint32_t len = split_len(q), used = ceil_div(n, len);
-                if (c.sh.kind == kPkSgpr && len / c.sh.x < 512) continue;   // SGPR loop wants >= 512 bodies per wave
+                if (c.sh.kind == kPkSgpr && len / c.sh.x < 256) continue;   // SGPR loop wants >= 256 bodies per wave
                 const uint64_t blocks = (uint64_t)iblocks * used;
                 const uint64_t full = blocks / slots, rem = blocks % slots;
                 const double tile = c.sh.kind == kPkSgpr ? 256.0 : 256.0 * c.sh.x;
@@ -261,8 +263,9 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 const double iters = std::ceil(wave_len / c.sh.ls);
                 // a SIMD with fewer than 4 resident waves cannot keep its issue port full
                 // (measured with the pure-ALU loop, profiles/r01/ubench_run1.txt, profiles/r02/ubench3_*.txt)
+                const bool sg = c.sh.kind == kPkSgpr;     // no barriers, no tile hand-over: fills better at 2-3 waves
                 auto round_cycles = [&](double per_cu) {
-                    const double fill = per_cu >= 4 ? 1.0 : per_cu >= 3 ? 0.92 : per_cu >= 2 ? 0.82 : 0.62;
+                    const double fill = per_cu >= 4 ? 1.0 : per_cu >= 3 ? (sg ? 0.95 : 0.92) : per_cu >= 2 ? (sg ? 0.88 : 0.82) : 0.62;
                     return std::max(iters * per_cu * c.cyc_iter / fill, stages * kTileLatency) + kPrologue;
                 };
                 double cyc = full * round_cycles(occ);
@@ -579,7 +582,13 @@ int nb_upload(nb_sim* s, const void* bodies, const void* vel, const void* accel)
     NB_HIP(s, hipMemcpy(s->bodies[s->cur], bodies, row * s->n, hipMemcpyHostToDevice));
     NB_HIP(s, hipMemcpy(s->vel, (const char*)vel + row * s->sb, row * s->sc, hipMemcpyHostToDevice));
     if (accel) NB_HIP(s, hipMemcpy(s->acc, (const char*)accel + row * s->sb, row * s->sc, hipMemcpyHostToDevice));
-    else NB_HIP(s, hipMemset(s->acc, 0, row * s->sc));   // WebGPU zero-init, nbody3d.js:195-199
+    else {
+        // WebGPU zero-init, nbody3d.js:195-199.  On the ENGINE stream: a hipMemset on the null stream is
+        // asynchronous for device memory and the engine's non-blocking stream does not wait for it
+        // -- the fused step reads accel in its first microsecond.
+        NB_HIP(s, hipMemsetAsync(s->acc, 0, row * s->sc, s->stream));
+        NB_HIP(s, hipStreamSynchronize(s->stream));
+    }
     s->uploaded = true;
     return NB_OK;
 }
@@ -827,7 +836,7 @@ int nb_frame_request(nb_sim* s)
             memset(f.h_speed, 0, sizeof(float) * s->n);
             NB_HIP(s, hipMalloc((void**)&f.d_bodies, sizeof(float) * 5 * s->n));
             f.d_speed = f.d_bodies + (size_t)4 * s->n;
-            NB_HIP(s, hipMemset(f.d_speed, 0, sizeof(float) * s->n));
+            NB_HIP(s, hipMemsetAsync(f.d_speed, 0, sizeof(float) * s->n, s->stream));   // ordered before the pack kernel
             NB_HIP(s, hipEventCreateWithFlags(&f.packed, hipEventDisableTiming));
             NB_HIP(s, hipEventCreateWithFlags(&f.landed, hipEventDisableTiming));
         }

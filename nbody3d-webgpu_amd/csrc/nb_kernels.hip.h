@@ -46,8 +46,50 @@ template <typename T> struct vec4;
 template <> struct vec4<float> { using type = float4; };
 template <> struct vec4<double> { using type = double4; };
 
+// Diagnostic build only (tools/ubench4.hip, -DNB_STAMPS): per-wave s_memtime stamps at the phase
+// boundaries of the LDS-tile kernels, written to a buffer nothing else reads.  The product build
+// compiles NB_STAMP to nothing (MI355X_MICROARCH.md 'DVFS give-back' item 6: no stamp executes
+// in the real kernel).
+#ifdef NB_STAMPS
+__device__ unsigned long long* nb_stamp_buf;
+#define NB_STAMP(k)                                                                                         \
+    do {                                                                                                    \
+        unsigned long long t_;                                                                              \
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
+        if ((threadIdx.x & 63) == 0) nb_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = t_; \
+        if ((k) == 0) {                 /* where the wave runs: HW_ID (wave/simd/cu/sh/se) and XCC_ID */       \
+            unsigned hw_, xcc_;                                                                                 \
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xcc_)); \
+            if ((threadIdx.x & 63) == 0) nb_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = ((unsigned long long)xcc_ << 32) | hw_; \
+        }                                                                                                   \
+        if ((k) == 0 || (k) == 4) {     /* 100 MHz wall clock beside the first and last stamp */                \
+            unsigned long long r_;                                                                              \
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_)::"memory");                    \
+            if ((threadIdx.x & 63) == 0) nb_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + ((k) == 0 ? 5 : 6)] = r_; \
+        }                                                                                                   \
+    } while (0)
+#else
+#define NB_STAMP(k) do { } while (0)
+#endif
+
 constexpr int kBlock = 256;  // threads per workgroup = reference TILE_SIZE (nbody3d.js:4,240)
 constexpr int kTile = 256;   // j-bodies per LDS tile unit (nbody3d.js:229); TL units are staged at once
+
+// Whole-row global loads.  HIP's float4/double4 are structs of scalars: a plain `bodies[j]` is
+// four scalar loads that the backend re-merges as it sees fit (seen: dwordx2 + dwordx3 + dwordx2
+// for one row).  Going through the native vector type keeps ONE global_load_dwordx4 (two for f64).
+typedef float nb_v4f __attribute__((ext_vector_type(4)));
+typedef double nb_v4d __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float4* p)
+{
+    const nb_v4f v = *reinterpret_cast<const nb_v4f*>(p);
+    return float4{v.x, v.y, v.z, v.w};
+}
+__device__ __forceinline__ double4 ld4(const double4* p)
+{
+    const nb_v4d v = *reinterpret_cast<const nb_v4d*>(p);
+    return double4{v.x, v.y, v.z, v.w};
+}
 
 __device__ __forceinline__ float nb_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double nb_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
@@ -124,6 +166,24 @@ __device__ __forceinline__ float group_sum(float v)
     if constexpr (LS >= 64) v = dpp_add<0x143, 0xC>(v);   // row_bcast31 into rows 2 and 3
     return v;
 }
+// The same reduction for NV values at once, step-major: the NV adds of a step are independent, so
+// no DPP hazard wait falls between them (value by value every add waits on the one before).
+// Per value the operations and their order are exactly group_sum's: bit-identical results.
+template <int LS, int NV>
+__device__ __forceinline__ void group_sum_all(float (&v)[NV])
+{
+#define NB_DPP_STEP(MIN_LS, CTRL, MASK)                                  \
+    if constexpr (LS >= MIN_LS) {                                        \
+        _Pragma("unroll") for (int i = 0; i < NV; ++i) v[i] = dpp_add<CTRL, MASK>(v[i]); \
+    }
+    NB_DPP_STEP(2, 0xB1, 0xF)
+    NB_DPP_STEP(4, 0x4E, 0xF)
+    NB_DPP_STEP(8, 0x141, 0xF)
+    NB_DPP_STEP(16, 0x140, 0xF)
+    NB_DPP_STEP(32, 0x142, 0xA)
+    NB_DPP_STEP(64, 0x143, 0xC)
+#undef NB_DPP_STEP
+}
 template <int LS>
 __device__ __forceinline__ double group_sum(double v)
 {
@@ -177,8 +237,7 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
 #pragma unroll
     for (int k = 0; k < IPL; ++k) {
         const uint32_t il = bxi * IPB + k * GROUPS + grp;
-        V4 b = V4{0, 0, 0, 0};
-        if (il < i_count) b = bodies[i_begin + il];
+        const V4 b = ld4(bodies + i_begin + (il < i_count ? il : i_count - 1));   // clamped, branch-free (sum never stored)
         xi[k] = b.x; yi[k] = b.y; zi[k] = b.z;
         ax[k] = 0; ay[k] = 0; az[k] = 0;
     }
@@ -188,14 +247,19 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
     if (j1 > n) j1 = n;
     const uint32_t ntiles = (j1 > j0) ? (j1 - j0 + kTile - 1) / kTile : 0;
 
+    // load: raw, clamped, nothing consumes it until finish() right before the LDS store -- a use
+    // next to the load would park the wave on vmcnt(0) and expose the latency every tile
     auto stage = [&](uint32_t t) -> V4 {
         const uint32_t j = j0 + t * kTile + tid;
-        V4 b = V4{0, 0, 0, 0};              // past the range: zero mass, contributes exactly 0
-        if (j < j1) { b = bodies[j]; b.w *= G; }
+        return ld4(bodies + (j < j1 ? j : j1 - 1));
+    };
+    auto finish = [&](uint32_t t, V4 b) -> V4 {
+        const uint32_t j = j0 + t * kTile + tid;
+        b.w = j < j1 ? b.w * G : T(0);      // past the range: zero mass, contributes exactly 0
         return b;
     };
 
-    if (ntiles) tile[0][tid] = stage(0);
+    if (ntiles) tile[0][tid] = finish(0, stage(0));
     __syncthreads();
 
     for (uint32_t t = 0; t < ntiles; ++t) {
@@ -218,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
                 for (int k = 0; k < IPL; ++k) pair(b.x, b.y, b.z, b.w, xi[k], yi[k], zi[k], eps2, ax[k], ay[k], az[k]);
             }
         }
-        if (more) tile[cur ^ 1][tid] = nxt;
+        if (more) tile[cur ^ 1][tid] = finish(t + 1, nxt);
         __syncthreads();
     }
 
@@ -280,22 +344,75 @@ struct PkCore {
         const nb_f2 e2 = nb_f2{eps2, eps2};
         const uint32_t ntiles = (j1 > j0) ? (j1 - j0 + TILE - 1) / TILE : 0;
 
+        // The global loads of a stage are issued back to back with NOTHING consuming them until the
+        // stage is stored (clamped index instead of a bounds branch; G and the zero-mass mask are
+        // applied in store()): any use next to the load would park the wave on vmcnt(0) right
+        // there and the "next tile in flight under this tile's compute" would not be in flight.
         float4 nxt[TL];
+        uint32_t nxt_j0 = 0;
         auto load = [&](uint32_t t) {
+            nxt_j0 = j0 + t * TILE;
 #pragma unroll
             for (int q = 0; q < TL; ++q) {
-                const uint32_t j = j0 + t * TILE + q * kBlock + tid;
-                nxt[q] = float4{0, 0, 0, 0};              // past the range: zero mass, contributes exactly 0
-                if (j < j1) { nxt[q] = bodies[j]; nxt[q].w *= G; }
+                const uint32_t j = nxt_j0 + q * kBlock + tid;
+                nxt[q] = ld4(bodies + (j < j1 ? j : j1 - 1));
             }
         };
         auto store = [&](int buf) {
 #pragma unroll
-            for (int q = 0; q < TL; ++q) tile[buf][q * kBlock + tid] = nxt[q];
+            for (int q = 0; q < TL; ++q) {
+                const uint32_t j = nxt_j0 + q * kBlock + tid;
+                float4 b = nxt[q];
+                b.w = j < j1 ? b.w * G : 0.0f;           // past the range: zero mass, contributes exactly 0
+                tile[buf][q * kBlock + tid] = b;
+            }
+        };
+
+        // one stage: JB j-bodies (rows p[0], p[LS], ...) against the lane's NG packed groups.
+        // (Tried and dropped: issuing a stage's ds_read_b128s one stage ahead through asm statements.
+        // One wave alone ran the loop 25 % faster, four per SIMD 3-7 % slower -- the statements fence
+        // the scheduler at every stage -- and the step time did not move: at these sizes the waves
+        // wait on the next tile's global loads, not on LDS.  profiles/r02/ubench4_*.txt)
+        auto math = [&](const float4* p) {
+            nb_f2 bx[JB], by[JB], bz[JB], bm[JB];
+#pragma unroll
+            for (int u = 0; u < JB; ++u) {
+                const float4 b = p[u * LS];
+                bx[u] = nb_f2{b.x, b.x}; by[u] = nb_f2{b.y, b.y}; bz[u] = nb_f2{b.z, b.z}; bm[u] = nb_f2{b.w, b.w};
+            }
+            nb_f2 dx[NC], dy[NC], dz[NC], d2[NC], r[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dx[c] = bx[c / NG] - xi[c % NG];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dy[c] = by[c / NG] - yi[c % NG];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) dz[c] = bz[c / NG] - zi[c % NG];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = d2[c] * d2[c];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+#pragma unroll
+            for (int c = 0; c < NC; ++c) r[c] = bm[c / NG] * r[c];
+            // accumulate in ascending j for every group (same order as the plain loop)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) ax[c % NG] = __builtin_elementwise_fma(r[c], dx[c], ax[c % NG]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) ay[c % NG] = __builtin_elementwise_fma(r[c], dy[c], ay[c % NG]);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) az[c % NG] = __builtin_elementwise_fma(r[c], dz[c], az[c % NG]);
         };
 
         if (ntiles) { load(0); store(0); }
         __syncthreads();
+        NB_STAMP(1);
 
         for (uint32_t t = 0; t < ntiles; ++t) {
             const int cur = t & 1;
@@ -311,56 +428,28 @@ struct PkCore {
             const int chunks = ((cnt + LS - 1) / LS + U - 1) / U;
             for (int ch = 0; ch < chunks; ++ch) {
 #pragma unroll UNROLL
-                for (int uu = 0; uu < UNR; ++uu) {
-                    const int jj = ch * U + uu * JB;
-                    nb_f2 bx[JB], by[JB], bz[JB], bm[JB];
-#pragma unroll
-                    for (int u = 0; u < JB; ++u) {
-                        const float4 b = tile[cur][(jj + u) * LS + js];
-                        bx[u] = nb_f2{b.x, b.x}; by[u] = nb_f2{b.y, b.y}; bz[u] = nb_f2{b.z, b.z}; bm[u] = nb_f2{b.w, b.w};
-                    }
-                    nb_f2 dx[NC], dy[NC], dz[NC], d2[NC], r[NC];
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) dx[c] = bx[c / NG] - xi[c % NG];
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) dy[c] = by[c / NG] - yi[c % NG];
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) dz[c] = bz[c / NG] - zi[c % NG];
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) r[c] = d2[c] * d2[c];
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) r[c] = r[c] * d2[c];
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) r[c] = bm[c / NG] * r[c];
-                    // accumulate in ascending j for every group (same order as the plain loop)
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) ax[c % NG] = __builtin_elementwise_fma(r[c], dx[c], ax[c % NG]);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) ay[c % NG] = __builtin_elementwise_fma(r[c], dy[c], ay[c % NG]);
-#pragma unroll
-                    for (int c = 0; c < NC; ++c) az[c % NG] = __builtin_elementwise_fma(r[c], dz[c], az[c % NG]);
-                }
+                for (int uu = 0; uu < UNR; ++uu) math(&tile[cur][(ch * U + uu * JB) * LS + js]);
             }
             if (more) store(cur ^ 1);
             __syncthreads();
         }
+        NB_STAMP(2);
 
         if constexpr (LS > 1) {
+            float r[6 * NG];
 #pragma unroll
             for (int g = 0; g < NG; ++g) {
-                ax[g].x = group_sum<LS>(ax[g].x); ax[g].y = group_sum<LS>(ax[g].y);
-                ay[g].x = group_sum<LS>(ay[g].x); ay[g].y = group_sum<LS>(ay[g].y);
-                az[g].x = group_sum<LS>(az[g].x); az[g].y = group_sum<LS>(az[g].y);
+                r[6 * g + 0] = ax[g].x; r[6 * g + 1] = ax[g].y; r[6 * g + 2] = ay[g].x;
+                r[6 * g + 3] = ay[g].y; r[6 * g + 4] = az[g].x; r[6 * g + 5] = az[g].y;
+            }
+            group_sum_all<LS, 6 * NG>(r);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                ax[g] = nb_f2{r[6 * g + 0], r[6 * g + 1]}; ay[g] = nb_f2{r[6 * g + 2], r[6 * g + 3]};
+                az[g] = nb_f2{r[6 * g + 4], r[6 * g + 5]};
             }
         }
+        NB_STAMP(3);
     }
 };
 
@@ -370,10 +459,13 @@ struct PkCore {
 // at 8 (6) waves per SIMD the allocator spilled 10..64 VGPRs of the loop to scratch.
 // (TL = 4 stages 32 KiB of LDS per workgroup: at most 5 workgroups per CU, so the target is 4.)
 #define NB_PK_WAVES(NG, TL) 4
+// the small-system shapes (one group, 1024-body stages) also hold a prefetched vel/acc pair and two
+// stage register sets: allow them the 168-VGPR budget of 3 waves per SIMD instead of spilling
+#define NB_PK_WAVES_MIN(NG, TL) ((NG) == 1 && (TL) == 4 ? 3 : 4)
 
 // K1, packed, j-tile in LDS.
 template <int NG, int LS, int TL>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NB_PK_WAVES(NG, TL), NB_PK_WAVES(NG, TL))))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NB_PK_WAVES_MIN(NG, TL), NB_PK_WAVES(NG, TL))))
 void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial, uint32_t n, uint32_t i_begin,
                  uint32_t i_count, float G, float eps2, uint32_t j_per_split, SplitWindow win)
 {
@@ -388,11 +480,12 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
     nb_f2 xi[NG], yi[NG], zi[NG], ax[NG], ay[NG], az[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        float4 b0 = float4{0, 0, 0, 0}, b1 = float4{0, 0, 0, 0};
+        // rows past the shard are clamped to its last row (their sums are never stored): no bounds
+        // branch, so the loads of all groups are in flight together
         const uint32_t il0 = bxi * IPB + (2 * g) * GROUPS + grp;
         const uint32_t il1 = il0 + GROUPS;
-        if (il0 < i_count) b0 = bodies[i_begin + il0];
-        if (il1 < i_count) b1 = bodies[i_begin + il1];
+        const float4 b0 = ld4(bodies + i_begin + (il0 < i_count ? il0 : i_count - 1));
+        const float4 b1 = ld4(bodies + i_begin + (il1 < i_count ? il1 : i_count - 1));
         xi[g] = nb_f2{b0.x, b1.x}; yi[g] = nb_f2{b0.y, b1.y}; zi[g] = nb_f2{b0.z, b1.z};
         ax[g] = nb_f2{0, 0}; ay[g] = nb_f2{0, 0}; az[g] = nb_f2{0, 0};
     }
@@ -421,7 +514,7 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
 // nbody3d.js:283 vs :257).  vel/acc are only touched by their own lane: in place.
 // Bit-identical to nb_force_pk<NG,LS,TL> with jsplit = 1 followed by nb_integrate.
 template <int NG, int LS, int TL>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NB_PK_WAVES(NG, TL), NB_PK_WAVES(NG, TL))))
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NB_PK_WAVES_MIN(NG, TL), NB_PK_WAVES(NG, TL))))
 void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bodies_out, float4* __restrict__ vel,
                    float4* __restrict__ acc, uint32_t n, float G, float eps2, float dt)
 {
@@ -429,6 +522,7 @@ void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bo
     constexpr int IPB = GROUPS * 2 * NG;
     constexpr int IPL = 2 * NG;
     constexpr bool PREFETCH = NG == 1;     // vel/acc of the storing lane loaded before the loop (short loops)
+    NB_STAMP(0);
     const uint32_t bxi = blockIdx.x;
     const int tid = threadIdx.x;
     const int grp = tid / LS;
@@ -437,19 +531,22 @@ void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bo
 
     nb_f2 xi[NG], yi[NG], zi[NG], ax[NG], ay[NG], az[NG];
     float4 v0[PREFETCH ? IPL : 1], a0[PREFETCH ? IPL : 1];
+    float w0[PREFETCH ? IPL : 1];           // .w of the lane's bodies (integrated like xyz, :283)
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        float4 b0 = float4{0, 0, 0, 0}, b1 = float4{0, 0, 0, 0};
+        // rows past n are clamped to the last row (never stored): branch-free, all loads in flight
+        // together; every lane of a group loads the same rows (one request per group)
         const uint32_t il0 = bxi * IPB + (2 * g) * GROUPS + grp;
         const uint32_t il1 = il0 + GROUPS;
-        if (il0 < n) b0 = bodies_in[il0];
-        if (il1 < n) b1 = bodies_in[il1];
+        const uint32_t c0 = il0 < n ? il0 : n - 1, c1 = il1 < n ? il1 : n - 1;
+        const float4 b0 = ld4(bodies_in + c0);
+        const float4 b1 = ld4(bodies_in + c1);
         xi[g] = nb_f2{b0.x, b1.x}; yi[g] = nb_f2{b0.y, b1.y}; zi[g] = nb_f2{b0.z, b1.z};
         ax[g] = nb_f2{0, 0}; ay[g] = nb_f2{0, 0}; az[g] = nb_f2{0, 0};
         if constexpr (PREFETCH) {
-            v0[2 * g] = v0[2 * g + 1] = a0[2 * g] = a0[2 * g + 1] = float4{0, 0, 0, 0};
-            if (owner && il0 < n) { v0[2 * g] = vel[il0]; a0[2 * g] = acc[il0]; }
-            if (owner && il1 < n) { v0[2 * g + 1] = vel[il1]; a0[2 * g + 1] = acc[il1]; }
+            w0[2 * g] = b0.w; w0[2 * g + 1] = b1.w;
+            v0[2 * g] = ld4(vel + c0); a0[2 * g] = ld4(acc + c0);
+            v0[2 * g + 1] = ld4(vel + c1); a0[2 * g + 1] = ld4(acc + c1);
         }
     }
     PkCore<NG, LS, TL>::run(bodies_in, 0, n, G, eps2, xi, yi, zi, ax, ay, az);
@@ -460,9 +557,11 @@ void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bo
             const int g = k / 2;
             const uint32_t il = bxi * IPB + k * GROUPS + grp;
             if (il < n) {
-                float4 v, ao;
-                if constexpr (PREFETCH) { v = v0[k]; ao = a0[k]; } else { v = vel[il]; ao = acc[il]; }
-                const float4 x = bodies_in[il];      // all four components: .w is integrated like xyz (:283)
+                float4 v, ao, x;                     // x with all four components: .w is integrated like xyz (:283)
+                if constexpr (PREFETCH) {
+                    v = v0[k]; ao = a0[k];
+                    x = (k & 1) ? float4{xi[g].y, yi[g].y, zi[g].y, w0[k]} : float4{xi[g].x, yi[g].x, zi[g].x, w0[k]};
+                } else { v = ld4(vel + il); ao = ld4(acc + il); x = ld4(bodies_in + il); }
                 float4 nx, nv, na;
                 if (k & 1) leapfrog<float>(x, v, ao, ax[g].y, ay[g].y, az[g].y, dt, nx, nv, na);
                 else leapfrog<float>(x, v, ao, ax[g].x, ay[g].x, az[g].x, dt, nx, nv, na);
@@ -472,6 +571,7 @@ void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bo
             }
         }
     }
+    NB_STAMP(4);
 }
 
 // K1, packed form with the j-bodies broadcast from SGPRs instead of LDS (SURVEY.md §8 f3
@@ -504,11 +604,10 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
     nb_f2 xi[NG], yi[NG], zi[NG], ax[NG], ay[NG], az[NG];
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        float4 b0 = float4{0, 0, 0, 0}, b1 = float4{0, 0, 0, 0};
         const uint32_t il0 = bxi * IPB + (2 * g) * LANES + lane;
         const uint32_t il1 = il0 + LANES;
-        if (il0 < i_count) b0 = bodies[i_begin + il0];
-        if (il1 < i_count) b1 = bodies[i_begin + il1];
+        const float4 b0 = ld4(bodies + i_begin + (il0 < i_count ? il0 : i_count - 1));   // clamped, branch-free
+        const float4 b1 = ld4(bodies + i_begin + (il1 < i_count ? il1 : i_count - 1));
         xi[g] = nb_f2{b0.x, b1.x}; yi[g] = nb_f2{b0.y, b1.y}; zi[g] = nb_f2{b0.z, b1.z};
         ax[g] = nb_f2{0, 0}; ay[g] = nb_f2{0, 0}; az[g] = nb_f2{0, 0};
     }
@@ -666,17 +765,17 @@ __global__ __launch_bounds__(kBlock) void nb_integrate(typename vec4<T>::type* _
         uint32_t sp = r;
         // 4 independent loads per trip, summed in ascending split order
         for (; sp + 3 * R < jsplit; sp += 4 * R) {
-            const V4 p0 = partial[(size_t)sp * i_count + il];
-            const V4 p1 = partial[(size_t)(sp + R) * i_count + il];
-            const V4 p2 = partial[(size_t)(sp + 2 * R) * i_count + il];
-            const V4 p3 = partial[(size_t)(sp + 3 * R) * i_count + il];
+            const V4 p0 = ld4(partial + (size_t)sp * i_count + il);
+            const V4 p1 = ld4(partial + (size_t)(sp + R) * i_count + il);
+            const V4 p2 = ld4(partial + (size_t)(sp + 2 * R) * i_count + il);
+            const V4 p3 = ld4(partial + (size_t)(sp + 3 * R) * i_count + il);
             sx += p0.x; sy += p0.y; sz += p0.z;
             sx += p1.x; sy += p1.y; sz += p1.z;
             sx += p2.x; sy += p2.y; sz += p2.z;
             sx += p3.x; sy += p3.y; sz += p3.z;
         }
         for (; sp < jsplit; sp += R) {
-            const V4 p = partial[(size_t)sp * i_count + il];
+            const V4 p = ld4(partial + (size_t)sp * i_count + il);
             sx += p.x; sy += p.y; sz += p.z;
         }
     }
@@ -690,7 +789,7 @@ __global__ __launch_bounds__(kBlock) void nb_integrate(typename vec4<T>::type* _
     }
     if (!valid || r != 0) return;
     V4 nx, nv, na;
-    leapfrog<T>(bodies[i_begin + il], vel[il], acc[il], sx, sy, sz, dt, nx, nv, na);
+    leapfrog<T>(ld4(bodies + i_begin + il), ld4(vel + il), ld4(acc + il), sx, sy, sz, dt, nx, nv, na);
     vel[il] = nv;                                                       // :281
     bodies[i_begin + il] = nx;                                          // :283
     acc[il] = na;                                                       // :290
@@ -709,9 +808,9 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_swap(typename vec4<T>::ty
     using V4 = typename vec4<T>::type;
     const uint32_t il = blockIdx.x * kBlock + threadIdx.x;
     if (il >= i_count) return;
-    const V4 a = anew[il];
+    const V4 a = ld4(anew + il);
     V4 nx, nv, na;
-    leapfrog<T>(bodies[i_begin + il], vel[il], aold[il], a.x, a.y, a.z, dt, nx, nv, na);
+    leapfrog<T>(ld4(bodies + i_begin + il), ld4(vel + il), ld4(aold + il), a.x, a.y, a.z, dt, nx, nv, na);
     vel[il] = nv;
     bodies[i_begin + il] = nx;
 }

@@ -9,6 +9,8 @@ if [ "$what" = tests ] || [ "$what" = all ]; then
   tail -25 gpurun_out/pytest_gpu.txt
 fi
 if [ "$what" = scan ] || [ "$what" = all ]; then
+  step ubench4 120 tools/ubench4
+  cut -c1-210 gpurun_out/ubench4.txt
   step shape_scan 900 python tools/shape_scan.py 1024 2048 4096 8192 16384 40002 65536
   grep -A6 "== N=" gpurun_out/shape_scan.txt | cut -c1-150
 fi

@@ -39,7 +39,7 @@ def candidates(n):
                 for js in (1, 2, 4, 8, 16, 32, 64):
                     ipb = (256 // ws) * ipl
                     wgs = -(-n // ipb) * js
-                    if wgs < 512 or wgs > 8192 or n / js / ws < 512:
+                    if wgs < 512 or wgs > 8192 or n / js / ws < 256:
                         continue
                     out.append(("sgpr_ipl%d_ws%d_js%d" % (ipl, ws, js), dict(force_variant=300000 + ipl * 1000 + 10 + ws, jsplit=js)))
     return out
