@@ -13,6 +13,8 @@
 #include "nb_internal.h"
 #include "nb_kernels.hip.h"
 
+#include <hip/hip_ext.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -232,6 +234,8 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         }
     }
     if (!pinned || js == 0) {
+        struct Scored { Shape sh; uint32_t q; double t; };
+        std::vector<Scored> scored;
         double best_t = 1e300;
         for (const Cand& c : cands) {
             if (pinned && !(c.sh.kind == sh.kind && c.sh.ipl == sh.ipl && c.sh.ls == sh.ls && c.sh.x == sh.x)) continue;
@@ -278,9 +282,20 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 // balance gain is a wash (N = 262,144: 8 vs 16 splits), the smaller HBM footprint wins
                 const double after = c.sh.kind == kFused ? 0.0 : (double)used * sc * 4 * s->esz / 2.0e12 + 3e-6;
                 const double t = std::max(cyc / kClock, stream_s) / (1.0 - 0.03 / rounds) + after;
-                if (t < best_t) { best_t = t; if (!pinned) sh = c.sh; js = q; }
+                scored.push_back({c.sh, q, t});
+                if (t < best_t) best_t = t;
             }
         }
+        // Among the shapes within 0.4 % of the best estimate take the one with the FEWEST j-splits:
+        // measured at N = 262,144, 8 / 16 / 32 splits differ by 0.1-0.3 % in step time
+        // (profiles/r02/sweep_jsplit_n262144.txt) while every split is another partial array
+        // written by K1 and read back by K2.
+        const Scored* pick = nullptr;
+        for (const Scored& c : scored) {
+            if (c.t > best_t * 1.004) continue;
+            if (!pick || c.q < pick->q || (c.q == pick->q && c.t < pick->t)) pick = &c;
+        }
+        if (pick) { if (!pinned) sh = pick->sh; js = pick->q; }
     }
     if (js < 1) {   // pinned shape outside the model's candidate list: fill ~4096 workgroups
         js = ceil_div((uint32_t)n_cu * 16, ceil_div(sc, ipb_of(sh)));
@@ -318,8 +333,16 @@ Shape shape_of(const nb_sim* s)
 
 // part: 0 = all splits, 1 = only the splits inside this shard's own rows,
 //       2 = all the others
+// t0/t1 (optional): events stamped at the kernel's begin / end (hipExtLaunchKernel)
+void launch_kernel(const void* fn, dim3 grid, dim3 block, void** args, hipStream_t stream, hipEvent_t t0, hipEvent_t t1)
+{
+    // error picked up by hipGetLastError in nb_step
+    if (t0 || t1) (void)hipExtLaunchKernel(fn, grid, block, args, 0, stream, t0, t1, 0);
+    else (void)hipLaunchKernel(fn, grid, block, args, 0, stream);
+}
+
 template <typename T>
-void launch_force(nb_sim* s, int part = 0)
+void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr)
 {
     using V4 = typename nb::vec4<T>::type;
     const Shape sh = shape_of(s);
@@ -334,11 +357,11 @@ void launch_force(nb_sim* s, int part = 0)
     T G = (T)s->G, e2 = (T)s->eps2;
     uint32_t n = s->n, sb = s->sb, sc = s->sc, jps = s->j_per_split;
     void* args[] = {&b, &p, &n, &sb, &sc, &G, &e2, &jps, &win};
-    (void)hipLaunchKernel(kernel_of(s->f64, sh), grid, block, args, 0, s->stream);   // error picked up by hipGetLastError
+    launch_kernel(kernel_of(s->f64, sh), grid, block, args, s->stream, t0, t1);
 }
 
 // The fused one-launch step: reads bodies[cur], writes bodies[cur ^ 1], then the roles flip.
-void launch_fused(nb_sim* s)
+void launch_fused(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr)
 {
     const Shape sh = shape_of(s);
     dim3 grid(ceil_div(s->n, ipb_of(sh))), block(nb::kBlock);
@@ -348,32 +371,34 @@ void launch_fused(nb_sim* s)
     uint32_t n = s->n;
     float G = (float)s->G, e2 = (float)s->eps2, dt = (float)s->dt;
     void* args[] = {&bin, &bout, &v, &a, &n, &G, &e2, &dt};
-    (void)hipLaunchKernel(kernel_of(false, sh), grid, block, args, 0, s->stream);
+    launch_kernel(kernel_of(false, sh), grid, block, args, s->stream, t0, t1);
     s->cur ^= 1;
 }
 
 template <typename T>
-void launch_integrate(nb_sim* s)
+void launch_integrate(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr)
 {
     using V4 = typename nb::vec4<T>::type;
+    V4 *b = (V4*)s->bodies[s->cur], *v = (V4*)s->vel;
+    uint32_t sb = s->sb, sc = s->sc, js = s->jsplit;
+    T dt = (T)s->dt;
     if (s->swap_acc) {
         // jsplit == 1: the single partial array IS a_new; K2 reads it beside a_old and the two
         // buffers swap roles (no 16-B store of a per body: 96 B per body in all)
-        dim3 grid(ceil_div(s->sc, nb::kBlock)), block(nb::kBlock);
-        hipLaunchKernelGGL((nb::nb_integrate_swap<T>), grid, block, 0, s->stream, (V4*)s->bodies[s->cur], (V4*)s->vel,
-                           (const V4*)s->acc, (const V4*)s->partial, s->sb, s->sc, (T)s->dt);
+        const V4 *ao = (const V4*)s->acc, *an = (const V4*)s->partial;
+        void* args[] = {&b, &v, &ao, &an, &sb, &sc, &dt};
+        launch_kernel((const void*)&nb::nb_integrate_swap<T>, dim3(ceil_div(sc, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
         std::swap(s->acc, s->partial);
         s->acc_parity ^= 1;
         return;
     }
     // lanes per body: enough to keep ~8 partial loads per lane at most
-    const int R = s->jsplit >= 32 ? 8 : s->jsplit >= 8 ? 4 : 1;
-    dim3 grid(ceil_div(s->sc * (uint32_t)R, nb::kBlock)), block(nb::kBlock);
-#define NB_K2(RR)                                                                                                   \
-    hipLaunchKernelGGL((nb::nb_integrate<T, RR>), grid, block, 0, s->stream, (V4*)s->bodies[s->cur], (V4*)s->vel,   \
-                       (V4*)s->acc, (const V4*)s->partial, s->sb, s->sc, s->jsplit, (T)s->dt)
-    if (R == 8) NB_K2(8); else if (R == 4) NB_K2(4); else NB_K2(1);
-#undef NB_K2
+    const int R = js >= 32 ? 8 : js >= 8 ? 4 : 1;
+    V4* a = (V4*)s->acc;
+    const V4* p = (const V4*)s->partial;
+    void* args[] = {&b, &v, &a, &p, &sb, &sc, &js, &dt};
+    const void* fn = R == 8 ? (const void*)&nb::nb_integrate<T, 8> : R == 4 ? (const void*)&nb::nb_integrate<T, 4> : (const void*)&nb::nb_integrate<T, 1>;
+    launch_kernel(fn, dim3(ceil_div(sc * (uint32_t)R, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
 }
 
 void launch_step(nb_sim* s)
@@ -384,34 +409,40 @@ void launch_step(nb_sim* s)
 }
 
 constexpr uint32_t kGraphChunk = 16;   // even: buffer roles (ping-pong, acc swap) are back where they started
+constexpr uint32_t kGraphBig = 128;
+constexpr uint32_t kGraphSteps[2] = {kGraphChunk, kGraphBig};
 
 void drop_graph(nb_sim* s)
 {
-    if (s->graph_exec) { (void)hipGraphExecDestroy(s->graph_exec); s->graph_exec = nullptr; }
-    if (s->graph) { (void)hipGraphDestroy(s->graph); s->graph = nullptr; }
+    for (auto& g : s->graphs) {
+        if (g.exec) { (void)hipGraphExecDestroy(g.exec); g.exec = nullptr; }
+        if (g.graph) { (void)hipGraphDestroy(g.graph); g.graph = nullptr; }
+    }
 }
 
 // buffer-role parity a captured graph is valid for
 int role_parity(const nb_sim* s) { return s->cur | (s->acc_parity << 1); }
 
-// Captures kGraphChunk steps on the engine's own stream.  Returns false (and disables graphs
+// Captures kGraphSteps[which] steps on the engine's own stream.  Returns false (and disables graphs
 // for the handle) if anything goes wrong; the caller then issues plain launches -- same
 // kernels, same results.
-bool ensure_graph(nb_sim* s)
+bool ensure_graph(nb_sim* s, int which)
 {
-    if (s->graph_exec && s->graph_dt == s->dt && s->graph_G == s->G && s->graph_cur == role_parity(s)) return true;
-    drop_graph(s);
+    auto& slot = s->graphs[which];
+    if (slot.exec && slot.dt == s->dt && slot.G == s->G && slot.parity == role_parity(s)) return true;
+    if (slot.exec) { (void)hipGraphExecDestroy(slot.exec); slot.exec = nullptr; }
+    if (slot.graph) { (void)hipGraphDestroy(slot.graph); slot.graph = nullptr; }
     void *acc0 = s->acc, *par0 = s->partial;
     const int cur0 = s->cur, par_bit0 = s->acc_parity;
     if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { s->graphs_ok = false; return false; }
-    for (uint32_t k = 0; k < kGraphChunk; ++k) launch_step(s);
+    for (uint32_t k = 0; k < kGraphSteps[which]; ++k) launch_step(s);
     hipGraph_t g = nullptr;
     const bool ok = hipStreamEndCapture(s->stream, &g) == hipSuccess && g;
     s->acc = acc0; s->partial = par0; s->cur = cur0; s->acc_parity = par_bit0;   // an even number of role flips: explicit for clarity
     if (!ok) { (void)hipGetLastError(); s->graphs_ok = false; return false; }
     hipGraphExec_t ge = nullptr;
     if (hipGraphInstantiate(&ge, g, nullptr, nullptr, 0) != hipSuccess) { (void)hipGraphDestroy(g); (void)hipGetLastError(); s->graphs_ok = false; return false; }
-    s->graph = g; s->graph_exec = ge; s->graph_dt = s->dt; s->graph_G = s->G; s->graph_cur = role_parity(s);
+    slot.graph = g; slot.exec = ge; slot.dt = s->dt; slot.G = s->G; slot.parity = role_parity(s);
     return true;
 }
 
@@ -612,34 +643,35 @@ int nb_step(nb_sim* s, uint32_t nsteps)
     // Multi-step calls on the engine's own stream replay a captured graph of
     // kGraphChunk steps (no exchange, no per-kernel timing requested).
     if (s->own_stream && s->graphs_ok && !exchange && !s->timing && nsteps >= kGraphChunk) {
-        while (nsteps >= kGraphChunk && ensure_graph(s)) {
-            NB_HIP(s, hipGraphLaunch(s->graph_exec, s->stream));
-            nsteps -= kGraphChunk;
-            s->steps_done += kGraphChunk;
+        for (int which = 1; which >= 0; --which) {
+            while (nsteps >= kGraphSteps[which] && ensure_graph(s, which)) {
+                NB_HIP(s, hipGraphLaunch(s->graphs[which].exec, s->stream));
+                nsteps -= kGraphSteps[which];
+                s->steps_done += kGraphSteps[which];
+            }
         }
     }
     for (uint32_t k = 0; k < nsteps; ++k) {
         nb_events ev;
         const bool rec = s->timing && get_events(s, &ev) == 0;
-        if (rec) NB_HIP(s, hipEventRecord(ev.e[0], s->stream));
+        hipEvent_t* e = rec ? ev.e : nullptr;
         if (s->fused) {
-            launch_fused(s);
-            if (rec) { NB_HIP(s, hipEventRecord(ev.e[1], s->stream)); NB_HIP(s, hipEventRecord(ev.e[2], s->stream)); }
+            launch_fused(s, e ? e[0] : nullptr, e ? e[1] : nullptr);
         } else {
             if (s->gather_pending) {
                 // the previous step's all-gather is still in flight: own-row splits first
-                if (s->f64) launch_force<double>(s, 1); else launch_force<float>(s, 1);
-                if (rec) NB_HIP(s, hipEventRecord(ev.e[1], s->stream));
+                if (s->f64) launch_force<double>(s, 1, e ? e[0] : nullptr, e ? e[1] : nullptr);
+                else launch_force<float>(s, 1, e ? e[0] : nullptr, e ? e[1] : nullptr);
                 if (int rc = finish_gather(s)) return rc;
-                if (rec) NB_HIP(s, hipEventRecord(ev.e[3], s->stream));
-                if (s->f64) launch_force<double>(s, 2); else launch_force<float>(s, 2);
-                if (rec) { NB_HIP(s, hipEventRecord(ev.e[4], s->stream)); ev.two = true; }
+                if (s->f64) launch_force<double>(s, 2, e ? e[3] : nullptr, e ? e[4] : nullptr);
+                else launch_force<float>(s, 2, e ? e[3] : nullptr, e ? e[4] : nullptr);
+                if (rec) ev.two = s->own_splits > 0 && s->own_splits < s->jsplit;
             } else {
-                if (s->f64) launch_force<double>(s); else launch_force<float>(s);
-                if (rec) NB_HIP(s, hipEventRecord(ev.e[1], s->stream));
+                if (s->f64) launch_force<double>(s, 0, e ? e[0] : nullptr, e ? e[1] : nullptr);
+                else launch_force<float>(s, 0, e ? e[0] : nullptr, e ? e[1] : nullptr);
             }
-            if (s->f64) launch_integrate<double>(s); else launch_integrate<float>(s);
-            if (rec) NB_HIP(s, hipEventRecord(ev.e[2], s->stream));
+            if (s->f64) launch_integrate<double>(s, e ? e[6] : nullptr, e ? e[2] : nullptr);
+            else launch_integrate<float>(s, e ? e[6] : nullptr, e ? e[2] : nullptr);
         }
         NB_HIP(s, hipGetLastError());
         ++s->steps_done;
@@ -740,12 +772,8 @@ int nb_step_times(nb_sim* s, double* force_ms, double* integrate_ms, double* exc
     for (auto& ev : s->pending) {
         float a = 0, b = 0, c = 0, d = 0;
         NB_HIP(s, hipEventElapsedTime(&a, ev.e[0], ev.e[1]));
-        if (ev.two) {   // own-row splits, [gather wait], remaining splits
-            NB_HIP(s, hipEventElapsedTime(&c, ev.e[3], ev.e[4]));
-            NB_HIP(s, hipEventElapsedTime(&b, ev.e[4], ev.e[2]));
-        } else {
-            NB_HIP(s, hipEventElapsedTime(&b, ev.e[1], ev.e[2]));
-        }
+        if (ev.two) NB_HIP(s, hipEventElapsedTime(&c, ev.e[3], ev.e[4]));   // own-row splits, [gather wait], remaining splits
+        if (!s->fused) NB_HIP(s, hipEventElapsedTime(&b, ev.e[6], ev.e[2]));
         if (ev.xchg) { NB_HIP(s, hipEventElapsedTime(&d, ev.e[2], ev.e[5])); ++nx; }
         f += a + c; g += b; x += d;
     }

@@ -10,10 +10,12 @@
 #include <string>
 #include <vector>
 
-// e[0]..e[1]: force launch(es) issued before a pending gather is waited for (or the only
-// force launch, or the whole fused step); e[3]..e[4]: force launch issued after it;
-// e[1]/e[4]..e[2]: integrate; e[2]..e[5]: position exchange (RCCL all-gather on the engine stream).
-struct nb_events { hipEvent_t e[6]; bool two, xchg; };
+// Kernel-exact timing: the events are handed to hipExtLaunchKernel, which stamps them at the
+// kernel's own begin and end (no marker packets between the kernels of a step).
+// e[0]..e[1]: force launch issued before a pending gather is waited for (or the only force
+// launch, or the whole fused step); e[3]..e[4]: force launch issued after it; e[6]..e[2]: integrate;
+// e[2]..e[5]: position exchange (RCCL all-gather on the engine stream; e[5] is a plain record).
+struct nb_events { hipEvent_t e[7]; bool two, xchg; };
 
 struct nb_rccl;   // nb_comm.hip
 
@@ -71,10 +73,13 @@ struct nb_sim {
     bool timing = false;
     // HIP-graph replay of multi-step calls (launch-bound small N): kGraphChunk steps captured
     // once per (dt, G, buffer parity) and replayed
-    hipGraph_t graph = nullptr;
-    hipGraphExec_t graph_exec = nullptr;
-    double graph_dt = 0.0, graph_G = 0.0;
-    int graph_cur = 0;
+    struct graph_slot {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        double dt = 0.0, G = 0.0;
+        int parity = 0;
+    } graphs[2];                     // [0]: kGraphChunk steps, [1]: kGraphBig steps (a replay costs the host
+                                     // ~10-16 us: amortised over 128 steps it stops showing at N ~ 1,024)
     bool graphs_ok = true;           // cleared if capture ever fails: fall back to plain launches
     std::vector<nb_events> pool;     // recycled events
     std::vector<nb_events> pending;

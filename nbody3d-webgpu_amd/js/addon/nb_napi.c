@@ -199,7 +199,7 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     get_u32_prop(env, argv[0], "collective", &collective);   /* 0 peer copies, 1 RCCL (nb_multi_collective) */
     nb_sim *sim = NULL;
     nb_multi *multi = NULL;
-    if (shards > 1) {   /* single-process multi-device: shards round-robin over the visible GPUs */
+    if (shards > 1 || (shards == 1 && collective)) {   /* single-process multi-device: shards round-robin over the visible GPUs */
         cfg.device = -1; cfg.shard_begin = cfg.shard_count = 0;
         int rc = p_multi_create(&cfg, shards, NULL, &multi);
         if (rc != NB_OK) return throw_msg(env, rc, p_multi_last_error(NULL), "nb_multi_create");

@@ -17,12 +17,13 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "nbody3d-webgpu_amd"))
 
 from nbody3d_amd import ic  # noqa: E402
-from nbody3d_amd.shard import ShardPlan, torch_allgather_hook  # noqa: E402
+from nbody3d_amd.shard import ShardPlan, torch_allgather_hook, torch_allgather_overlapped_hooks  # noqa: E402
 from oracle import oracle  # noqa: E402
 
 
 def main():
     out, n, steps = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    overlapped = len(sys.argv) > 4 and sys.argv[4] == "overlapped"
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     plan = ShardPlan(n, world, rank)
@@ -30,7 +31,16 @@ def main():
     bodies = torch.from_numpy(plan.pad(b).copy())           # the replicated array
     vel = plan.pad(v).copy()
     acc = np.zeros_like(vel)
-    hook = torch_allgather_hook(bodies, plan)
+    if overlapped:
+        # the two-phase hooks: begin() starts the IN-PLACE all-gather (input = this rank's rows of the
+        # replicated array, never written by the collective), wait() completes it
+        begin, wait = torch_allgather_overlapped_hooks(bodies, plan)
+
+        def hook(*a):
+            rc = begin(*a)
+            return rc or wait(0)
+    else:
+        hook = torch_allgather_hook(bodies, plan)
     G, dt = 1.0, 1e-3
     bnp = bodies.numpy()                                    # shares storage with the tensor
     for _ in range(steps):

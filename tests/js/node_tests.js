@@ -98,6 +98,36 @@ if (mode === 'cpu') {
   check('multi_diagnostics_match_single', Math.abs(dm.kinetic - d.kinetic) < 1e-3 * Math.abs(d.kinetic) && dm.potential < 0, dm);
   check('multi_has_no_kernel_timing', throws(function () { sm.kernelTimes(); }, /not available/));
   sm.destroy();
+  // the same handle in RCCL mode (ncclCommInitAll + grouped in-place ncclAllGather, SURVEY.md §8(e)):
+  // one shard on the one GPU of a test box -- RCCL refuses two ranks on one device
+  const sr = new nb.Simulation({ G: m.G, dt: m.dt, shards: 1, collective: 'rccl' }).init([b0, v0]);
+  const ci = sr.collectiveInfo();
+  check('multi_rccl_mode_info', ci.mode === 'rccl' && ci.nranks === 1 && ci.rcclVersion > 20000, ci);
+  sr.simulate(100);
+  const er = relPosErr(sr.read().bodies, loadF64('plummer1024_s100_bodies'), m.r_scale);
+  check('gpu_multi_rccl_handle_vs_f64_oracle', er < 2e-5, { err: er, variant: sr.variant() });
+  sr.destroy();
+  check('multi_rccl_refuses_shared_device', nb.deviceCount() >= 2 ||
+    throws(function () { new nb.Simulation({ shards: 2, collective: 'rccl' }).init([b0, v0]); }, /own device/));
+  // viewer frame feed (nbody3d.js:408-415,482-487; colour input :380): snapshot == read() of that step,
+  // later steps do not disturb it
+  const sf = new nb.Simulation({ G: m.G, dt: m.dt }).init([b0, v0]);
+  sf.simulate(7);
+  const at7 = sf.read();
+  sf.requestFrame();
+  sf.simulate(5);
+  const fr = sf.frame(true);
+  let speedOk = fr !== null && fr.step === 7 && bitsEqual(fr.bodies, at7.bodies);
+  for (let i = 0; speedOk && i < 1024; i += 37) {
+    const vx = at7.vel[4 * i], vy = at7.vel[4 * i + 1], vz = at7.vel[4 * i + 2];
+    const want = Math.sqrt(Math.fround(Math.fround(Math.fround(vx * vx) + Math.fround(vy * vy)) + Math.fround(vz * vz)));
+    speedOk = Math.abs(fr.speed[i] - want) <= 4e-7 * Math.max(want, 1e-30);
+  }
+  check('frame_feed_equals_read', speedOk, fr ? { step: fr.step } : null);
+  check('frame_before_request_throws', throws(function () { new nb.Simulation({}).init([b0, v0]).frame(false); }, /nb_frame_request has not been called/));
+  const st = sf.enableTiming(true).simulate(3).stepTimes();
+  check('step_times', st.launches === 3 && st.forceMs > 0 && st.exchangeMs === 0, st);
+  sf.destroy();
   // f64 simulation takes Float64Array
   const s64 = new nb.Simulation({ f64: true, G: m.G, dt: m.dt }).init([Float64Array.from(b0), Float64Array.from(v0)]);
   s64.simulate(100);

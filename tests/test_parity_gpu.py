@@ -110,8 +110,9 @@ def test_intermediate_checkpoints_and_restore(manifest):
 
 
 def test_graph_replay_equals_single_steps():
-    """nb_step(k >= 16) replays a captured HIP graph of 16 [force, integrate]
-    pairs; it must be bit-identical to k single-step calls, and follow dt/G
+    """nb_step(k >= 16) replays captured HIP graphs (16 and 128 steps; fused one-launch steps
+    ping-pong the position buffers, so a graph is only valid for the buffer parity it was
+    captured at); it must be bit-identical to k single-step calls, and follow dt/G
     changes between calls (the graph bakes them in and is re-captured)."""
     b, v = ic.plummer(1024, seed=18)
     with Simulation(1024) as a, Simulation(1024) as c:
@@ -123,6 +124,9 @@ def test_graph_replay_equals_single_steps():
         a.simulate(35, 5e-4, 0.5)          # new params: re-capture
         for _ in range(35):
             c.step(5e-4, 0.5)
+        a.simulate(300)                    # 2 x 128-step graph + 2 x 16-step graph + 12 plain, odd parity start
+        for _ in range(300):
+            c.step()
         ra, rc = a.read(), c.read()
     for x, y in zip(ra, rc):
         assert x.tobytes() == y.tobytes()

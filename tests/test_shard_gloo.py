@@ -39,13 +39,16 @@ def test_shard_plan_partitions_and_pads():
         ShardPlan(10, 2, 2)
 
 
-@pytest.mark.parametrize("n,world", [(1024, 2), (1000, 2), (1536, 3)])
-def test_sharded_steps_equal_unsharded_oracle(tmp_path, n, world):
+@pytest.mark.parametrize("n,world,mode", [(1024, 2, "plain"), (1000, 2, "plain"), (1536, 3, "plain"), (1000, 2, "overlapped"),
+                                           (1536, 3, "overlapped")])
+def test_sharded_steps_equal_unsharded_oracle(tmp_path, n, world, mode):
+    """mode 'overlapped' drives the two-phase hooks, whose all-gather is in place (the input is a
+    view of the rank's own rows inside the output tensor)."""
     steps = 4
     out = str(tmp_path / "result.npz")
     env = dict(os.environ, OMP_NUM_THREADS="2")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), WORKER, out, str(n), str(steps)]
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), WORKER, out, str(n), str(steps), mode]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     got = np.load(out)

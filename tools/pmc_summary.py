@@ -11,8 +11,9 @@ import os
 import sys
 
 src, dst, n, dtype = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+variant = sys.argv[5] if len(sys.argv) > 5 else None      # nb_variant_name() of the profiled run (bench.py keys on it)
 os.makedirs(dst, exist_ok=True)
-out = {"source": src, "n": n, "dtype": dtype, "kernels": {}}
+out = {"source": src, "n": n, "dtype": dtype, "kernel_variant": variant, "kernels": {}}
 
 
 def short(name):
@@ -53,11 +54,12 @@ for k, d in out["kernels"].items():
     if "FETCH_SIZE" in pm or "WRITE_SIZE" in pm:
         d["hbm_bytes_per_launch"] = {"read": 2 * 1024 * pm.get("FETCH_SIZE", 0), "written": 1024 * pm.get("WRITE_SIZE", 0)}
 json.dump(out, open(os.path.join(dst, "summary.json"), "w"), indent=1)
-k1 = [k for k in out["kernels"] if "nb_force" in k]
-if k1 and "hbm_bytes_per_launch" in out["kernels"][k1[0]]:
+k1 = [k for k in out["kernels"] if "nb_force" in k or "nb_step_fused" in k]
+if k1 and "hbm_bytes_per_launch" in out["kernels"][k1[0]] and len(sys.argv) > 6 and sys.argv[6] == "--write-traffic":
     h = out["kernels"][k1[0]]["hbm_bytes_per_launch"]
-    json.dump({"n": n, "n_gpus": 1, "dtype": dtype, "kernel": k1[0], "bytes_per_launch": h["read"] + h["written"],
-               "read": h["read"], "written": h["written"],
-               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 on gfx950"},
-              open(os.path.join(os.path.dirname(dst.rstrip('/')), "..", "k1_hbm_traffic.json") if False else "profiles/k1_hbm_traffic.json", "w"), indent=1)
+    json.dump({"n": n, "n_gpus": 1, "dtype": dtype, "kernel": k1[0], "kernel_variant": variant, "source": dst,
+               "bytes_per_launch": h["read"] + h["written"], "read": h["read"], "written": h["written"],
+               "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes; KiB units; FETCH_SIZE x2 on gfx950 "
+                         "(MI355X_MICROARCH.md 'HBM')"},
+              open("profiles/k1_hbm_traffic.json", "w"), indent=1)
 print(json.dumps(out, indent=1)[:3000])
