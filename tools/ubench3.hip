@@ -117,6 +117,62 @@ __global__ __launch_bounds__(256) void kmf(const float* seed, float* out, unsign
 }
 
 // ------------------------------------------------------------------------------------------
+// (1b) the same question across waves: a 512-thread workgroup puts two waves on every SIMD.
+//   MIX 0: both run today's all-VALU body;  MIX 1: both run 8 x v_mfma_f32_16x16x4_f32 per iteration;
+//   MIX 2: waves 0-3 (one per SIMD) run the VALU body, waves 4-7 the MFMAs.
+// Separate pipes would finish MIX 2 in ~max(MIX 0, MIX 1)/2; one shared datapath in ~their mean.
+template <int MIX>
+__global__ __launch_bounds__(512) void kco(const float* seed, float* out, unsigned long long* stamps, int iters)
+{
+    const float s = seed[threadIdx.x & 63];
+    const bool mfma_role = MIX == 1 || (MIX == 2 && (threadIdx.x >> 6) >= 4);
+    f2 xi[4], yi[4], zi[4], ax[4], ay[4], az[4];
+    f4 acc4[8];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        xi[g] = f2{s + g, s - g}; yi[g] = f2{s * 2 + g, s * 3 - g}; zi[g] = f2{s * 5 + g, s * 7 - g};
+        ax[g] = ay[g] = az[g] = f2{0, 0};
+    }
+#pragma unroll
+    for (int g = 0; g < 8; ++g) acc4[g] = f4{0, 0, 0, 0};
+    const f2 e2 = f2{1e-4f, 1e-4f};
+    float bx = s * 0.3f, by = s * 0.7f, bz = s * 0.11f, bm = 1.f + s, bq = s * 0.01f;
+    unsigned long long t0, t1, r0, r1;
+    STAMP0
+    if (mfma_role) {      // wave-uniform branch
+        for (int it = 0; it < iters; ++it) {
+            bx += 1e-3f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc4[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(bx, bq, acc4[q], 0, 0, 0);
+        }
+    } else {
+        for (int it = 0; it < iters; ++it) {
+            bx += 1e-3f; by -= 1e-3f; bz += 2e-3f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const f2 dx = f2{bx, bx} - xi[g], dy = f2{by, by} - yi[g], dz = f2{bz, bz} - zi[g];
+                const f2 d2 = __builtin_elementwise_fma(dz, dz, __builtin_elementwise_fma(dy, dy, __builtin_elementwise_fma(dx, dx, e2)));
+                const f2 d6 = d2 * d2 * d2;
+                const f2 r = f2{__builtin_amdgcn_rsqf(d6.x), __builtin_amdgcn_rsqf(d6.y)};
+                const f2 sm = f2{bm, bm} * r;
+                ax[g] = __builtin_elementwise_fma(sm, dx, ax[g]);
+                ay[g] = __builtin_elementwise_fma(sm, dy, ay[g]);
+                az[g] = __builtin_elementwise_fma(sm, dz, az[g]);
+            }
+        }
+    }
+    STAMP1
+    float v = 0;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v += ax[g].x + ax[g].y + ay[g].x + ay[g].y + az[g].x + az[g].y;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) v += acc4[g].x + acc4[g].y + acc4[g].z + acc4[g].w;
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+    out[gid] = v;
+    if ((threadIdx.x & 63) == 0) { stamps[2 * (gid >> 6)] = t1 - t0; stamps[2 * (gid >> 6) + 1] = r1 - r0; }
+}
+
+// ------------------------------------------------------------------------------------------
 // (2a) single-instruction issue cost: 16 independent copies of one instruction per iteration
 #define OPK(NAME, TY, INIT, ASM16, CONSTRAINTS)                                                            \
     __global__ __launch_bounds__(256) void NAME(const float* seed, float* out, unsigned long long* stamps, int iters) \
@@ -280,6 +336,26 @@ int main(int argc, char** argv)
         RUN("A + 8 mfma32x32x2  [full accumulate]", (kmf<2, 8>), bpc, 1);
         RUN("8 mfma16x16x4 only", (kmf<4, 8>), bpc, 1);
         RUN("8 mfma32x32x2 only", (kmf<5, 8>), bpc, 1);
+    }
+    printf("\n== (1b) VALU-only waves beside MFMA-only waves on the same SIMD (512-thread workgroups, one per CU: 2 waves per SIMD;\n"
+           "        wall ms is what matters: separate pipes -> MIX2 ~ max(MIX0, MIX1) / 2, one datapath -> ~ (MIX0 + MIX1) / 2) ==\n");
+    for (int rep = 0; rep < 2; ++rep) {
+        const int nb_ = ncu;
+        auto wall = [&](auto kern) {
+            float best = 1e30f;
+            for (int r = 0; r < 3; ++r) {
+                hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+                CK(hipEventRecord(e0));
+                hipLaunchKernelGGL(kern, nb_, 512, 0, 0, d_seed, d_out, d_st, iters);
+                CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                best = std::min(best, ms);
+            }
+            return best;
+        };
+        const float m0 = wall(kco<0>), m1 = wall(kco<1>), m2 = wall(kco<2>);
+        printf("MIX0 VALU|VALU %8.3f ms   MIX1 MFMA|MFMA %8.3f ms   MIX2 VALU|MFMA %8.3f ms   (max/2 = %.3f, mean = %.3f)\n", m0, m1, m2,
+               std::max(m0, m1) / 2, (m0 + m1) / 2);
     }
     printf("\n== (2a) instruction issue cost (16 independent instructions per iteration) ==\n");
     for (int bpc = 1; bpc <= 4; bpc *= 2) {
