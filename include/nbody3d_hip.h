@@ -262,8 +262,9 @@ const char *nb_variant_name(nb_sim *s);
  * step stream: nb_frame_request enqueues a small pack kernel behind the steps issued so far
  * (f32 bodies[4n] + speed[n] into a staging buffer) and the copy to pinned host memory runs
  * on a second stream beside the following steps.  nb_frame_acquire returns the newest frame
- * that has landed: pointers into engine-owned pinned memory, valid until the second
- * nb_frame_request after the one that produced it (two slots).  On a shard handle speed[]
+ * that has landed: pointers into engine-owned pinned memory, valid until the fourth
+ * nb_frame_request after the one that produced it (a ring of four slots: the host may run
+ * that far ahead of the copies before a request blocks).  On a shard handle speed[]
  * is filled for the handle's own rows only. */
 int nb_frame_request(nb_sim *s);
 int nb_frame_acquire(nb_sim *s, int wait, const float **bodies, const float **speed,

@@ -865,30 +865,35 @@ int nb_frame_request(nb_sim* s)
             NB_HIP(s, hipMalloc((void**)&f.d_bodies, sizeof(float) * 5 * s->n));
             f.d_speed = f.d_bodies + (size_t)4 * s->n;
             NB_HIP(s, hipMemsetAsync(f.d_speed, 0, sizeof(float) * s->n, s->stream));   // ordered before the pack kernel
-            NB_HIP(s, hipEventCreateWithFlags(&f.packed, hipEventDisableTiming));
+            NB_HIP(s, hipEventCreate(&f.packed));     // stamped by hipExtLaunchKernel
             NB_HIP(s, hipEventCreateWithFlags(&f.landed, hipEventDisableTiming));
         }
     }
     nb_frame_slot& f = s->frame[s->frame_next];
-    // the host copy issued from this slot two requests ago must have finished reading its
-    // staging buffer (normally long done); the step stream itself never waits for a copy
+    // the host copy issued from this slot kFrameSlots requests ago must have finished reading its
+    // staging buffer (normally long done; a host that runs further ahead than that is held back
+    // here, on the host side); the step stream itself never waits for a copy
     if (f.in_flight) NB_HIP(s, hipEventSynchronize(f.landed));
-    dim3 grid(ceil_div(s->n, nb::kBlock)), block(nb::kBlock);
-    if (s->f64)
-        hipLaunchKernelGGL((nb::nb_frame_pack<double>), grid, block, 0, s->stream, (const double4*)s->bodies[s->cur],
-                           (const double4*)s->vel, s->n, s->sb, s->sc, (float4*)f.d_bodies, f.d_speed);
-    else
-        hipLaunchKernelGGL((nb::nb_frame_pack<float>), grid, block, 0, s->stream, (const float4*)s->bodies[s->cur],
-                           (const float4*)s->vel, s->n, s->sb, s->sc, (float4*)f.d_bodies, f.d_speed);
-    NB_HIP(s, hipGetLastError());
-    NB_HIP(s, hipEventRecord(f.packed, s->stream));
+    // the "packed" event rides on the pack kernel's own completion signal (hipExtLaunchKernel):
+    // no marker packet on the step stream, so the next step's kernel is not held behind one
+    {
+        dim3 grid(ceil_div(s->n, nb::kBlock)), block(nb::kBlock);
+        const void* b = s->bodies[s->cur];
+        const void* v = s->vel;
+        uint32_t n = s->n, sb = s->sb, sc = s->sc;
+        float4* ob = (float4*)f.d_bodies;
+        float* os = f.d_speed;
+        void* args[] = {&b, &v, &n, &sb, &sc, &ob, &os};
+        const void* fn = s->f64 ? (const void*)&nb::nb_frame_pack<double> : (const void*)&nb::nb_frame_pack<float>;
+        NB_HIP(s, hipExtLaunchKernel(fn, grid, block, args, 0, s->stream, nullptr, f.packed, 0));
+    }
     NB_HIP(s, hipStreamWaitEvent(s->frame_stream, f.packed, 0));
     NB_HIP(s, hipMemcpyAsync(f.h_bodies, f.d_bodies, sizeof(float) * 5 * s->n, hipMemcpyDeviceToHost, s->frame_stream));
     NB_HIP(s, hipEventRecord(f.landed, s->frame_stream));
     f.step = s->steps_done;
     f.in_flight = true; f.valid = true;
     s->frame_latest = s->frame_next;
-    s->frame_next ^= 1;
+    s->frame_next = (s->frame_next + 1) % nb_sim::kFrameSlots;
     return NB_OK;
 }
 
@@ -898,8 +903,9 @@ int nb_frame_acquire(nb_sim* s, int wait, const float** bodies, const float** sp
     if (s->frame_latest < 0) return fail(s, NB_ERR_STATE, "nb_frame_acquire: nb_frame_request has not been called");
     NB_HIP(s, hipSetDevice(s->device));
     int pick = -1;
-    for (int k = 0; k < 2 && pick < 0; ++k) {          // newest first
-        nb_frame_slot& f = s->frame[s->frame_latest ^ k];
+    for (int k = 0; k < nb_sim::kFrameSlots && pick < 0; ++k) {          // newest first
+        const int idx = (s->frame_latest - k + nb_sim::kFrameSlots) % nb_sim::kFrameSlots;
+        nb_frame_slot& f = s->frame[idx];
         if (!f.valid) continue;
         if (f.in_flight) {
             if (wait && k == 0) NB_HIP(s, hipEventSynchronize(f.landed));
@@ -908,7 +914,7 @@ int nb_frame_acquire(nb_sim* s, int wait, const float** bodies, const float** sp
             if (q != hipSuccess) return fail(s, NB_ERR_HIP, std::string("nb_frame_acquire: ") + hipGetErrorString(q));
             f.in_flight = false;
         }
-        pick = s->frame_latest ^ k;
+        pick = idx;
     }
     if (pick < 0) return NB_NOT_READY;
     const nb_frame_slot& f = s->frame[pick];

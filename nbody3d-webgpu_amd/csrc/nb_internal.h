@@ -86,7 +86,8 @@ struct nb_sim {
     size_t pool_next = 0;
     // viewer frame feed
     hipStream_t frame_stream = nullptr;
-    nb_frame_slot frame[2];
+    static constexpr int kFrameSlots = 4;   // the host may run this many snapshots ahead of the copies
+    nb_frame_slot frame[kFrameSlots];
     int frame_next = 0;              // slot the next request writes
     int frame_latest = -1;           // most recently requested slot
 };

@@ -260,6 +260,20 @@ def test_bench_multi_gpu_launches_its_own_ranks():
         assert "2 ranks need 2 GPUs" in (p.stderr + p.stdout), (p.stderr + p.stdout)[-1500:]
 
 
+def test_bench_two_rank_control_flow_rehearsal():
+    """The complete multi-rank flow of bench.py -- self-started ranks, shard plan, per-rank gates,
+    replica agreement, max-over-ranks timing -- with two ranks SHARING the one GPU (exchange staged
+    through host memory over gloo: RCCL refuses two ranks on one device).  Marked REHEARSAL in the
+    line; the sharded state must equal an unsharded run."""
+    p, out = _bench("--gpus", "2", "--exchange", "host", "--nbodies", "16384", "--steps", "3", "--warmup", "2",
+                    "--no-cpu-baseline", timeout=600)
+    assert p.returncode == 0 and out, (p.stderr + p.stdout)[-2000:]
+    assert out["n_gpus"] == 2 and "REHEARSAL" in out and out["value"] > 0
+    assert out["replica_check"]["pass"] and out["shape_check"]["pass"] and out["check"]["pass"]
+    assert out["rehearsal_max_rel_diff_vs_unsharded"] < 1e-6
+    assert out["per_rank"]["rows"] == 8192 and out["exchange"]["bytes_sent_per_rank"] == 8192 * 16
+
+
 # ---- frame feed, integrate pass ----------------------------------------------------------------
 
 @pytest.mark.parametrize("precision", ["f32", "f64"])
