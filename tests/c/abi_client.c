@@ -3,7 +3,8 @@
  *
  *   abi_client <golden dir>    exit 0 = all checks passed; prints one line per check.
  * Without a GPU it checks the no-device contract; with one it runs the N=1,024 Plummer
- * fixture for 10 steps and compares with the committed oracle vector. */
+ * fixture for 10 steps and compares with the committed oracle vector, then the frame feed, the
+ * kernel timing, and both native-RCCL forms with one rank. */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -70,7 +71,58 @@ int main(int argc, char **argv)
         if (out[4 * i + 3] != b[4 * i + 3] || acc[4 * i + 3] != 0.0f) { printf("FAIL mass/accel.w lane\n"); fails++; break; }
     double diag[5];
     if (nb_diagnostics(sim, diag) != NB_OK || !(diag[1] < 0.0)) { printf("FAIL diagnostics\n"); fails++; } else printf("ok diagnostics KE=%.6f PE=%.6f\n", diag[0], diag[1]);
+
+    /* viewer frame feed (nbody3d.js:408-415,482-487): snapshot of the state now, read back after more steps */
+    const float *fb = NULL, *fs = NULL;
+    uint64_t fstep = 0;
+    if (nb_frame_request(sim) != NB_OK || nb_step(sim, 3) != NB_OK || nb_frame_acquire(sim, 1, &fb, &fs, &fstep) != NB_OK) {
+        printf("FAIL frame feed: %s\n", nb_last_error(sim)); fails++;
+    } else {
+        int same = fstep == 10 && memcmp(fb, out, sizeof(float) * 4 * n) == 0 && fs[0] >= 0.0f;
+        printf("%s frame feed: snapshot of step %llu equals the download of that step\n", same ? "ok" : "FAIL", (unsigned long long)fstep);
+        if (!same) fails++;
+    }
+    /* kernel-exact timing (role of TimingHelper, util.js:297-423) */
+    double f_ms = 0, i_ms = 0, x_ms = 0; uint32_t launches = 0;
+    if (nb_enable_timing(sim, 1) != NB_OK || nb_step(sim, 4) != NB_OK || nb_step_times(sim, &f_ms, &i_ms, &x_ms, &launches) != NB_OK ||
+        launches != 4 || !(f_ms > 0.0)) { printf("FAIL step times\n"); fails++; }
+    else printf("ok step times: %u launches, force %.4f ms, integrate %.4f ms\n", launches, f_ms, i_ms);
     nb_destroy(sim);
+
+    /* native RCCL collective with one rank: a shard handle that owns every row */
+    cfg.shard_begin = 0; cfg.shard_count = n;
+    nb_sim *sh = NULL;
+    unsigned char id[NB_RCCL_ID_BYTES];
+    int nr = 0, rk = -1, ver = 0;
+    if (nb_create(&cfg, &sh) != NB_OK || nb_rccl_unique_id(id) != NB_OK || nb_rccl_attach(sh, id, 1, 0, 0) != NB_OK ||
+        nb_rccl_info(sh, &nr, &rk, &ver) != NB_OK || nr != 1 || rk != 0 ||
+        nb_upload(sh, b, v, NULL) != NB_OK || nb_set_params(sh, 1e-3, 1.0) != NB_OK || nb_step(sh, 10) != NB_OK ||
+        nb_download(sh, acc, NULL, NULL) != NB_OK) {
+        printf("FAIL rccl single rank: %s\n", sh ? nb_last_error(sh) : nb_last_error(NULL)); fails++;
+    } else {
+        double w2 = 0.0;
+        for (uint32_t i = 0; i < 4 * n; ++i) { double d = fabs((double)acc[i] - (double)ref[i]); if (i % 4 != 3 && d > w2) w2 = d; }
+        printf("%s rccl-attached handle (nranks %d, rccl %d): max |dx| vs oracle = %.3g\n", w2 < 1e-5 ? "ok" : "FAIL", nr, ver, w2);
+        if (!(w2 < 1e-5)) fails++;
+    }
+    if (sh) { nb_rccl_detach(sh); nb_destroy(sh); }
+
+    /* one process, one shard, RCCL mode of the multi handle: ncclCommInitAll + grouped all-gather */
+    cfg.shard_begin = cfg.shard_count = 0;
+    nb_multi *m = NULL;
+    int mode = -1;
+    if (nb_multi_create(&cfg, 1, NULL, &m) != NB_OK || nb_multi_set_collective(m, NB_MULTI_RCCL) != NB_OK ||
+        nb_multi_collective_info(m, &mode, &nr, &ver) != NB_OK || mode != NB_MULTI_RCCL || nr != 1 ||
+        nb_multi_upload(m, b, v, NULL) != NB_OK || nb_multi_set_params(m, 1e-3, 1.0) != NB_OK || nb_multi_step(m, 10) != NB_OK ||
+        nb_multi_download(m, acc, NULL, NULL) != NB_OK) {
+        printf("FAIL multi rccl: %s\n", nb_multi_last_error(m)); fails++;
+    } else {
+        double w3 = 0.0;
+        for (uint32_t i = 0; i < 4 * n; ++i) { double d = fabs((double)acc[i] - (double)ref[i]); if (i % 4 != 3 && d > w3) w3 = d; }
+        printf("%s multi handle in RCCL mode: max |dx| vs oracle = %.3g\n", w3 < 1e-5 ? "ok" : "FAIL", w3);
+        if (!(w3 < 1e-5)) fails++;
+    }
+    if (m) nb_multi_destroy(m);
     free(b); free(v); free(ref); free(out); free(acc);
     return fails ? 1 : 0;
 }

@@ -35,3 +35,5 @@ def test_c_client_reports_missing_device():
 def test_c_client_runs_the_fixture_on_the_gpu():
     out = run()
     assert "fixture after 10 steps" in out and "ok diagnostics" in out
+    assert "ok frame feed" in out and "ok step times" in out
+    assert "ok rccl-attached handle" in out and "ok multi handle in RCCL mode" in out
