@@ -69,3 +69,16 @@ def test_bench_refuses_to_run_without_a_gpu():
                        timeout=300)
     assert p.returncode != 0 and "no GPU visible" in (p.stderr + p.stdout)
     assert not any(l.startswith("{") for l in p.stdout.splitlines())
+
+
+@pytest.mark.skipif(have_gpu(), reason="checks the no-device error path")
+def test_bench_multi_gpu_self_launch_fails_cleanly_without_gpus():
+    """`bench.py --gpus 2` with no launcher: the GPU-free parent starts two ranks through
+    torch.distributed.run; with no GPU each rank must stop at the device check (no hang, no JSON)."""
+    import subprocess
+    import sys
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode != 0
+    assert "no GPU visible" in (p.stderr + p.stdout), (p.stderr + p.stdout)[-1500:]
+    assert not any(l.startswith("{") for l in p.stdout.splitlines())
