@@ -97,7 +97,8 @@ typedef struct nb_config {
     /* Force-kernel launch shape overrides for tuning; 0 -> engine heuristics.  */
     uint32_t force_variant; /* 6 decimal digits K II LL X: K = 1 scalar loop, 2 packed f32 with
                                the j-tile in LDS, 3 packed f32 with j broadcast from SGPRs,
-                               4 fused one-launch step (packed, LDS tile); II = bodies per
+                               4 fused one-launch step (packed, LDS tile), 5 the same with the
+                               j-bodies in registers (N <= 1,024 * X; II = 02, LL = 64); II = bodies per
                                lane (01..08); LL = lanes sharing a body (01..64); X = tile
                                units staged at once (K = 2, 4: 1 or 4) or waves splitting j
                                (K = 3: 1 or 4).  E.g. 402644.  See nb_variant_name().    */

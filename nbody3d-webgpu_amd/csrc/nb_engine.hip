@@ -50,7 +50,7 @@ using nbi::fail;
 
 uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-enum Kind { kScalar = 1, kPkLds = 2, kPkSgpr = 3, kFused = 4 };
+enum Kind { kScalar = 1, kPkLds = 2, kPkSgpr = 3, kFused = 4, kDirect = 5 };   // kDirect: fused, registers only (x = MAXJ/16)
 struct Shape { int kind, ipl, ls, x; };   // x: tile units (LDS kinds) or j-splitting waves (SGPR kind)
 
 bool pow2(int v) { return v >= 1 && (v & (v - 1)) == 0; }
@@ -124,6 +124,9 @@ const void* kernel_of(bool f64, const Shape& sh)
         case kPkLds: return f64 || (sh.ipl & 1) ? nullptr : pk_force_kernel(sh.ipl / 2, sh.ls, sh.x);
         case kFused: return f64 || (sh.ipl & 1) ? nullptr : pk_fused_kernel(sh.ipl / 2, sh.ls, sh.x);
         case kPkSgpr: return f64 || sh.ls != 1 || !(sh.x == 1 || sh.x == 4) ? nullptr : sgpr_kernel(sh.ipl, sh.x);
+        case kDirect:
+            if (f64 || sh.ipl != 2 || sh.ls != 64) return nullptr;
+            return sh.x == 1 ? (const void*)&nb::nb_step_direct<16> : sh.x == 2 ? (const void*)&nb::nb_step_direct<32> : nullptr;
         default: return nullptr;
     }
 }
@@ -154,7 +157,7 @@ bool decode_variant(uint32_t v, Shape* out)
     }
     if (v < 100000) return false;
     Shape sh{(int)(v / 100000), (int)(v / 1000 % 100), (int)(v / 10 % 100), (int)(v % 10)};
-    if (sh.kind < kScalar || sh.kind > kFused || !pow2(sh.ls)) return false;
+    if (sh.kind < kScalar || sh.kind > kDirect || !pow2(sh.ls)) return false;
     if (sh.kind == kScalar) sh.x = 1;
     *out = sh;
     return true;
@@ -167,6 +170,8 @@ void name_variant(nb_sim* s, const Shape& sh)
         snprintf(buf, sizeof buf, "f32pk_sgpr_ipl%d%s_js%u", sh.ipl, sh.x == 4 ? "_ws4" : "", s->jsplit);
     else if (sh.kind == kFused)
         snprintf(buf, sizeof buf, "f32pk_fused_lds%d_ipl%d_ls%d", nb::kTile * sh.x, sh.ipl, sh.ls);
+    else if (sh.kind == kDirect)
+        snprintf(buf, sizeof buf, "f32pk_fused_regs%d_ipl%d_ls%d", 64 * 16 * sh.x, sh.ipl, sh.ls);
     else
         snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.kind == kPkLds ? "pk" : "",
                  nb::kTile * (sh.kind == kPkLds ? sh.x : 1), sh.ipl, sh.ls, s->jsplit);
@@ -219,6 +224,9 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         // SGPR loop: 8 bodies per lane measured ~2 % ahead of 4 (profiles/r02/shape_scan_*.txt)
         for (int ipl : {8, 4})
             for (int ws : {1, 4}) cands.push_back({{kPkSgpr, ipl, 1, ws}, (ipl == 8 ? 32.5 : 33.2) * ipl});
+        // registers-only fused step: no tile hand-over at all (64 issue cycles per j, nothing to wait for)
+        if (may_fuse && n <= 1024) cands.push_back({{kDirect, 2, 64, 1}, 64.0});
+        if (may_fuse && n <= 2048) cands.push_back({{kDirect, 2, 64, 2}, 64.0});
     }
 
     Shape sh{s->f64 ? kScalar : kPkLds, 2, 1, 1};
@@ -229,7 +237,8 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         Shape want;
         if (decode_variant(variant, &want)) {
             if (s->f64 && want.kind != kScalar) want = {kScalar, want.ipl > 4 ? 4 : want.ipl, 1, 1};
-            if (want.kind == kFused && !may_fuse && !s->f64) want.kind = kPkLds;   // same loop, two kernels
+            if ((want.kind == kFused || want.kind == kDirect) && !may_fuse && !s->f64) want = {kPkLds, want.ipl, want.ls, 1};   // same loop, two kernels
+            if (want.kind == kDirect && n > 1024u * (uint32_t)want.x) want = {kFused, 2, 64, 4};
             if (kernel_of(s->f64, want)) { sh = want; pinned = true; }
         }
     }
@@ -253,9 +262,9 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
             uint32_t js_hi = n / kMinSplitLen;
             if (js_hi < 1) js_hi = 1;
             if (js_hi > kMaxSplit) js_hi = kMaxSplit;
-            if (c.sh.kind == kFused) js_hi = 1;
+            if (c.sh.kind == kFused || c.sh.kind == kDirect) js_hi = 1;
             uint32_t js_lo = cfg.jsplit ? cfg.jsplit : 1, js_top = cfg.jsplit ? cfg.jsplit : js_hi;
-            if (c.sh.kind == kFused) { if (cfg.jsplit > 1) continue; js_lo = js_top = 1; }
+            if (c.sh.kind == kFused || c.sh.kind == kDirect) { if (cfg.jsplit > 1) continue; js_lo = js_top = 1; }
             for (uint32_t q = js_lo; q <= js_top; ++q) {
                 const uint32_t len = split_len(q), used = ceil_div(n, len);
                 if (c.sh.kind == kPkSgpr && len / c.sh.x < 256) continue;   // SGPR loop wants >= 256 bodies per wave
@@ -263,7 +272,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 const uint64_t full = blocks / slots, rem = blocks % slots;
                 const double tile = c.sh.kind == kPkSgpr ? 256.0 : 256.0 * c.sh.x;
                 const double wave_len = c.sh.kind == kPkSgpr ? (double)len / c.sh.x : (double)len;
-                const double stages = std::ceil(wave_len / tile);
+                const double stages = c.sh.kind == kDirect ? 0.5 : std::ceil(wave_len / tile);
                 const double iters = std::ceil(wave_len / c.sh.ls);
                 // a SIMD with fewer than 4 resident waves cannot keep its issue port full
                 // (measured with the pure-ALU loop, profiles/r01/ubench_run1.txt, profiles/r02/ubench3_*.txt)
@@ -280,7 +289,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 const double stream_s = (double)iblocks * n * 4 * s->esz / 8.0e12;
                 // K2 reads every split's partial back (and K1 writes it): priced at 2 TB/s so that, when the
                 // balance gain is a wash (N = 262,144: 8 vs 16 splits), the smaller HBM footprint wins
-                const double after = c.sh.kind == kFused ? 0.0 : (double)used * sc * 4 * s->esz / 2.0e12 + 3e-6;
+                const double after = (c.sh.kind == kFused || c.sh.kind == kDirect) ? 0.0 : (double)used * sc * 4 * s->esz / 2.0e12 + 3e-6;
                 const double t = std::max(cyc / kClock, stream_s) / (1.0 - 0.03 / rounds) + after;
                 scored.push_back({c.sh, q, t});
                 if (t < best_t) best_t = t;
@@ -303,11 +312,12 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         if (js > hi) js = hi;
         if (js < 1) js = 1;
     }
-    if (sh.kind == kFused) js = 1;
+    if (sh.kind == kFused || sh.kind == kDirect) js = 1;
     s->ipl = sh.ipl; s->ls = sh.ls;
-    s->packed = sh.kind != kScalar; s->sgpr = sh.kind == kPkSgpr; s->fused = sh.kind == kFused;
+    s->packed = sh.kind != kScalar; s->sgpr = sh.kind == kPkSgpr; s->fused = sh.kind == kFused || sh.kind == kDirect;
+    s->direct = sh.kind == kDirect;
     s->ws = sh.kind == kPkSgpr ? sh.x : 1;
-    s->tl = (sh.kind == kPkLds || sh.kind == kFused) ? sh.x : 1;
+    s->tl = (sh.kind == kPkLds || sh.kind == kFused || sh.kind == kDirect) ? sh.x : 1;
     s->j_per_split = split_len(js);
     s->jsplit = ceil_div(n, s->j_per_split);   // a split may end up empty after rounding
     s->swap_acc = !s->fused && s->jsplit == 1;
@@ -325,6 +335,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
 
 Shape shape_of(const nb_sim* s)
 {
+    if (s->direct) return {kDirect, s->ipl, s->ls, s->tl};
     if (s->fused) return {kFused, s->ipl, s->ls, s->tl};
     if (s->sgpr) return {kPkSgpr, s->ipl, 1, s->ws};
     if (s->packed) return {kPkLds, s->ipl, s->ls, s->tl};

@@ -58,7 +58,8 @@ struct nb_sim {
     bool sgpr = false;     // nb_force_pk_sgpr: j broadcast from SGPRs instead of the LDS tile
     int ws = 1;            // SGPR kernel: waves of a workgroup that split the j-range (1 or 4)
     int tl = 1;            // LDS kernels: 256-body tiles staged at once (1 or 4)
-    bool fused = false;    // nb_step_fused: K2 folded into K1's epilogue (jsplit == 1, whole system)
+    bool fused = false;    // nb_step_fused / nb_step_direct: K2 folded into K1's epilogue (jsplit == 1, whole system)
+    bool direct = false;   // nb_step_direct: the fused step with each lane's j-bodies in registers (N <= 2,048)
     int acc_parity = 0;    // swap_acc: how often acc/partial have swapped roles (mod 2)
     bool swap_acc = false; // two-kernel step with jsplit == 1: K2 reads the partial as a_new and the
                            // acc/partial buffers swap roles (96 B per body)

@@ -16,6 +16,8 @@
 //                                        epilogue (no j-split across workgroups: LS lanes of a
 //                                        wave share an i-body instead) -- one launch per step,
 //                                        no partial sums through memory
+//               nb_step_direct<MAXJ>     the same for N <= 2,048 with each lane's j-bodies loaded
+//                                        straight into registers (no LDS tile, no barrier)
 //
 // CDNA4 mapping of the force loop (wave = 64 lanes, 4 SIMDs/CU, 160 KiB LDS/CU):
 //   * a 256-thread workgroup (4 waves, one per SIMD) stages a j-tile of 256*TL bodies
@@ -572,6 +574,96 @@ void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bo
         }
     }
     NB_STAMP(4);
+}
+
+// The fused step for systems of at most 64*MAXJ bodies (MAXJ = 16: N <= 1,024; 32: N <= 2,048), without
+// LDS: a wave's 64 lanes share two bodies (the nb_step_fused<1,64,*> mapping) and lane js needs
+// exactly the j-bodies js, js+64, js+128, ... -- at most MAXJ rows, so it loads them straight into
+// registers (coalesced: 1 KiB per wave load, every load of the kernel in flight at once) and runs
+// the packed loop on registers.  No tile store, no barrier, no ds_read latency: the step is three
+// memory round trips (arguments, loads, stores) and 64 issue cycles per j.  Every wave reads all
+// N rows itself (4x the L2 traffic of the tiled kernel): only for systems this small.
+// Same j order per lane and same reduction as nb_step_fused<1,64,*>: bit-identical results.
+template <int MAXJ>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXJ > 16 ? 2 : 3, 4)))
+void nb_step_direct(const float4* __restrict__ bodies_in, float4* __restrict__ bodies_out, float4* __restrict__ vel,
+                    float4* __restrict__ acc, uint32_t n, float G, float eps2, float dt)
+{
+    constexpr int GROUPS = kBlock / 64;     // one wave per pair of bodies
+    constexpr int IPB = GROUPS * 2;
+    const int tid = threadIdx.x;
+    const int grp = tid / 64, js = tid % 64;
+    const uint32_t il0 = blockIdx.x * IPB + grp, il1 = il0 + GROUPS;
+    const uint32_t c0 = il0 < n ? il0 : n - 1, c1 = il1 < n ? il1 : n - 1;
+    // every global load of the kernel, back to back, nothing consuming them yet
+    const float4 b0 = ld4(bodies_in + c0), b1 = ld4(bodies_in + c1);
+    const float4 v0 = ld4(vel + c0), v1 = ld4(vel + c1), a0 = ld4(acc + c0), a1 = ld4(acc + c1);
+    nb_v4f q[MAXJ];
+#pragma unroll
+    for (int k = 0; k < MAXJ; ++k) {
+        const uint32_t j = (uint32_t)k * 64u + (uint32_t)js;
+        q[k] = *reinterpret_cast<const nb_v4f*>(bodies_in + (j < n ? j : n - 1));
+    }
+    // pin all MAXJ loads HERE, ahead of the first stage: left alone the backend sinks the loads of
+    // the later stages into those stages' (wave-uniform) branches and pays their latency there
+#pragma unroll
+    for (int k = 0; k < MAXJ; ++k) asm volatile("" : "+v"(q[k]));
+    const nb_f2 xi = nb_f2{b0.x, b1.x}, yi = nb_f2{b0.y, b1.y}, zi = nb_f2{b0.z, b1.z};
+    nb_f2 ax = nb_f2{0, 0}, ay = nb_f2{0, 0}, az = nb_f2{0, 0};
+    const nb_f2 e2 = nb_f2{eps2, eps2};
+    const uint32_t nj = (n + 63) / 64;      // rows of 64 bodies that exist (wave-uniform)
+#pragma unroll
+    for (int k0 = 0; k0 < MAXJ; k0 += 4) {
+        if ((uint32_t)k0 < nj) {            // 4 j-bodies = 4 independent chains, stage-major as in PkCore
+            nb_f2 bx[4], by[4], bz[4], bm[4], dx[4], dy[4], dz[4], d2[4], r[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t j = (uint32_t)(k0 + u) * 64u + (uint32_t)js;
+                const nb_v4f b = q[k0 + u];
+                const float gm = j < n ? b.w * G : 0.0f;          // past the end: zero mass, contributes exactly 0
+                bx[u] = nb_f2{b.x, b.x}; by[u] = nb_f2{b.y, b.y}; bz[u] = nb_f2{b.z, b.z}; bm[u] = nb_f2{gm, gm};
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dx[c] = bx[c] - xi;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dy[c] = by[c] - yi;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dz[c] = bz[c] - zi;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = d2[c] * d2[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = bm[c] * r[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ax = __builtin_elementwise_fma(r[c], dx[c], ax);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ay = __builtin_elementwise_fma(r[c], dy[c], ay);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) az = __builtin_elementwise_fma(r[c], dz[c], az);
+        }
+    }
+    float red[6] = {ax.x, ax.y, ay.x, ay.y, az.x, az.y};
+    group_sum_all<64, 6>(red);
+    if (js == 63) {
+        float4 nx, nv, na;
+        if (il0 < n) {
+            leapfrog<float>(b0, v0, a0, red[0], red[2], red[4], dt, nx, nv, na);
+            vel[il0] = nv; bodies_out[il0] = nx; acc[il0] = na;
+        }
+        if (il1 < n) {
+            leapfrog<float>(b1, v1, a1, red[1], red[3], red[5], dt, nx, nv, na);
+            vel[il1] = nv; bodies_out[il1] = nx; acc[il1] = na;
+        }
+    }
 }
 
 // K1, packed form with the j-bodies broadcast from SGPRs instead of LDS (SURVEY.md §8 f3

@@ -55,6 +55,25 @@ def test_fused_step_is_bit_identical_to_the_two_kernel_step(ipl, ls, tl, n):
     assert rel_pos_err(fb, rb, 1.0) < 2e-5, fname
 
 
+@pytest.mark.parametrize("n,x", [(1, 1), (63, 1), (771, 1), (1000, 1), (1024, 1), (1000, 2), (1025, 2), (1500, 2), (2048, 2)])
+def test_registers_only_fused_step_is_bit_identical_to_the_tiled_fused_step(n, x):
+    """nb_step_direct<16|32> (N <= 1,024 | 2,048: each lane's j-bodies loaded straight into registers,
+    no LDS) == nb_step_fused<1,64,4>: same lane -> j mapping, same order, same reduction."""
+    b, v = ic.uniform_cube(n, seed=35)
+    db, dv, da, dname = run(b, v, 19, force_variant=502640 + x)
+    fb, fv, fa, fname = run(b, v, 19, force_variant=402644)
+    assert "fused_regs%d" % (1024 * x) in dname and "fused_lds1024" in fname, (dname, fname)
+    assert db.tobytes() == fb.tobytes() and dv.tobytes() == fv.tobytes() and da.tobytes() == fa.tobytes(), (dname, fname)
+    rb, _, _ = oracle.run_f32(b, v, None, 1e-3, 1.0, 19)
+    assert rel_pos_err(db, rb, 1.0) < 2e-5, dname
+
+
+def test_registers_only_step_is_refused_above_its_size():
+    b, v = ic.plummer(4096, seed=36)
+    _, _, _, name = run(b, v, 1, force_variant=502641)       # 4,096 bodies do not fit 16 rows per lane
+    assert "fused_lds1024" in name, name
+
+
 def test_default_small_system_takes_the_fused_path_and_flag_disables_it():
     b, v = ic.plummer(4096, seed=32)
     fb, fv, fa, fname = run(b, v, 5)

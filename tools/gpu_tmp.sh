@@ -1,5 +1,2 @@
-python tools/feed_driver.py 1000 feedacq
-node tests/js/node_default_workload.js 2000 | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('node plain', d['ms_per_frame'])"
-node tests/js/node_default_workload.js 2000 feed | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('node feed', d['ms_per_frame'], d['frames_landed_in_loop'])"
-node tests/js/node_default_workload.js 2000 feednoacq | python3 -c "import json,sys; d=json.loads(sys.stdin.read()); print('node feed no acquire', d['ms_per_frame'], d['frames_landed_in_loop'])"
-python -m pytest tests/test_c_client.py -m gpu -q 2>&1 | tail -3
+python -m pytest tests/test_round2_gpu.py -m gpu -q --timeout 600 -k "registers or default_small" 2>&1 | tail -3
+python tools/shape_scan.py 512 1024 1536 2048 --quick 2>&1 | grep -E "== N|auto|direct|fused_ipl2_ls64_tl4" | cut -c1-120

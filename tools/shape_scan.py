@@ -33,6 +33,10 @@ def candidates(n):
                 if n / ls < 16:
                     continue
                 out.append(("fused_ipl%d_ls%d_tl%d" % (ipl, ls, tl), dict(force_variant=400000 + ipl * 1000 + ls * 10 + tl)))
+    if n <= 2048:
+        out.append(("direct_regs2048", dict(force_variant=502642)))
+    if n <= 1024:
+        out.append(("direct_regs1024", dict(force_variant=502641)))
     if n >= 16384:
         for ipl in (4, 8):
             for ws in (1, 4):
