@@ -58,20 +58,28 @@ __device__ unsigned long long* nb_stamp_buf;
     do {                                                                                                    \
         unsigned long long t_;                                                                              \
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); \
-        if ((threadIdx.x & 63) == 0) nb_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (k)] = t_; \
+        if ((threadIdx.x & 63) == 0) nb_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = t_; \
         if ((k) == 0) {                 /* where the wave runs: HW_ID (wave/simd/cu/sh/se) and XCC_ID */       \
             unsigned hw_, xcc_;                                                                                 \
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw_), "=s"(xcc_)); \
-            if ((threadIdx.x & 63) == 0) nb_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + 7] = ((unsigned long long)xcc_ << 32) | hw_; \
+            if ((threadIdx.x & 63) == 0) nb_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 7] = ((unsigned long long)xcc_ << 32) | hw_; \
         }                                                                                                   \
         if ((k) == 0 || (k) == 4) {     /* 100 MHz wall clock beside the first and last stamp */                \
             unsigned long long r_;                                                                              \
             asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(r_)::"memory");                    \
-            if ((threadIdx.x & 63) == 0) nb_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + ((k) == 0 ? 5 : 6)] = r_; \
+            if ((threadIdx.x & 63) == 0) nb_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + ((k) == 0 ? 5 : 6)] = r_; \
         }                                                                                                   \
+    } while (0)
+// without the drain: for points inside the tile loop
+#define NB_STAMP_LIGHT(k)                                                                                   \
+    do {                                                                                                    \
+        unsigned long long t_;                                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                          \
+        if ((threadIdx.x & 63) == 0) nb_stamp_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (k)] = t_; \
     } while (0)
 #else
 #define NB_STAMP(k) do { } while (0)
+#define NB_STAMP_LIGHT(k) do { } while (0)
 #endif
 
 constexpr int kBlock = 256;  // threads per workgroup = reference TILE_SIZE (nbody3d.js:4,240)
@@ -419,7 +427,9 @@ struct PkCore {
         for (uint32_t t = 0; t < ntiles; ++t) {
             const int cur = t & 1;
             const bool more = (t + 1 < ntiles);
+            if (t == 1) NB_STAMP_LIGHT(8);
             if (more) load(t + 1);
+            if (t == 1) NB_STAMP_LIGHT(9);
             // JB j-bodies x NG groups = 4 independent dependency chains, issued stage-major:
             // consecutive packed ops never depend on each other, so the backend needs no s_nop
             // between a v_pk_* / v_rsq result and its consumer (gfx950 VALU hazard) and one wave
@@ -432,8 +442,11 @@ struct PkCore {
 #pragma unroll UNROLL
                 for (int uu = 0; uu < UNR; ++uu) math(&tile[cur][(ch * U + uu * JB) * LS + js]);
             }
+            if (t == 1) NB_STAMP_LIGHT(10);
             if (more) store(cur ^ 1);
+            if (t == 1) NB_STAMP_LIGHT(11);
             __syncthreads();
+            if (t == 1) NB_STAMP_LIGHT(12);
         }
         NB_STAMP(2);
 

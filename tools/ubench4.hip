@@ -25,7 +25,7 @@ void run(uint32_t n, int steps)
     float4 *b0, *b1, *v, *a;
     unsigned long long* st;
     CK(hipMalloc(&b0, 16 * n)); CK(hipMalloc(&b1, 16 * n)); CK(hipMalloc(&v, 16 * n)); CK(hipMalloc(&a, 16 * n));
-    CK(hipMalloc(&st, sizeof(unsigned long long) * 8 * 4 * grid));
+    CK(hipMalloc(&st, sizeof(unsigned long long) * 16 * 4 * grid));
     CK(hipMemcpy(b0, hb.data(), 16 * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(v, hz.data(), 16 * n, hipMemcpyHostToDevice));
     CK(hipMemcpy(a, hz.data(), 16 * n, hipMemcpyHostToDevice));
@@ -41,15 +41,15 @@ void run(uint32_t n, int steps)
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         best = std::min(best, ms);
     }
-    std::vector<unsigned long long> h((size_t)8 * 4 * grid);
+    std::vector<unsigned long long> h((size_t)16 * 4 * grid);
     CK(hipMemcpy(h.data(), st, sizeof(unsigned long long) * h.size(), hipMemcpyDeviceToHost));
     const size_t nw = (size_t)4 * grid;
     std::vector<double> ph[4], t0, t4, clk;
     for (size_t w = 0; w < nw; ++w) {
-        if (!h[w * 8] || !h[w * 8 + 4]) continue;
-        for (int p = 0; p < 4; ++p) ph[p].push_back((double)(h[w * 8 + p + 1] - h[w * 8 + p]));
-        t0.push_back((double)h[w * 8]); t4.push_back((double)h[w * 8 + 4]);
-        if (h[w * 8 + 6] > h[w * 8 + 5]) clk.push_back((double)(h[w * 8 + 4] - h[w * 8]) / (double)(h[w * 8 + 6] - h[w * 8 + 5]) * 0.1);
+        if (!h[w * 16] || !h[w * 16 + 4]) continue;
+        for (int p = 0; p < 4; ++p) ph[p].push_back((double)(h[w * 16 + p + 1] - h[w * 16 + p]));
+        t0.push_back((double)h[w * 16]); t4.push_back((double)h[w * 16 + 4]);
+        if (h[w * 16 + 6] > h[w * 16 + 5]) clk.push_back((double)(h[w * 16 + 4] - h[w * 16]) / (double)(h[w * 16 + 6] - h[w * 16 + 5]) * 0.1);
     }
     for (auto& p : ph) std::sort(p.begin(), p.end());
     std::sort(clk.begin(), clk.end());
@@ -61,16 +61,30 @@ void run(uint32_t n, int steps)
            "entry spread %6.0f, first-in->last-out %7.0f cycles; in-kernel clock %.2f GHz -> %.2f us\n",
            n, NG, LS, TL, grid, ph[0].size(), nw, 1e3 * best / steps, ph[0][m], ph[1][m], ph[2][m], ph[3][m], lastin - first, lastout - first,
            ghz, ghz > 0 ? (lastout - first) / (ghz * 1e3) : 0.0);
+    {   // inside tile 1 of the loop: issue of the next tile's loads, the tile's math, LDS store of the next tile, barrier
+        std::vector<double> a, b, c, d;
+        for (size_t w = 0; w < nw; ++w) {
+            if (!h[w * 16 + 8] || !h[w * 16 + 12]) continue;
+            a.push_back((double)(h[w * 16 + 9] - h[w * 16 + 8])); b.push_back((double)(h[w * 16 + 10] - h[w * 16 + 9]));
+            c.push_back((double)(h[w * 16 + 11] - h[w * 16 + 10])); d.push_back((double)(h[w * 16 + 12] - h[w * 16 + 11]));
+        }
+        if (!a.empty()) {
+            for (auto* v : {&a, &b, &c, &d}) std::sort(v->begin(), v->end());
+            const size_t mm = a.size() / 2, p9 = a.size() * 9 / 10;
+            printf("        tile 1, cycles med (p90): issue loads %.0f (%.0f)  math %.0f (%.0f)  wait+LDS store %.0f (%.0f)  barrier %.0f (%.0f)\n",
+                   a[mm], a[p9], b[mm], b[p9], c[mm], c[p9], d[mm], d[p9]);
+        }
+    }
     // residency: workgroups per CU (HW_ID: cu_id bits 11:8, sh_id 12, se_id 15:13; XCC_ID bits 3:0) and the
     // slowest wave against the median one
     {
         std::vector<int> per_cu(8 * 64, 0);
         std::vector<double> tot;
         for (size_t w = 0; w < nw; ++w) {
-            if (!h[w * 8] || !h[w * 8 + 4]) continue;
-            tot.push_back((double)(h[w * 8 + 4] - h[w * 8]));
+            if (!h[w * 16] || !h[w * 16 + 4]) continue;
+            tot.push_back((double)(h[w * 16 + 4] - h[w * 16]));
             if (w % 4 == 0) {
-                const unsigned hw = (unsigned)(h[w * 8 + 7] & 0xffffffffu), xcc = (unsigned)(h[w * 8 + 7] >> 32) & 0xf;
+                const unsigned hw = (unsigned)(h[w * 16 + 7] & 0xffffffffu), xcc = (unsigned)(h[w * 16 + 7] >> 32) & 0xf;
                 const unsigned cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
                 per_cu[(xcc & 7) * 64 + ((se * 2 + sh) * 16 + cu) % 64]++;
             }
@@ -78,9 +92,9 @@ void run(uint32_t n, int steps)
         // who is slow?  mean lifetime by XCC, by blockIdx quartile, by wave slot of the workgroup
         double sx[8] = {0}, sq[4] = {0}, sw[4] = {0}; int nx[8] = {0}, nq[4] = {0}, nwv[4] = {0};
         for (size_t w = 0; w < nw; ++w) {
-            if (!h[w * 8] || !h[w * 8 + 4]) continue;
-            const double life = (double)(h[w * 8 + 4] - h[w * 8]);
-            const unsigned xcc = (unsigned)(h[(w / 4 * 4) * 8 + 7] >> 32) & 7;
+            if (!h[w * 16] || !h[w * 16 + 4]) continue;
+            const double life = (double)(h[w * 16 + 4] - h[w * 16]);
+            const unsigned xcc = (unsigned)(h[(w / 4 * 4) * 16 + 7] >> 32) & 7;
             sx[xcc] += life; nx[xcc]++;
             const int q = (int)((w / 4) * 4 / grid); sq[q] += life; nq[q]++;
             sw[w % 4] += life; nwv[w % 4]++;
@@ -107,7 +121,6 @@ int main()
 {
     const int steps = 200;
     printf("note: s_memtime counts shader-clock cycles on gfx950 (MI355X_MICROARCH.md cycle constants)\n");
-    run<1, 64, 4>(1024, steps);
     run<1, 64, 4>(2048, steps);
     run<1, 64, 4>(4096, steps);
     run<1, 32, 4>(4096, steps);
