@@ -76,9 +76,20 @@ bool pow2(int v) { return v >= 1 && (v & (v - 1)) == 0; }
         case 64: return (const void*)&nb::F<NG, 64, 4>;                  \
         default: return nullptr;                                         \
     }
+#define NB_LS_CASES_T8(F, NG, ls)                                       \
+    switch (ls) {                                                        \
+        case 32: return (const void*)&nb::F<NG, 32, 8>;                  \
+        case 64: return (const void*)&nb::F<NG, 64, 8>;                  \
+        default: return nullptr;                                         \
+    }
 #define NB_PK_TABLE(NAME, F)                                            \
     const void* NAME(int ng, int ls, int tl)                            \
     {                                                                    \
+        if (tl == 8) {          /* 2048-body stages: 64 KiB of LDS, <= 2 workgroups per CU */ \
+            if (ng == 1) { NB_LS_CASES_T8(F, 1, ls) }                    \
+            if (ng == 2) { NB_LS_CASES_T8(F, 2, ls) }                    \
+            if (ng == 4) { NB_LS_CASES_T8(F, 4, ls) }                    \
+        }                                                                \
         if (tl == 1) {                                                   \
             if (ng == 1) { NB_LS_CASES(F, 1, 1, ls) }                    \
             if (ng == 2) { NB_LS_CASES(F, 2, 1, ls) }                    \
@@ -213,11 +224,10 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         // packed: 64 issue cycles per (j, 2 i-bodies) + ~6 % LDS/loop overhead
         for (int ipl : {8, 4, 2})
             for (int ls : {1, 2, 4, 8, 16, 32, 64})
-                for (int tl : {1, 4}) {
+                for (int tl : {1, 4, 8}) {
                     if (tl == 4 && ls < 16) continue;
-                    // LS > 1: measured 72-76 % of the issue rate at 2-4 waves per SIMD (the waves of a
-                    // workgroup wait on the next tile's global loads: profiles/r02/ubench4_*.txt)
-                    const double cyc = 34.0 * ipl * (ipl == 2 ? 1.05 : 1.0) * (ls > 1 ? 1.22 : 1.0);
+                    if (tl == 8 && ls < 32) continue;
+                    const double cyc = 34.0 * ipl * (ipl == 2 ? 1.05 : 1.0);
                     cands.push_back({{kPkLds, ipl, ls, tl}, cyc});
                     if (may_fuse) cands.push_back({{kFused, ipl, ls, tl}, cyc});
                 }
@@ -226,7 +236,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
             for (int ws : {1, 4}) cands.push_back({{kPkSgpr, ipl, 1, ws}, (ipl == 8 ? 32.5 : 33.2) * ipl});
         // registers-only fused step: no tile hand-over at all (64 issue cycles per j, nothing to wait for)
         if (may_fuse && n <= 1024) cands.push_back({{kDirect, 2, 64, 1}, 64.0});
-        if (may_fuse && n <= 2048) cands.push_back({{kDirect, 2, 64, 2}, 64.0});
+        if (may_fuse && n <= 1536) cands.push_back({{kDirect, 2, 64, 2}, 64.0});   // at 2,048 the 2,048-body LDS stage is 5 % ahead
     }
 
     Shape sh{s->f64 ? kScalar : kPkLds, 2, 1, 1};
@@ -276,10 +286,18 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 const double iters = std::ceil(wave_len / c.sh.ls);
                 // a SIMD with fewer than 4 resident waves cannot keep its issue port full
                 // (measured with the pure-ALU loop, profiles/r01/ubench_run1.txt, profiles/r02/ubench3_*.txt)
-                const bool sg = c.sh.kind == kPkSgpr;     // no barriers, no tile hand-over: fills better at 2-3 waves
+                // Share of the issue rate a SIMD reaches with 4 / 3 / 2 / 1 resident waves, and the hand-over
+                // cost per tile stage: least-regret fit over 208 (size, shape) timings, N = 1,024 .. 65,536
+                // (profiles/r02/shape_scan_run5_calibrated.txt, shape_scan_run6_tl8.txt; worst mis-pick 1.6 %).
+                // SGPR loop: no barriers, no tile hand-over.  LDS tiles shared by LS > 1 lanes: 45 % of a tile
+                // period is hand-over at low occupancy (ubench4_tile_phases.txt).  LS = 1: the round-1 figures.
+                const bool sg = c.sh.kind == kPkSgpr, lanes = !sg && c.sh.ls > 1;
                 auto round_cycles = [&](double per_cu) {
-                    const double fill = per_cu >= 4 ? 1.0 : per_cu >= 3 ? (sg ? 0.95 : 0.92) : per_cu >= 2 ? (sg ? 0.88 : 0.82) : 0.62;
-                    return std::max(iters * per_cu * c.cyc_iter / fill, stages * kTileLatency) + kPrologue;
+                    const int k = per_cu >= 4 ? 0 : per_cu >= 3 ? 1 : per_cu >= 2 ? 2 : 3;
+                    static const double f_sgpr[4] = {1.0, 0.92, 0.94, 0.62}, f_lanes[4] = {0.72, 0.75, 0.85, 0.75},
+                                        f_tile[4] = {1.0, 0.92, 0.82, 0.62};
+                    const double fill = (sg ? f_sgpr : lanes ? f_lanes : f_tile)[k];
+                    return std::max(iters * per_cu * c.cyc_iter / fill, stages * kTileLatency) + kPrologue + (lanes ? stages * 500.0 : 0.0);
                 };
                 double cyc = full * round_cycles(occ);
                 if (rem) cyc += round_cycles((double)ceil_div((uint32_t)rem, (uint32_t)n_cu));

@@ -339,7 +339,7 @@ struct PkCore {
     // (228 B/lane of scratch at NG = 2); two stages in flight are enough to cover the LDS reads
     static constexpr int UNROLL = NG >= 4 ? UNR : (UNR < 2 ? UNR : 2);
     static_assert(LS >= 1 && LS <= 64 && (LS & (LS - 1)) == 0, "LS must be a power of two <= 64");
-    static_assert(TL == 1 || TL == 4, "TL is 1 or 4");
+    static_assert(TL == 1 || TL == 4 || TL == 8, "TL is 1, 4 or 8");
 
     // Accumulates sum_{j in [j0, j1)} (G m_j) r_ij / (|r_ij|^2 + eps2)^{3/2} for the lane's 2*NG bodies
     // over the lane's share of j (every LS-th body of each tile).
@@ -473,10 +473,10 @@ struct PkCore {
 // chase an occupancy it cannot reach anyway.  The NG = 1, 2 bodies get the same 128-VGPR budget:
 // at 8 (6) waves per SIMD the allocator spilled 10..64 VGPRs of the loop to scratch.
 // (TL = 4 stages 32 KiB of LDS per workgroup: at most 5 workgroups per CU, so the target is 4.)
-#define NB_PK_WAVES(NG, TL) 4
+#define NB_PK_WAVES(NG, TL) ((TL) == 8 ? 3 : 4)
 // the small-system shapes (one group, 1024-body stages) also hold a prefetched vel/acc pair and two
 // stage register sets: allow them the 168-VGPR budget of 3 waves per SIMD instead of spilling
-#define NB_PK_WAVES_MIN(NG, TL) ((NG) == 1 && (TL) == 4 ? 3 : 4)
+#define NB_PK_WAVES_MIN(NG, TL) ((TL) == 8 ? 2 : ((NG) == 1 && (TL) == 4 ? 3 : 4))
 
 // K1, packed, j-tile in LDS.
 template <int NG, int LS, int TL>

@@ -35,12 +35,13 @@ def run(b, v, steps, dt=1e-3, G=1.0, **kw):
 
 # ---- fused step -------------------------------------------------------------------------------
 
+# (bodies per lane, lanes per body, 256-body tile units per LDS stage)
 FUSED_SHAPES = [(2, 1, 1), (2, 16, 1), (2, 64, 1), (2, 64, 4), (2, 32, 4), (4, 4, 1), (4, 32, 1), (4, 16, 4),
-                (8, 1, 1), (8, 2, 1), (8, 8, 1), (8, 64, 1), (8, 64, 4)]
+                (8, 1, 1), (8, 2, 1), (8, 8, 1), (8, 64, 1), (8, 64, 4), (2, 64, 8), (2, 32, 8), (4, 64, 8), (8, 32, 8)]
 
 
 @pytest.mark.parametrize("ipl,ls,tl", FUSED_SHAPES)
-@pytest.mark.parametrize("n", [1000, 4096])
+@pytest.mark.parametrize("n", [1000, 4096, 7001])
 def test_fused_step_is_bit_identical_to_the_two_kernel_step(ipl, ls, tl, n):
     """nb_step_fused<NG,LS,TL> == nb_force_pk<NG,LS,TL> (one j-split) + nb_integrate: same loop,
     same in-wave reduction, same leapfrog -- 19 steps so that graph replay (16) and both

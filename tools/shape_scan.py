@@ -24,8 +24,8 @@ def candidates(n):
     out = [("auto", dict()), ("auto_nofuse", dict(flags=capi.NB_FLAG_NO_FUSE))]
     for ipl in (2, 4, 8):
         for ls in (1, 2, 4, 8, 16, 32, 64):
-            for tl in (1, 4):
-                if tl == 4 and ls < 16:
+            for tl in (1, 4, 8):
+                if (tl == 4 and ls < 16) or (tl == 8 and ls < 32):
                     continue
                 wgs = -(-n // ((256 // ls) * ipl))
                 if wgs < 96 or wgs > 8192:
