@@ -354,9 +354,12 @@ def test_frame_feed_does_not_stall_the_step_stream():
             return time.perf_counter() - t0
 
     loop(False)
-    base = min(loop(False), loop(False))
-    feed = min(loop(True), loop(True))
-    assert feed < 1.03 * base, (feed, base)
+    loop(True)                                   # first use allocates the frame slots
+    base, feed = [], []
+    for _ in range(3):                           # interleaved, best of three each (rule 24: A/B in one process)
+        base.append(loop(False))
+        feed.append(loop(True))
+    assert min(feed) < 1.03 * min(base), (feed, base)
 
 
 def test_integrate_pass_measures_the_integrator_alone():
