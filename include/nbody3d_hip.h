@@ -101,7 +101,8 @@ typedef struct nb_config {
                                j-bodies in registers (N <= 1,024 * X; II = 02, LL = 64); II = bodies per
                                lane (01..08); LL = lanes sharing a body (01..64); X = tile
                                units (256 bodies) per LDS stage (K = 2, 4: 1, 4 or 8) or waves splitting j
-                               (K = 3: 1 or 4).  E.g. 402644.  See nb_variant_name().    */
+                               (K = 3: 1 or 4; 5 = 4 waves with 64-bit pair loads).  E.g. 402644.
+                               See nb_variant_name().                              */
     uint32_t jsplit;        /* number of j-partitions (grid.y)                  */
     uint32_t flags;         /* NB_FLAG_*                                        */
     uint32_t reserved[5];

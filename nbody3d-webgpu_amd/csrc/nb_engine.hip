@@ -54,6 +54,7 @@ enum Kind { kScalar = 1, kPkLds = 2, kPkSgpr = 3, kFused = 4, kDirect = 5 };   /
 struct Shape { int kind, ipl, ls, x; };   // x: tile units (LDS kinds) or j-splitting waves (SGPR kind)
 
 bool pow2(int v) { return v >= 1 && (v & (v - 1)) == 0; }
+int sgpr_ws(int x) { return x == 5 ? 4 : x; }   // SGPR kind: x = 5 is WS = 4 with 64-bit pair loads
 
 // ---- kernel tables ---------------------------------------------------------------------------
 // packed LDS kernels: NG in {1,2,4}, LS in {1,2,4,8,16,32,64}, TL = 1; TL = 4 for LS >= 16
@@ -123,6 +124,7 @@ const void* scalar_kernel(int ipl, int ls)
 const void* sgpr_kernel(int ipl, int ws)
 {
     if (ipl == 4) return ws == 4 ? (const void*)&nb::nb_force_pk_sgpr<2, 4> : (const void*)&nb::nb_force_pk_sgpr<2, 1>;
+    if (ipl == 8 && ws == 5) return (const void*)&nb::nb_force_pk_sgpr<4, 4, true>;     // A/B arm: 64-bit pair loads
     if (ipl == 8) return ws == 4 ? (const void*)&nb::nb_force_pk_sgpr<4, 4> : (const void*)&nb::nb_force_pk_sgpr<4, 1>;
     return nullptr;
 }
@@ -134,7 +136,7 @@ const void* kernel_of(bool f64, const Shape& sh)
         case kScalar: return f64 ? scalar_kernel<double>(sh.ipl, sh.ls) : scalar_kernel<float>(sh.ipl, sh.ls);
         case kPkLds: return f64 || (sh.ipl & 1) ? nullptr : pk_force_kernel(sh.ipl / 2, sh.ls, sh.x);
         case kFused: return f64 || (sh.ipl & 1) ? nullptr : pk_fused_kernel(sh.ipl / 2, sh.ls, sh.x);
-        case kPkSgpr: return f64 || sh.ls != 1 || !(sh.x == 1 || sh.x == 4) ? nullptr : sgpr_kernel(sh.ipl, sh.x);
+        case kPkSgpr: return f64 || sh.ls != 1 || !(sh.x == 1 || sh.x == 4 || sh.x == 5) ? nullptr : sgpr_kernel(sh.ipl, sh.x);
         case kDirect:
             if (f64 || sh.ipl != 2 || sh.ls != 64) return nullptr;
             return sh.x == 1 ? (const void*)&nb::nb_step_direct<16> : sh.x == 2 ? (const void*)&nb::nb_step_direct<32> : nullptr;
@@ -145,7 +147,7 @@ const void* kernel_of(bool f64, const Shape& sh)
 // i-bodies per workgroup
 uint32_t ipb_of(const Shape& sh)
 {
-    if (sh.kind == kPkSgpr) return (uint32_t)(nb::kBlock / sh.x) * sh.ipl;
+    if (sh.kind == kPkSgpr) return (uint32_t)(nb::kBlock / sgpr_ws(sh.x)) * sh.ipl;
     return (uint32_t)(nb::kBlock / sh.ls) * sh.ipl;
 }
 
@@ -178,7 +180,7 @@ void name_variant(nb_sim* s, const Shape& sh)
 {
     char buf[112];
     if (sh.kind == kPkSgpr)
-        snprintf(buf, sizeof buf, "f32pk_sgpr_ipl%d%s_js%u", sh.ipl, sh.x == 4 ? "_ws4" : "", s->jsplit);
+        snprintf(buf, sizeof buf, "f32pk_sgpr_ipl%d%s_js%u", sh.ipl, sh.x == 4 ? "_ws4" : sh.x == 5 ? "_ws4p" : "", s->jsplit);
     else if (sh.kind == kFused)
         snprintf(buf, sizeof buf, "f32pk_fused_lds%d_ipl%d_ls%d", nb::kTile * sh.x, sh.ipl, sh.ls);
     else if (sh.kind == kDirect)
@@ -234,6 +236,11 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         // SGPR loop: 8 bodies per lane measured ~2 % ahead of 4 (profiles/r02/shape_scan_*.txt)
         for (int ipl : {8, 4})
             for (int ws : {1, 4}) cands.push_back({{kPkSgpr, ipl, 1, ws}, (ipl == 8 ? 32.5 : 33.2) * ipl});
+        // the same loop with every body loaded as two SGPR pairs (8 s_load_dwordx2 per 4 bodies): the backend
+        // then folds z and the mass into the packed ops too (no v_mov: 448 instead of 456 VALU instructions per
+        // 8 bodies).  Measured +0.4..1.2 % on 8,192-body waves, -1.2 % on 2,048-body ones
+        // (profiles/r02/sweep_sgpr_pair_loads.txt): only offered to long loops (below).
+        cands.push_back({{kPkSgpr, 8, 1, 5}, 32.5 * 8 * 0.993});
         // registers-only fused step: no tile hand-over at all (64 issue cycles per j, nothing to wait for)
         if (may_fuse && n <= 1024) cands.push_back({{kDirect, 2, 64, 1}, 64.0});
         if (may_fuse && n <= 1536) cands.push_back({{kDirect, 2, 64, 2}, 64.0});   // at 2,048 the 2,048-body LDS stage is 5 % ahead
@@ -277,11 +284,12 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
             if (c.sh.kind == kFused || c.sh.kind == kDirect) { if (cfg.jsplit > 1) continue; js_lo = js_top = 1; }
             for (uint32_t q = js_lo; q <= js_top; ++q) {
                 const uint32_t len = split_len(q), used = ceil_div(n, len);
-                if (c.sh.kind == kPkSgpr && len / c.sh.x < 256) continue;   // SGPR loop wants >= 256 bodies per wave
+                if (c.sh.kind == kPkSgpr && len / sgpr_ws(c.sh.x) < 256) continue;   // SGPR loop wants >= 256 bodies per wave
+                if (c.sh.kind == kPkSgpr && c.sh.x == 5 && len / 4 < 6144) continue;        // pair loads: long loops only
                 const uint64_t blocks = (uint64_t)iblocks * used;
                 const uint64_t full = blocks / slots, rem = blocks % slots;
                 const double tile = c.sh.kind == kPkSgpr ? 256.0 : 256.0 * c.sh.x;
-                const double wave_len = c.sh.kind == kPkSgpr ? (double)len / c.sh.x : (double)len;
+                const double wave_len = c.sh.kind == kPkSgpr ? (double)len / sgpr_ws(c.sh.x) : (double)len;
                 const double stages = c.sh.kind == kDirect ? 0.5 : std::ceil(wave_len / tile);
                 const double iters = std::ceil(wave_len / c.sh.ls);
                 // a SIMD with fewer than 4 resident waves cannot keep its issue port full
@@ -308,7 +316,9 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 // K2 reads every split's partial back (and K1 writes it): priced at 2 TB/s so that, when the
                 // balance gain is a wash (N = 262,144: 8 vs 16 splits), the smaller HBM footprint wins
                 const double after = (c.sh.kind == kFused || c.sh.kind == kDirect) ? 0.0 : (double)used * sc * 4 * s->esz / 2.0e12 + 3e-6;
-                const double t = std::max(cyc / kClock, stream_s) / (1.0 - 0.03 / rounds) + after;
+                // balance: the last round runs partly empty and the first at a lower clock.  SGPR kernel at
+                // N = 262,144: 2 / 3 / 4 / 6 / 8 rounds lose 2.0 / 1.1 / 0.7 / 0.5 / 0 % (sweep_sgpr_pair_loads.txt)
+                const double t = std::max(cyc / kClock, stream_s) / (1.0 - (sg ? 0.045 : 0.03) / rounds) + after;
                 scored.push_back({c.sh, q, t});
                 if (t < best_t) best_t = t;
             }

@@ -691,7 +691,7 @@ void nb_step_direct(const float4* __restrict__ bodies_in, float4* __restrict__ b
 //           workgroup's j-range; their sums are added through LDS in wave order (deterministic)
 //           and ONE partial is stored: a quarter of the j-splits, partial arrays and K2 traffic
 //           for the same grid size and the same work per wave.
-template <int NG, int WS>
+template <int NG, int WS, bool PAIRS = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NG >= 4 ? 4 : 6, NG >= 4 ? 4 : 6)))
 void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ partial, uint32_t n, uint32_t i_begin,
                       uint32_t i_count, float G, float eps2, uint32_t j_per_split, SplitWindow win)
@@ -797,7 +797,45 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
     const uint32_t nb8 = j1 > j0 ? (j1 - j0) / 8 : 0;
     const float4* pj = bodies + j0;
     uint32_t j = j0;
-    if (nb8) {
+    if constexpr (PAIRS) {
+        // A/B arm: every body as two 64-bit SGPR pairs (x,y) and (z,m), 8 s_load_dwordx2 per 4 bodies, so
+        // that all four broadcasts fold into the packed ops as SGPR operands (no v_mov for z and m)
+        struct Oct { nb_f2 p[8]; };
+        auto f4p = [](const nb_f2& xy, const nb_f2& zm) { return float4{xy.x, xy.y, zm.x, zm.y}; };
+#define NB_ACC4 "+v"(ax[0]), "+v"(ax[1]), "+v"(ax[2]), "+v"(ax[3]), "+v"(ay[0]), "+v"(ay[1]), "+v"(ay[2]), "+v"(ay[3]), \
+                "+v"(az[0]), "+v"(az[1]), "+v"(az[2]), "+v"(az[3])
+#define NB_ACC2 "+v"(ax[0]), "+v"(ax[1]), "+v"(ay[0]), "+v"(ay[1]), "+v"(az[0]), "+v"(az[1])
+#define NB_OCT(q) (q).p[0], (q).p[1], (q).p[2], (q).p[3], (q).p[4], (q).p[5], (q).p[6], (q).p[7]
+        auto wait8 = [&](Oct& q) {
+            if constexpr (NG == 4) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.p[0]), "+s"(q.p[1]), "+s"(q.p[2]), "+s"(q.p[3]), "+s"(q.p[4]), "+s"(q.p[5]), "+s"(q.p[6]), "+s"(q.p[7]), NB_ACC4 : : "memory");
+            else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q.p[0]), "+s"(q.p[1]), "+s"(q.p[2]), "+s"(q.p[3]), "+s"(q.p[4]), "+s"(q.p[5]), "+s"(q.p[6]), "+s"(q.p[7]), NB_ACC2 : : "memory");
+        };
+#define NB_LOAD8(o) "s_load_dwordx2 %0, %" #o ", 0x0\n\ts_load_dwordx2 %1, %" #o ", 0x8\n\ts_load_dwordx2 %2, %" #o ", 0x10\n\t" \
+                    "s_load_dwordx2 %3, %" #o ", 0x18\n\ts_load_dwordx2 %4, %" #o ", 0x20\n\ts_load_dwordx2 %5, %" #o ", 0x28\n\t" \
+                    "s_load_dwordx2 %6, %" #o ", 0x30\n\ts_load_dwordx2 %7, %" #o ", 0x38"
+        auto request8 = [&](Oct& q, const float4* p) {
+            if constexpr (NG == 4) asm volatile(NB_LOAD8(20) : "=&s"(q.p[0]), "=&s"(q.p[1]), "=&s"(q.p[2]), "=&s"(q.p[3]), "=&s"(q.p[4]), "=&s"(q.p[5]), "=&s"(q.p[6]), "=&s"(q.p[7]), NB_ACC4 : "s"(p) : "memory");
+            else asm volatile(NB_LOAD8(14) : "=&s"(q.p[0]), "=&s"(q.p[1]), "=&s"(q.p[2]), "=&s"(q.p[3]), "=&s"(q.p[4]), "=&s"(q.p[5]), "=&s"(q.p[6]), "=&s"(q.p[7]), NB_ACC2 : "s"(p) : "memory");
+        };
+#undef NB_LOAD8
+#undef NB_OCT
+#undef NB_ACC2
+#undef NB_ACC4
+        if (nb8) {
+            Oct A, B;
+            request8(A, pj);
+            for (uint32_t it = 0; it < nb8; ++it) {
+                wait8(A);
+                request8(B, pj + 4);
+                eval4(f4p(A.p[0], A.p[1]), f4p(A.p[2], A.p[3]), f4p(A.p[4], A.p[5]), f4p(A.p[6], A.p[7]));
+                wait8(B);
+                pj += 8;
+                if (it + 1 < nb8) request8(A, pj);
+                eval4(f4p(B.p[0], B.p[1]), f4p(B.p[2], B.p[3]), f4p(B.p[4], B.p[5]), f4p(B.p[6], B.p[7]));
+            }
+            j += nb8 * 8;
+        }
+    } else if (nb8) {
         Quad A, B;
         request(A, pj);
         for (uint32_t it = 0; it < nb8; ++it) {

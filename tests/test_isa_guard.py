@@ -27,9 +27,10 @@ def kernel_bodies():
     subprocess.check_call(["make", "-C", CSRC, "-s", "asm"])
     text = open(ASM).read()
     out = {}
-    # nb_force_pk_sgpr<NG, WS>: NG in {2, 4} packed groups, WS in {1, 4} j-splitting waves
-    for m in re.finditer(r"^(_ZN2nb16nb_force_pk_sgprILi(\d)ELi(\d)EEE\w+):\s*;.*?$(.*?)s_endpgm", text, re.S | re.M):
-        out[(int(m.group(2)), int(m.group(3)))] = m.group(4).splitlines()
+    # nb_force_pk_sgpr<NG, WS, PAIRS>: NG in {2, 4} packed groups, WS in {1, 4} j-splitting waves,
+    # PAIRS: bodies fetched as 64-bit pairs (s_load_dwordx2) instead of quads (s_load_dwordx4)
+    for m in re.finditer(r"^(_ZN2nb16nb_force_pk_sgprILi(\d)ELi(\d)ELb([01])EEE\w+):\s*;.*?$(.*?)s_endpgm", text, re.S | re.M):
+        out[(int(m.group(2)), int(m.group(3)), int(m.group(4)))] = m.group(5).splitlines()
     return out
 
 
@@ -45,7 +46,7 @@ def sregs(operand_text):
 
 def test_no_instruction_touches_a_requested_sgpr_before_its_wait():
     bodies = kernel_bodies()
-    assert set(bodies) == {(2, 1), (2, 4), (4, 1), (4, 4)}, "expected all four nb_force_pk_sgpr instantiations"
+    assert set(bodies) == {(2, 1, 0), (2, 4, 0), (4, 1, 0), (4, 4, 0), (4, 4, 1)}, "expected all five nb_force_pk_sgpr instantiations"
     for ng, lines in bodies.items():
         pending = set()
         requests = waits = 0
@@ -63,7 +64,7 @@ def test_no_instruction_touches_a_requested_sgpr_before_its_wait():
             op, _, rest = code.partition(" ")
             # only the hand-placed requests (inside asm statements) are untracked by hipcc;
             # its own scalar loads (kernel arguments) get compiler-inserted waits
-            if op == "s_load_dwordx4" and in_asm:
+            if op in ("s_load_dwordx4", "s_load_dwordx2") and in_asm:
                 dst = rest.split(",")[0]
                 src = ",".join(rest.split(",")[1:])
                 # the address registers of a request must not be pending either

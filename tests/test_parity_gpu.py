@@ -26,7 +26,7 @@ TOL_POS, TOL_TIGHT, TOL_ACC = 1e-4, 2e-5, 2e-5
 VARIANTS = [(0, 0), (1, 1), (1, 3), (2, 1), (2, 2), (4, 1), (4, 4), (14, 1), (14, 2), (116, 1), (164, 1), (164, 2),
             (22, 1), (22, 3), (24, 1), (24, 2), (28, 1), (28, 2), (34, 1), (34, 3), (38, 1), (38, 2),
             (202021, 1), (202164, 2), (202644, 1), (204081, 3), (204324, 1), (208161, 2), (208644, 1),
-            (304014, 1), (304014, 3), (308014, 1), (308014, 2),
+            (304014, 1), (304014, 3), (308014, 1), (308014, 2), (308015, 1), (308015, 3),
             (402011, 0), (402161, 0), (402644, 0), (404041, 0), (404324, 0), (408011, 0), (408161, 0), (408644, 0)]
 
 
@@ -169,7 +169,7 @@ def test_ragged_sizes(n):
 
 
 @pytest.mark.parametrize("n", [9, 263, 1001, 4099])
-@pytest.mark.parametrize("variant", [34, 38, 304014, 308014])
+@pytest.mark.parametrize("variant", [34, 38, 304014, 308014, 308015])
 def test_ragged_sizes_on_the_sgpr_kernel(n, variant):
     """The SGPR-broadcast kernel walks j in batches of 8 with a scalar remainder loop:
     N not a multiple of 8 (and splits that end mid-batch) must still match the oracle."""
