@@ -198,7 +198,7 @@ void name_variant(nb_sim* s, const Shape& sh)
 //       compute  = loop iterations per wave * SIMD cycles per iteration * resident workgroups
 //                  per CU (the waves of a SIMD share its issue port) / fill
 //       latency  = tile stages per wave * ~3000 cycles (global load + LDS store + barrier)
-//       balance  = 1 - 0.03 / rounds (more rounds even out DVFS/tail: +3..4 % from 1 to 4)
+//       balance  = 1 - 0.03 / rounds, 0.045 for the SGPR kernel (more rounds even out DVFS/tail)
 //       follows  = two-kernel step: the K1 -> K2 boundary (~1.5 us) + K2 reading every split's
 //                  partial back; fused step: nothing (its epilogue is the integrator)
 //   and keeps the minimum.  A split is any multiple of 8 bodies >= 128 -- not a multiple of
