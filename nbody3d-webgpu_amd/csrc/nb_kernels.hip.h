@@ -426,7 +426,11 @@ struct PkCore {
 
         for (uint32_t t = 0; t < ntiles; ++t) {
             const int cur = t & 1;
+#ifdef NB_FAKE_STAGING   // diagnostic upper bound only (tools/ubench4.hip): no tile hand-over after the first tile
+            const bool more = false;
+#else
             const bool more = (t + 1 < ntiles);
+#endif
             if (t == 1) NB_STAMP_LIGHT(8);
             if (more) load(t + 1);
             if (t == 1) NB_STAMP_LIGHT(9);
@@ -445,7 +449,9 @@ struct PkCore {
             if (t == 1) NB_STAMP_LIGHT(10);
             if (more) store(cur ^ 1);
             if (t == 1) NB_STAMP_LIGHT(11);
+#ifndef NB_FAKE_STAGING
             __syncthreads();
+#endif
             if (t == 1) NB_STAMP_LIGHT(12);
         }
         NB_STAMP(2);
