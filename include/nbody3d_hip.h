@@ -62,6 +62,9 @@ typedef enum nb_precision { NB_F32 = 0, NB_F64 = 1 } nb_precision;
 #define NB_FLAG_LDS_ONLY 4u  /* tuning/A-B: never pick the SGPR-broadcast force kernel */
 #define NB_FLAG_NO_FUSE 8u   /* tuning/A-B: never pick the fused one-launch step (force kernel +
                                 integrate kernel instead; bit-identical results) */
+#define NB_FLAG_POISON 16u   /* validation: the j-packed step (K = 6) overwrites every partial sum with NaN
+                                once its i-block is reduced, so a partial that is ever read stale (a missing
+                                release / acquire between workgroups) shows as NaN instead of a small error */
 
 /* nb_array: selector for nb_device_ptr */
 typedef enum nb_array { NB_BODIES = 0, NB_VEL = 1, NB_ACCEL = 2 } nb_array;
@@ -102,6 +105,10 @@ typedef struct nb_config {
                                lane (01..08); LL = lanes sharing a body (01..64); X = tile
                                units (256 bodies) per LDS stage (K = 2, 4: 1, 4 or 8) or waves splitting j
                                (K = 3: 1 or 4; 5 = 4 waves with 64-bit pair loads).  E.g. 402644.
+                               K = 6: fused step with two j-bodies per packed instruction streamed
+                               from a pair-transposed copy of the positions (II = 01, LL = 01;
+                               X = waves per workgroup splitting j: 4, 8, or 6 for 16); jsplit > 1
+                               splits j over workgroups too (reduced in the same launch).
                                See nb_variant_name().                              */
     uint32_t jsplit;        /* number of j-partitions (grid.y)                  */
     uint32_t flags;         /* NB_FLAG_*                                        */

@@ -50,11 +50,12 @@ using nbi::fail;
 
 uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-enum Kind { kScalar = 1, kPkLds = 2, kPkSgpr = 3, kFused = 4, kDirect = 5 };   // kDirect: fused, registers only (x = MAXJ/16)
+enum Kind { kScalar = 1, kPkLds = 2, kPkSgpr = 3, kFused = 4, kDirect = 5, kJpk = 6 };   // kDirect: fused, registers only (x = MAXJ/16)
 struct Shape { int kind, ipl, ls, x; };   // x: tile units (LDS kinds) or j-splitting waves (SGPR kind)
 
 bool pow2(int v) { return v >= 1 && (v & (v - 1)) == 0; }
 int sgpr_ws(int x) { return x == 5 ? 4 : x; }   // SGPR kind: x = 5 is WS = 4 with 64-bit pair loads
+int jpk_ws(int x) { return x == 6 ? 16 : x; }    // j-packed kind: x = 6 is 16 waves per workgroup
 
 // ---- kernel tables ---------------------------------------------------------------------------
 // packed LDS kernels: NG in {1,2,4}, LS in {1,2,4,8,16,32,64}, TL = 1; TL = 4 for LS >= 16
@@ -140,6 +141,10 @@ const void* kernel_of(bool f64, const Shape& sh)
         case kDirect:
             if (f64 || sh.ipl != 2 || sh.ls != 64) return nullptr;
             return sh.x == 1 ? (const void*)&nb::nb_step_direct<16> : sh.x == 2 ? (const void*)&nb::nb_step_direct<32> : nullptr;
+        case kJpk:
+            if (f64 || sh.ipl != 1 || sh.ls != 1) return nullptr;
+            return sh.x == 4 ? (const void*)&nb::nb_step_jpk<4> : sh.x == 8 ? (const void*)&nb::nb_step_jpk<8>
+                   : sh.x == 6 ? (const void*)&nb::nb_step_jpk<16> : nullptr;
         default: return nullptr;
     }
 }
@@ -147,6 +152,7 @@ const void* kernel_of(bool f64, const Shape& sh)
 // i-bodies per workgroup
 uint32_t ipb_of(const Shape& sh)
 {
+    if (sh.kind == kJpk) return 64;
     if (sh.kind == kPkSgpr) return (uint32_t)(nb::kBlock / sgpr_ws(sh.x)) * sh.ipl;
     return (uint32_t)(nb::kBlock / sh.ls) * sh.ipl;
 }
@@ -170,7 +176,7 @@ bool decode_variant(uint32_t v, Shape* out)
     }
     if (v < 100000) return false;
     Shape sh{(int)(v / 100000), (int)(v / 1000 % 100), (int)(v / 10 % 100), (int)(v % 10)};
-    if (sh.kind < kScalar || sh.kind > kDirect || !pow2(sh.ls)) return false;
+    if (sh.kind < kScalar || sh.kind > kJpk || !pow2(sh.ls)) return false;
     if (sh.kind == kScalar) sh.x = 1;
     *out = sh;
     return true;
@@ -185,6 +191,8 @@ void name_variant(nb_sim* s, const Shape& sh)
         snprintf(buf, sizeof buf, "f32pk_fused_lds%d_ipl%d_ls%d", nb::kTile * sh.x, sh.ipl, sh.ls);
     else if (sh.kind == kDirect)
         snprintf(buf, sizeof buf, "f32pk_fused_regs%d_ipl%d_ls%d", 64 * 16 * sh.x, sh.ipl, sh.ls);
+    else if (sh.kind == kJpk)
+        snprintf(buf, sizeof buf, "f32pk_fused_jpairs_ws%d_js%u", jpk_ws(sh.x), s->jsplit);
     else
         snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.kind == kPkLds ? "pk" : "",
                  nb::kTile * (sh.kind == kPkLds ? sh.x : 1), sh.ipl, sh.ls, s->jsplit);
@@ -256,6 +264,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
             if (s->f64 && want.kind != kScalar) want = {kScalar, want.ipl > 4 ? 4 : want.ipl, 1, 1};
             if ((want.kind == kFused || want.kind == kDirect) && !may_fuse && !s->f64) want = {kPkLds, want.ipl, want.ls, 1};   // same loop, two kernels
             if (want.kind == kDirect && n > 1024u * (uint32_t)want.x) want = {kFused, 2, 64, 4};
+            if (want.kind == kJpk && !may_fuse) want = {kPkSgpr, 4, 1, 4};      // whole-system f32 handles only
             if (kernel_of(s->f64, want)) { sh = want; pinned = true; }
         }
     }
@@ -323,6 +332,43 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 if (t < best_t) best_t = t;
             }
         }
+        // The j-packed fused step (force_variant K = 6; whole-system f32 handles): 64 i-bodies per workgroup of ws
+        // waves, the j-pairs split over ws waves x q workgroups.  One scalar request (4 pairs, 256 issue cycles)
+        // is in flight per wave and returns after ~1,100 cycles, so a SIMD needs > 4 resident waves to stay
+        // busy.  NOT offered by the automatic choice: through the engine it is within +-2 % of the SGPR two-kernel
+        // step from N = 8,192 to 65,536 (best case N = 16,384: 67.4 vs 68.7 us) and behind it in between
+        // (profiles/r02/shape_scan_jpk.txt, ubench5_*.txt); this model only picks the split count of a pinned shape.
+        if (may_fuse && pinned && sh.kind == kJpk) {
+            const uint32_t units = ((ceil_div(ceil_div(n, 2u), 4u) + 1u) & ~1u);
+            for (int x : {4, 8, 6}) {
+                const Shape jsh{kJpk, 1, 1, x};
+                if (sh.x != x) continue;
+                const int ws = jpk_ws(x);
+                int occ = 0;
+                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel_of(false, jsh), 64 * ws, 0) != hipSuccess || occ < 1) {
+                    (void)hipGetLastError();
+                    occ = 28 / ws;
+                }
+                const uint32_t iblocks = ceil_div(n, 64u);
+                const uint32_t q_lo = cfg.jsplit ? cfg.jsplit : 1, q_hi = cfg.jsplit ? cfg.jsplit : 16;
+                for (uint32_t q = q_lo; q <= q_hi; ++q) {
+                    const uint32_t upw = 2 * ceil_div(units / 2, (uint32_t)ws * q);
+                    if (upw < 8 && !cfg.jsplit && q > 1) continue;              // at least 64 bodies per wave
+                    const uint64_t blocks = (uint64_t)iblocks * q, slots = (uint64_t)occ * n_cu;
+                    const uint64_t full = blocks / slots, rem = blocks % slots;
+                    auto round_cycles = [&](double per_cu) {
+                        const double waves_per_simd = per_cu * ws / 4.0;
+                        return upw * std::max(260.0 * waves_per_simd, 1100.0) + 4000.0;
+                    };
+                    double cyc = full * round_cycles(occ);
+                    if (rem) cyc += round_cycles((double)ceil_div((uint32_t)rem, (uint32_t)n_cu));
+                    const double rounds = (double)full + (rem ? 1 : 0);
+                    const double t = cyc / kClock / (1.0 - 0.03 / rounds) + (q > 1 ? 2.5e-6 : 0.0);
+                    scored.push_back({jsh, q, t});
+                    if (t < best_t) best_t = t;
+                }
+            }
+        }
         // Among the shapes within 0.4 % of the best estimate take the one with the FEWEST j-splits:
         // measured at N = 262,144, 8 / 16 / 32 splits differ by 0.1-0.3 % in step time
         // (profiles/r02/sweep_jsplit_n262144.txt) while every split is another partial array
@@ -342,10 +388,23 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
     }
     if (sh.kind == kFused || sh.kind == kDirect) js = 1;
     s->ipl = sh.ipl; s->ls = sh.ls;
-    s->packed = sh.kind != kScalar; s->sgpr = sh.kind == kPkSgpr; s->fused = sh.kind == kFused || sh.kind == kDirect;
+    s->packed = sh.kind != kScalar; s->sgpr = sh.kind == kPkSgpr;
+    s->fused = sh.kind == kFused || sh.kind == kDirect || sh.kind == kJpk;
     s->direct = sh.kind == kDirect;
-    s->ws = sh.kind == kPkSgpr ? sh.x : 1;
+    s->jpk = sh.kind == kJpk;
+    s->ws = (sh.kind == kPkSgpr || sh.kind == kJpk) ? sh.x : 1;
     s->tl = (sh.kind == kPkLds || sh.kind == kFused || sh.kind == kDirect) ? sh.x : 1;
+    if (s->jpk) {
+        // j in whole 4-pair units, an even number per wave; splits that would be empty are dropped
+        const uint32_t units = ((ceil_div(ceil_div(n, 2u), 4u) + 1u) & ~1u);
+        if (js > 64) js = 64;
+        s->junits = 2 * ceil_div(units / 2, (uint32_t)jpk_ws(sh.x) * js);
+        s->jsplit = ceil_div(units, s->junits * (uint32_t)jpk_ws(sh.x));
+        s->j_per_split = s->junits * (uint32_t)jpk_ws(sh.x) * 8;
+        s->swap_acc = false; s->own_split0 = 0; s->own_splits = 0;
+        name_variant(s, sh);
+        return;
+    }
     s->j_per_split = split_len(js);
     s->jsplit = ceil_div(n, s->j_per_split);   // a split may end up empty after rounding
     s->swap_acc = !s->fused && s->jsplit == 1;
@@ -363,6 +422,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
 
 Shape shape_of(const nb_sim* s)
 {
+    if (s->jpk) return {kJpk, 1, 1, s->ws};
     if (s->direct) return {kDirect, s->ipl, s->ls, s->tl};
     if (s->fused) return {kFused, s->ipl, s->ls, s->tl};
     if (s->sgpr) return {kPkSgpr, s->ipl, 1, s->ws};
@@ -400,8 +460,39 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
 }
 
 // The fused one-launch step: reads bodies[cur], writes bodies[cur ^ 1], then the roles flip.
+// The pair-transposed copy the j-packed step streams from: rebuilt from bodies[cur] whenever the positions
+// were written from outside the step (upload, a raw device pointer handed out) or G changed (it is folded
+// into the mass lanes); the step itself keeps it current.
+void ensure_pairs(nb_sim* s)
+{
+    if (!s->jpk || (s->pairs_ok && s->pairs_G == s->G)) return;
+    const float4* b = (const float4*)s->bodies[s->cur];
+    float4* p = (float4*)s->pairs[s->cur];
+    uint32_t n = s->n;
+    float G = (float)s->G;
+    void* args[] = {&b, &p, &n, &G};
+    (void)hipLaunchKernel((const void*)&nb::nb_pairs_pack<0>, dim3(ceil_div(ceil_div(n, 2u), nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream);
+    s->pairs_ok = true; s->pairs_G = s->G;
+}
+
+void launch_jpk(nb_sim* s, hipEvent_t t0, hipEvent_t t1)
+{
+    const Shape sh = shape_of(s);
+    dim3 grid(ceil_div(s->n, 64u), s->jsplit), block(64 * jpk_ws(sh.x));
+    const float4 *bin = (const float4*)s->bodies[s->cur], *pin = (const float4*)s->pairs[s->cur];
+    float4 *bout = (float4*)s->bodies[s->cur ^ 1], *pout = (float4*)s->pairs[s->cur ^ 1];
+    float4 *v = (float4*)s->vel, *a = (float4*)s->acc, *part = (float4*)s->jpartial;
+    uint32_t* tk = s->tickets;
+    uint32_t n = s->n, upw = s->junits, poison = s->poison ? 1u : 0u;
+    float G = (float)s->G, e2 = (float)s->eps2, dt = (float)s->dt;
+    void* args[] = {&bin, &pin, &bout, &pout, &v, &a, &part, &tk, &n, &upw, &poison, &G, &e2, &dt};
+    launch_kernel(kernel_of(false, sh), grid, block, args, s->stream, t0, t1);
+    s->cur ^= 1;
+}
+
 void launch_fused(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr)
 {
+    if (s->jpk) { ensure_pairs(s); launch_jpk(s, t0, t1); return; }
     const Shape sh = shape_of(s);
     dim3 grid(ceil_div(s->n, ipb_of(sh))), block(nb::kBlock);
     const float4* bin = (const float4*)s->bodies[s->cur];
@@ -473,6 +564,7 @@ bool ensure_graph(nb_sim* s, int which)
     if (slot.graph) { (void)hipGraphDestroy(slot.graph); slot.graph = nullptr; }
     void *acc0 = s->acc, *par0 = s->partial;
     const int cur0 = s->cur, par_bit0 = s->acc_parity;
+    ensure_pairs(s);             // not part of the captured steps
     if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { s->graphs_ok = false; return false; }
     for (uint32_t k = 0; k < kGraphSteps[which]; ++k) launch_step(s);
     hipGraph_t g = nullptr;
@@ -607,6 +699,21 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     NB_HIPC(hipMalloc(&s->vel, row * s->sc));
     NB_HIPC(hipMalloc(&s->acc, row * s->sc));
     if (!s->fused) NB_HIPC(hipMalloc(&s->partial, row * s->sc * s->jsplit));
+    if (s->jpk) {
+        // pairs: whole 4-pair units (128 B) plus one spare the loop's last request may touch; everything past the
+        // system stays zero (zero-mass bodies at the origin).  Partials: 64 rows per (split, i-block).
+        const size_t pbytes = ((size_t)ceil_div(ceil_div(s->n, 2u), 4u) + 3) * 128;
+        const uint32_t iblocks = ceil_div(s->n, 64u);
+        for (auto& p : s->pairs) { NB_HIPC(hipMalloc(&p, pbytes)); NB_HIPC(hipMemset(p, 0, pbytes)); }
+        NB_HIPC(hipMalloc((void**)&s->tickets, sizeof(uint32_t) * iblocks));
+        NB_HIPC(hipMemset(s->tickets, 0, sizeof(uint32_t) * iblocks));
+        if (s->jsplit > 1) {
+            NB_HIPC(hipMalloc(&s->jpartial, (size_t)16 * 64 * iblocks * s->jsplit));
+            NB_HIPC(hipMemset(s->jpartial, 0xff, (size_t)16 * 64 * iblocks * s->jsplit));   // NaN until written
+        }
+        NB_HIPC(hipDeviceSynchronize());
+        s->poison = (cfg.flags & NB_FLAG_POISON) != 0;
+    }
     s->diag_blocks = ceil_div(s->sc, nb::kBlock);
     NB_HIPC(hipMalloc((void**)&s->diag, sizeof(double) * 5 * s->diag_blocks));
 #undef NB_HIPC
@@ -632,6 +739,9 @@ void nb_destroy(nb_sim* s)
     if (s->vel) (void)hipFree(s->vel);
     if (s->acc) (void)hipFree(s->acc);
     if (s->partial) (void)hipFree(s->partial);
+    for (auto& p : s->pairs) if (p) (void)hipFree(p);
+    if (s->jpartial) (void)hipFree(s->jpartial);
+    if (s->tickets) (void)hipFree(s->tickets);
     if (s->diag) (void)hipFree(s->diag);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
@@ -660,6 +770,7 @@ int nb_upload(nb_sim* s, const void* bodies, const void* vel, const void* accel)
         NB_HIP(s, hipStreamSynchronize(s->stream));
     }
     s->uploaded = true;
+    s->pairs_ok = false;
     return NB_OK;
 }
 
@@ -764,7 +875,7 @@ int nb_device_ptr(nb_sim* s, int which, void** out)
 {
     if (!s || !out) return NB_ERR_INVALID;
     switch (which) {
-        case NB_BODIES: *out = s->bodies[s->cur]; break;
+        case NB_BODIES: *out = s->bodies[s->cur]; s->pairs_ok = false; break;   // the caller may write through it
         case NB_VEL: *out = s->vel; break;
         case NB_ACCEL: *out = s->acc; break;
         default: return fail(s, NB_ERR_INVALID, "nb_device_ptr: unknown array");

@@ -60,6 +60,16 @@ struct nb_sim {
     int tl = 1;            // LDS kernels: 256-body tiles staged at once (1 or 4)
     bool fused = false;    // nb_step_fused / nb_step_direct: K2 folded into K1's epilogue (jsplit == 1, whole system)
     bool direct = false;   // nb_step_direct: the fused step with each lane's j-bodies in registers (N <= 2,048)
+    // nb_step_jpk: the fused step with the j-bodies streamed as SGPR pairs from a pair-transposed copy
+    // of the positions (pairs[k] goes with bodies[k]); js > 1 splits j over workgroups that meet at a ticket
+    bool jpk = false;
+    void* pairs[2] = {nullptr, nullptr};
+    bool pairs_ok = false;         // pairs[cur] matches bodies[cur] and pairs_G
+    double pairs_G = 0.0;          // G folded into the mass lanes of pairs[cur]
+    void* jpartial = nullptr;      // jsplit x 64-row blocks of partial sums (jsplit > 1)
+    uint32_t* tickets = nullptr;   // one arrival counter per i-block, zero between launches
+    uint32_t junits = 0;           // 4-pair units per wave
+    bool poison = false;           // NB_FLAG_POISON
     int acc_parity = 0;    // swap_acc: how often acc/partial have swapped roles (mod 2)
     bool swap_acc = false; // two-kernel step with jsplit == 1: K2 reads the partial as a_new and the
                            // acc/partial buffers swap roles (96 B per body)

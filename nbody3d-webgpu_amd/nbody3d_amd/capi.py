@@ -21,6 +21,7 @@ NB_F32, NB_F64 = 0, 1
 NB_FLAG_EXT_STREAM = 1
 NB_FLAG_LDS_ONLY = 4
 NB_FLAG_NO_FUSE = 8
+NB_FLAG_POISON = 16
 NB_RCCL_ID_BYTES = 128
 NB_RCCL_OVERLAP = 1
 NB_MULTI_PEER, NB_MULTI_RCCL = 0, 1

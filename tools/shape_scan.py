@@ -46,6 +46,13 @@ def candidates(n):
                     if wgs < 512 or wgs > 8192 or n / js / ws < 256:
                         continue
                     out.append(("sgpr_ipl%d_ws%d_js%d" % (ipl, ws, js), dict(force_variant=300000 + ipl * 1000 + 10 + ws, jsplit=js)))
+    if n >= 2048:          # j-packed fused step: 64 i-bodies per workgroup of ws waves, q splits across workgroups
+        for x, ws in ((4, 4), (8, 8), (6, 16)):
+            for js in (1, 2, 3, 4, 5, 6, 8, 12, 16):
+                wgs = -(-n // 64) * js
+                if wgs < 128 or wgs > 8192 or n / js / ws < 64:
+                    continue
+                out.append(("jpk_ws%d_js%d" % (ws, js), dict(force_variant=601010 + x, jsplit=js)))
     return out
 
 
