@@ -84,3 +84,83 @@ def test_no_instruction_touches_a_requested_sgpr_before_its_wait():
             touched = sregs(rest) & pending
             assert not touched, "NG,WS=%s: `%s` touches s%s before the wait" % (ng, code, sorted(touched))
         assert requests >= 8 and waits >= 2, (ng, requests, waits)
+
+
+def jpk_bodies():
+    if shutil.which("/opt/rocm/bin/hipcc") is None and shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    if not os.path.exists(ASM):
+        subprocess.check_call(["make", "-C", CSRC, "-s", "asm"])
+    text = open(ASM).read()
+    return {int(m.group(1)): m.group(2).splitlines()
+            for m in re.finditer(r"^_ZN2nb11nb_step_jpkILi(\d+)EEE\w+:\s*;.*?$(.*?)s_endpgm", text, re.S | re.M)}
+
+
+def vregs(operand_text):
+    regs = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", operand_text):
+        regs.update(range(int(a), int(b) + 1))
+    for a in re.findall(r"\bv(\d+)\b", operand_text):
+        regs.add(int(a))
+    return regs
+
+
+def test_jpk_scalar_requests_and_the_asynchronous_sink_register():
+    """nb_step_jpk: (1) the s_load_dwordx8 requests of a 4-pair unit obey the same rule as above;
+    (2) the L2 warm-up loads (`global_load_dword` inside an asm statement) complete asynchronously into
+    one VGPR: nothing may read or write that register until the explicit `s_waitcnt vmcnt(0)` asm --
+    a register the allocator had recycled was overwritten by a late return on the GPU (a memory
+    fault, fixed by keeping the register live across the statements); (3) the inner loop carries
+    exactly 96 packed + 16 v_rsq_f32 VALU instructions per two units and no v_mov."""
+    bodies = jpk_bodies()
+    assert set(bodies) == {4, 8, 16}
+    for ws, lines in bodies.items():
+        pending, sink, in_asm = set(), set(), False
+        requests = waits = sink_loads = 0
+        loop, in_loop = [], False
+        for ln in lines:
+            if "#ASMSTART" in ln:
+                in_asm = True
+                continue
+            if "#ASMEND" in ln:
+                in_asm = False
+                continue
+            code = ln.split(";")[0].strip()
+            if not code or code.startswith("."):
+                continue
+            if code.endswith(":"):
+                in_loop = False
+                continue
+            op, _, rest = code.partition(" ")
+            if op == "s_load_dwordx8" and in_asm:
+                dst, src = rest.split(",")[0], ",".join(rest.split(",")[1:])
+                assert not (sregs(src) & pending), (ws, code)
+                pending |= sregs(dst)
+                requests += 1
+                in_loop = True
+                continue
+            if op == "global_load_dword" and in_asm:
+                sink |= vregs(rest.split(",")[0])
+                sink_loads += 1
+                continue
+            if op == "s_waitcnt" and "vmcnt(0)" in rest and in_asm:
+                sink.clear()
+                continue
+            if op == "s_waitcnt" and "lgkmcnt(0)" in rest:
+                pending.clear()
+                waits += 1
+                continue
+            if op in ("s_branch",):
+                pending.clear()
+                continue
+            assert not (sregs(rest) & pending), "WS=%d: `%s` touches a requested SGPR before the wait" % (ws, code)
+            if sink and not op.startswith("s_") and op != "global_load_dword":
+                assert not (vregs(rest) & sink), "WS=%d: `%s` touches the sink VGPR before vmcnt(0)" % (ws, code)
+        assert requests >= 12 and waits >= 3 and sink_loads == 1, (ws, requests, waits, sink_loads)
+        # the steady-state loop: between the loop label that precedes the first in-loop wait and its back edge
+        text = "\n".join(lines)
+        m = re.search(r"^(\.LBB\d+_\d+):[^\n]*\n(?:(?!^\.LBB).*\n)*?\s*s_cbranch_scc\d \1\s*$", text, re.M)
+        assert m, ws
+        ops = [l.split(";")[0].strip().split(" ")[0] for l in m.group(0).splitlines()]
+        ops = [o for o in ops if o.startswith("v_")]
+        assert ops.count("v_rsq_f32_e32") == 16 and sum(o.startswith("v_pk_") for o in ops) == 96 and len(ops) == 112, (ws, len(ops))
