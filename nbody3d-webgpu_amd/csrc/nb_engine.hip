@@ -455,7 +455,8 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
     V4* p = (V4*)s->partial;
     T G = (T)s->G, e2 = (T)s->eps2;
     uint32_t n = s->n, sb = s->sb, sc = s->sc, jps = s->j_per_split;
-    void* args[] = {&b, &p, &n, &sb, &sc, &G, &e2, &jps, &win};
+    const void* zr = s->zero_row;     // read by the packed LDS kernels only (trailing argument; the others ignore it)
+    void* args[] = {&b, &p, &n, &sb, &sc, &G, &e2, &jps, &win, &zr};
     launch_kernel(kernel_of(s->f64, sh), grid, block, args, s->stream, t0, t1);
 }
 
@@ -500,7 +501,8 @@ void launch_fused(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr)
     float4 *v = (float4*)s->vel, *a = (float4*)s->acc;
     uint32_t n = s->n;
     float G = (float)s->G, e2 = (float)s->eps2, dt = (float)s->dt;
-    void* args[] = {&bin, &bout, &v, &a, &n, &G, &e2, &dt};
+    const void* zr = s->zero_row;
+    void* args[] = {&bin, &bout, &v, &a, &n, &G, &e2, &dt, &zr};
     launch_kernel(kernel_of(false, sh), grid, block, args, s->stream, t0, t1);
     s->cur ^= 1;
 }
@@ -714,6 +716,8 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
         NB_HIPC(hipDeviceSynchronize());
         s->poison = (cfg.flags & NB_FLAG_POISON) != 0;
     }
+    NB_HIPC(hipMalloc(&s->zero_row, 64));                     // a zero-mass body at the origin: what the LDS-DMA staging
+    NB_HIPC(hipMemsetAsync(s->zero_row, 0, 64, s->stream));   // of the packed tile kernels reads for rows past the range (stream-ordered)
     s->diag_blocks = ceil_div(s->sc, nb::kBlock);
     NB_HIPC(hipMalloc((void**)&s->diag, sizeof(double) * 5 * s->diag_blocks));
 #undef NB_HIPC
@@ -743,6 +747,7 @@ void nb_destroy(nb_sim* s)
     if (s->jpartial) (void)hipFree(s->jpartial);
     if (s->tickets) (void)hipFree(s->tickets);
     if (s->diag) (void)hipFree(s->diag);
+    if (s->zero_row) (void)hipFree(s->zero_row);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }

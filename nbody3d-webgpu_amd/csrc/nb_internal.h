@@ -48,6 +48,7 @@ struct nb_sim {
     void* acc = nullptr;
     void* partial = nullptr;
     double* diag = nullptr;
+    void* zero_row = nullptr;      // 64 zero bytes (LDS-DMA source for j past the range)
     uint32_t diag_blocks = 0;
     double dt = 0.0, G = 0.0;
     bool params_set = false, uploaded = false;

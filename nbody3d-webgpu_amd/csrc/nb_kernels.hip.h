@@ -21,8 +21,9 @@
 //
 // CDNA4 mapping of the force loop (wave = 64 lanes, 4 SIMDs/CU, 160 KiB LDS/CU):
 //   * a 256-thread workgroup (4 waves, one per SIMD) stages a j-tile of 256*TL bodies
-//     (x, y, z, G*m) in LDS, double buffered, ONE s_barrier per tile; the next tile's
-//     global_load_dwordx4 is in flight while the current tile computes;
+//     (x, y, z, m) in LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR staging, no ds_write),
+//     double buffered, ONE s_barrier per tile; the next tile lands while the current one computes
+//     (the scalar template nb_force<T,...> stages (x, y, z, G*m) through registers);
 //   * the inner loop reads the tile with ds_read_b128 at a wave-uniform address
 //     (LDS broadcast: one read feeds 64*IPL pair evaluations) -- LS == 1 -- or
 //     at LS consecutive addresses when LS lanes share one i-body;
@@ -341,40 +342,38 @@ struct PkCore {
     static_assert(LS >= 1 && LS <= 64 && (LS & (LS - 1)) == 0, "LS must be a power of two <= 64");
     static_assert(TL == 1 || TL == 4 || TL == 8, "TL is 1, 4 or 8");
 
-    // Accumulates sum_{j in [j0, j1)} (G m_j) r_ij / (|r_ij|^2 + eps2)^{3/2} for the lane's 2*NG bodies
-    // over the lane's share of j (every LS-th body of each tile).
-    static __device__ __forceinline__ void run(const float4* __restrict__ bodies, const uint32_t j0, const uint32_t j1,
-                                               const float G, const float eps2, const nb_f2 (&xi)[NG],
-                                               const nb_f2 (&yi)[NG], const nb_f2 (&zi)[NG], nb_f2 (&ax)[NG],
-                                               nb_f2 (&ay)[NG], nb_f2 (&az)[NG])
+    // Accumulates G * sum_{j in [j0, j1)} m_j r_ij / (|r_ij|^2 + eps2)^{3/2} for the lane's 2*NG bodies over the
+    // lane's share of j (every LS-th body of each tile).  G multiplies the finished sums (as in
+    // nb_force_pk_sgpr: rounding only; identical bits when G = 1).
+    static __device__ __forceinline__ void run(const float4* __restrict__ bodies, const float4* __restrict__ zero_row,
+                                               const uint32_t j0, const uint32_t j1, const float G, const float eps2,
+                                               const nb_f2 (&xi)[NG], const nb_f2 (&yi)[NG], const nb_f2 (&zi)[NG],
+                                               nb_f2 (&ax)[NG], nb_f2 (&ay)[NG], nb_f2 (&az)[NG])
     {
-        __shared__ float4 tile[2][TILE];
+        __shared__ float4 tile[2][TILE];                     // the only LDS object of the kernel
         const int tid = threadIdx.x;
         const int js = tid % LS;
         const nb_f2 e2 = nb_f2{eps2, eps2};
         const uint32_t ntiles = (j1 > j0) ? (j1 - j0 + TILE - 1) / TILE : 0;
 
-        // The global loads of a stage are issued back to back with NOTHING consuming them until the
-        // stage is stored (clamped index instead of a bounds branch; G and the zero-mass mask are
-        // applied in store()): any use next to the load would park the wave on vmcnt(0) right
-        // there and the "next tile in flight under this tile's compute" would not be in flight.
-        float4 nxt[TL];
-        uint32_t nxt_j0 = 0;
-        auto load = [&](uint32_t t) {
-            nxt_j0 = j0 + t * TILE;
+        // Staging by LDS-DMA (global_load_lds_dwordx4: one wave instruction moves the wave's 64 rows = 1 KiB
+        // straight into the tile, no VGPR staging, no ds_write, nothing for the wave to wait on until the
+        // barrier).  Round 2 staged through registers (global_load_dwordx4 -> G*m and zero-mass mask -> ds_write_b128):
+        // the same loop with DMA staging is 17 / 10 / 10 / 7 / 5 / 4 % faster at N = 2,048 / 4,096 / 8,192 / 16,384 /
+        // 32,768 / 65,536 (profiles/r02/ubench4_dma_staging.txt).  Rows past the range come from `zero_row`
+        // (a zero-mass body at the origin contributes exactly 0): the source address is per lane, the
+        // destination is wave-uniform base + lane * 16 B.  hipcc does not count asm loads: every tile ends
+        // with an explicit vmcnt(0) before its barrier.
+        auto stage = [&](uint32_t t, int buf) {
 #pragma unroll
             for (int q = 0; q < TL; ++q) {
-                const uint32_t j = nxt_j0 + q * kBlock + tid;
-                nxt[q] = ld4(bodies + (j < j1 ? j : j1 - 1));
-            }
-        };
-        auto store = [&](int buf) {
-#pragma unroll
-            for (int q = 0; q < TL; ++q) {
-                const uint32_t j = nxt_j0 + q * kBlock + tid;
-                float4 b = nxt[q];
-                b.w = j < j1 ? b.w * G : 0.0f;           // past the range: zero mass, contributes exactly 0
-                tile[buf][q * kBlock + tid] = b;
+                const uint32_t j = j0 + t * TILE + q * kBlock + tid;
+                const float4* src = j < j1 ? bodies + j : zero_row;
+                const uint32_t dst = __builtin_amdgcn_readfirstlane(
+                    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&tile[buf][q * kBlock + (tid & ~63)]);
+                unsigned keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
             }
         };
 
@@ -420,19 +419,15 @@ struct PkCore {
             for (int c = 0; c < NC; ++c) az[c % NG] = __builtin_elementwise_fma(r[c], dz[c], az[c % NG]);
         };
 
-        if (ntiles) { load(0); store(0); }
+        if (ntiles) stage(0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         NB_STAMP(1);
 
         for (uint32_t t = 0; t < ntiles; ++t) {
             const int cur = t & 1;
-#ifdef NB_FAKE_STAGING   // diagnostic upper bound only (tools/ubench4.hip): no tile hand-over after the first tile
-            const bool more = false;
-#else
-            const bool more = (t + 1 < ntiles);
-#endif
             if (t == 1) NB_STAMP_LIGHT(8);
-            if (more) load(t + 1);
+            if (t + 1 < ntiles) stage(t + 1, cur ^ 1);     // lands under this tile's compute (every wave left cur^1 at the last barrier)
             if (t == 1) NB_STAMP_LIGHT(9);
             // JB j-bodies x NG groups = 4 independent dependency chains, issued stage-major:
             // consecutive packed ops never depend on each other, so the backend needs no s_nop
@@ -447,11 +442,9 @@ struct PkCore {
                 for (int uu = 0; uu < UNR; ++uu) math(&tile[cur][(ch * U + uu * JB) * LS + js]);
             }
             if (t == 1) NB_STAMP_LIGHT(10);
-            if (more) store(cur ^ 1);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (t == 1) NB_STAMP_LIGHT(11);
-#ifndef NB_FAKE_STAGING
             __syncthreads();
-#endif
             if (t == 1) NB_STAMP_LIGHT(12);
         }
         NB_STAMP(2);
@@ -470,6 +463,9 @@ struct PkCore {
                 az[g] = nb_f2{r[6 * g + 4], r[6 * g + 5]};
             }
         }
+        const nb_f2 g2 = nb_f2{G, G};
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { ax[g] = g2 * ax[g]; ay[g] = g2 * ay[g]; az[g] = g2 * az[g]; }
         NB_STAMP(3);
     }
 };
@@ -488,7 +484,8 @@ struct PkCore {
 template <int NG, int LS, int TL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NB_PK_WAVES_MIN(NG, TL), NB_PK_WAVES(NG, TL))))
 void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial, uint32_t n, uint32_t i_begin,
-                 uint32_t i_count, float G, float eps2, uint32_t j_per_split, SplitWindow win)
+                 uint32_t i_count, float G, float eps2, uint32_t j_per_split, SplitWindow win,
+                 const float4* __restrict__ zero_row)
 {
     const uint32_t bxi = blockIdx.x;
     const uint32_t by = win.split(blockIdx.y);
@@ -513,7 +510,7 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
     const uint32_t j0 = by * j_per_split;
     uint32_t j1 = j0 + j_per_split;
     if (j1 > n) j1 = n;
-    PkCore<NG, LS, TL>::run(bodies, j0, j1, G, eps2, xi, yi, zi, ax, ay, az);
+    PkCore<NG, LS, TL>::run(bodies, zero_row, j0, j1, G, eps2, xi, yi, zi, ax, ay, az);
 
     if (js == LS - 1) {
         float4* out = partial + (size_t)by * i_count;
@@ -537,7 +534,7 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
 template <int NG, int LS, int TL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NB_PK_WAVES_MIN(NG, TL), NB_PK_WAVES(NG, TL))))
 void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bodies_out, float4* __restrict__ vel,
-                   float4* __restrict__ acc, uint32_t n, float G, float eps2, float dt)
+                   float4* __restrict__ acc, uint32_t n, float G, float eps2, float dt, const float4* __restrict__ zero_row)
 {
     constexpr int GROUPS = kBlock / LS;
     constexpr int IPB = GROUPS * 2 * NG;
@@ -570,7 +567,7 @@ void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bo
             v0[2 * g + 1] = ld4(vel + c1); a0[2 * g + 1] = ld4(acc + c1);
         }
     }
-    PkCore<NG, LS, TL>::run(bodies_in, 0, n, G, eps2, xi, yi, zi, ax, ay, az);
+    PkCore<NG, LS, TL>::run(bodies_in, zero_row, 0, n, G, eps2, xi, yi, zi, ax, ay, az);
 
     if (owner) {
 #pragma unroll
@@ -639,7 +636,7 @@ void nb_step_direct(const float4* __restrict__ bodies_in, float4* __restrict__ b
             for (int u = 0; u < 4; ++u) {
                 const uint32_t j = (uint32_t)(k0 + u) * 64u + (uint32_t)js;
                 const nb_v4f b = q[k0 + u];
-                const float gm = j < n ? b.w * G : 0.0f;          // past the end: zero mass, contributes exactly 0
+                const float gm = j < n ? b.w : 0.0f;              // past the end: zero mass, contributes exactly 0 (G: below)
                 bx[u] = nb_f2{b.x, b.x}; by[u] = nb_f2{b.y, b.y}; bz[u] = nb_f2{b.z, b.z}; bm[u] = nb_f2{gm, gm};
             }
 #pragma unroll
@@ -672,6 +669,8 @@ void nb_step_direct(const float4* __restrict__ bodies_in, float4* __restrict__ b
     }
     float red[6] = {ax.x, ax.y, ay.x, ay.y, az.x, az.y};
     group_sum_all<64, 6>(red);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) red[k] = G * red[k];        // G on the finished sums, exactly as PkCore::run
     if (js == 63) {
         float4 nx, nv, na;
         if (il0 < n) {
