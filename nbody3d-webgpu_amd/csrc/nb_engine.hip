@@ -218,7 +218,11 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
 {
     const uint32_t sc = s->sc, n = s->n;
     const uint32_t kMaxSplit = 128, kMinSplitLen = 128;
-    const double kTileLatency = 3000.0, kPrologue = 3000.0, kClock = 2.3e9;
+    // model constants; the NB_MODEL_* environment variables override them for calibration runs (tools/fit_model.py)
+    auto knob = [](const char* name, double dflt) { const char* e = getenv(name); return e && *e ? atof(e) : dflt; };
+    const double kTileLatency = knob("NB_MODEL_TILE_LATENCY", 3000.0), kPrologue = knob("NB_MODEL_PROLOGUE", 3000.0), kClock = 2.3e9;
+    const double kHandOver = knob("NB_MODEL_HANDOVER", 350.0), kLanesScale = knob("NB_MODEL_LANES_SCALE", 1.0);
+    const double kBoundary = knob("NB_MODEL_BOUNDARY", 3e-6);
     auto split_len = [&](uint32_t js) { return ceil_div(ceil_div(n, js), 8u) * 8u; };
     // an explicit shard (even one that covers every row: a 1-rank distributed run) keeps the
     // two-kernel step, whose position array stays put for the exchange
@@ -307,14 +311,16 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 // cost per tile stage: least-regret fit over 208 (size, shape) timings, N = 1,024 .. 65,536
                 // (profiles/r02/shape_scan_run5_calibrated.txt, shape_scan_run6_tl8.txt; worst mis-pick 1.6 %).
                 // SGPR loop: no barriers, no tile hand-over.  LDS tiles shared by LS > 1 lanes: 45 % of a tile
-                // period is hand-over at low occupancy (ubench4_tile_phases.txt).  LS = 1: the round-1 figures.
+                // period was hand-over at low occupancy with register staging (ubench4_tile_phases.txt); with
+                // LDS-DMA staging the per-stage charge went from 500 to 350 cycles (tools/fit_model.py over
+                // profiles/r02/shape_scan_dma_{a,b}.txt: worst regret 2.9 %, mean 0.5 % at 16 sizes).  LS = 1: the round-1 figures.
                 const bool sg = c.sh.kind == kPkSgpr, lanes = !sg && c.sh.ls > 1;
                 auto round_cycles = [&](double per_cu) {
                     const int k = per_cu >= 4 ? 0 : per_cu >= 3 ? 1 : per_cu >= 2 ? 2 : 3;
                     static const double f_sgpr[4] = {1.0, 0.92, 0.94, 0.62}, f_lanes[4] = {0.72, 0.75, 0.85, 0.75},
                                         f_tile[4] = {1.0, 0.92, 0.82, 0.62};
-                    const double fill = (sg ? f_sgpr : lanes ? f_lanes : f_tile)[k];
-                    return std::max(iters * per_cu * c.cyc_iter / fill, stages * kTileLatency) + kPrologue + (lanes ? stages * 500.0 : 0.0);
+                    const double fill = sg ? f_sgpr[k] : lanes ? f_lanes[k] * kLanesScale : f_tile[k];
+                    return std::max(iters * per_cu * c.cyc_iter / fill, stages * kTileLatency) + kPrologue + (lanes ? stages * kHandOver : 0.0);
                 };
                 double cyc = full * round_cycles(occ);
                 if (rem) cyc += round_cycles((double)ceil_div((uint32_t)rem, (uint32_t)n_cu));
@@ -324,7 +330,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 const double stream_s = (double)iblocks * n * 4 * s->esz / 8.0e12;
                 // K2 reads every split's partial back (and K1 writes it): priced at 2 TB/s so that, when the
                 // balance gain is a wash (N = 262,144: 8 vs 16 splits), the smaller HBM footprint wins
-                const double after = (c.sh.kind == kFused || c.sh.kind == kDirect) ? 0.0 : (double)used * sc * 4 * s->esz / 2.0e12 + 3e-6;
+                const double after = (c.sh.kind == kFused || c.sh.kind == kDirect) ? 0.0 : (double)used * sc * 4 * s->esz / 2.0e12 + kBoundary;
                 // balance: the last round runs partly empty and the first at a lower clock.  SGPR kernel at
                 // N = 262,144: 2 / 3 / 4 / 6 / 8 rounds lose 2.0 / 1.1 / 0.7 / 0.5 / 0 % (sweep_sgpr_pair_loads.txt)
                 const double t = std::max(cyc / kClock, stream_s) / (1.0 - (sg ? 0.045 : 0.03) / rounds) + after;
