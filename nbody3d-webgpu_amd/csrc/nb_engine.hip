@@ -461,8 +461,8 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
     V4* p = (V4*)s->partial;
     T G = (T)s->G, e2 = (T)s->eps2;
     uint32_t n = s->n, sb = s->sb, sc = s->sc, jps = s->j_per_split;
-    const void* zr = s->zero_row;     // read by the packed LDS kernels only (trailing argument; the others ignore it)
-    void* args[] = {&b, &p, &n, &sb, &sc, &G, &e2, &jps, &win, &zr};
+    const void* zr = s->zero_row;     // trailing parameter of the packed LDS-tile kernels only (LDS-DMA source for j past the range)
+    void* args[] = {&b, &p, &n, &sb, &sc, &G, &e2, &jps, &win, &zr};   // the other kernels declare nine parameters and never see it
     launch_kernel(kernel_of(s->f64, sh), grid, block, args, s->stream, t0, t1);
 }
 

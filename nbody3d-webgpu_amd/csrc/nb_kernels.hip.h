@@ -18,6 +18,9 @@
 //                                        no partial sums through memory
 //               nb_step_direct<MAXJ>     the same for N <= 2,048 with each lane's j-bodies loaded
 //                                        straight into registers (no LDS tile, no barrier)
+//               nb_step_jpk<WS>          A/B arm: packed across TWO j-BODIES streamed as SGPR pairs from a
+//                                        pair-transposed position copy; j split over the waves of a workgroup
+//                                        and over workgroups that meet at a ticket inside the launch
 //
 // CDNA4 mapping of the force loop (wave = 64 lanes, 4 SIMDs/CU, 160 KiB LDS/CU):
 //   * a 256-thread workgroup (4 waves, one per SIMD) stages a j-tile of 256*TL bodies
@@ -30,7 +33,7 @@
 //   * each lane keeps IPL i-bodies in VGPRs (register blocking), loaded with coalesced 16-B accesses;
 //   * f32: the arithmetic is packed across TWO i-bodies of the lane (v_pk_add/fma/mul_f32):
 //     per two pairs 3 v_pk_add, 3 v_pk_fma (r^2 + eps2), 2 v_pk_mul (cube), 2 v_rsq_f32,
-//     1 v_pk_mul (G*m_j), 3 v_pk_fma (accumulate) = 12 packed (4 cycles each) + 2 transcendental
+//     1 v_pk_mul (m_j), 3 v_pk_fma (accumulate) = 12 packed (4 cycles each) + 2 transcendental
 //     (8 cycles each) = 64 issue cycles per 128 pairs, issued stage-major over 4 independent
 //     chains so no hazard s_nop is needed;
 //   * no branch in the loop: with eps2 > 0 the self term is exactly 0*finite = 0 and bodies
