@@ -105,6 +105,12 @@ __device__ __forceinline__ double4 ld4(const double4* p)
     return double4{v.x, v.y, v.z, v.w};
 }
 
+// x, y, z of a row as ONE global_load_dwordx3: for i-rows whose mass is never used.  (With a dwordx4 the backend
+// recycles the dead fourth register while the load is still in flight and has to wait for it first --
+// seen as an s_waitcnt vmcnt(1) between the i-row loads of nb_force_pk_sgpr, which serialised them.)
+typedef float nb_v3f __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ nb_v3f ld3(const float4* p) { return *reinterpret_cast<const nb_v3f*>(p); }
+
 __device__ __forceinline__ float nb_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double nb_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 
@@ -720,14 +726,22 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
 
     nb_f2 xi[NG], yi[NG], zi[NG], ax[NG], ay[NG], az[NG];
 #pragma unroll
-    for (int g = 0; g < NG; ++g) {
-        const uint32_t il0 = bxi * IPB + (2 * g) * LANES + lane;
-        const uint32_t il1 = il0 + LANES;
-        const float4 b0 = ld4(bodies + i_begin + (il0 < i_count ? il0 : i_count - 1));   // clamped, branch-free
-        const float4 b1 = ld4(bodies + i_begin + (il1 < i_count ? il1 : i_count - 1));
-        xi[g] = nb_f2{b0.x, b1.x}; yi[g] = nb_f2{b0.y, b1.y}; zi[g] = nb_f2{b0.z, b1.z};
-        ax[g] = nb_f2{0, 0}; ay[g] = nb_f2{0, 0}; az[g] = nb_f2{0, 0};
-    }
+    for (int g = 0; g < NG; ++g) { ax[g] = nb_f2{0, 0}; ay[g] = nb_f2{0, 0}; az[g] = nb_f2{0, 0}; }
+    // The wave's i-rows, all 2*NG loads in flight together.  Called AFTER the first scalar request of the
+    // j-stream has been issued (below): neither depends on the other, and a workgroup's prologue is then
+    // one memory round trip instead of three (i-rows, i-rows behind a recycled register, first j request).
+    auto load_i_rows = [&]() {
+        nb_v3f b0[NG], b1[NG];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const uint32_t il0 = bxi * IPB + (2 * g) * LANES + lane;
+            const uint32_t il1 = il0 + LANES;
+            b0[g] = ld3(bodies + i_begin + (il0 < i_count ? il0 : i_count - 1));   // clamped, branch-free
+            b1[g] = ld3(bodies + i_begin + (il1 < i_count ? il1 : i_count - 1));
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { xi[g] = nb_f2{b0[g].x, b1[g].x}; yi[g] = nb_f2{b0[g].y, b1[g].y}; zi[g] = nb_f2{b0[g].z, b1[g].z}; }
+    };
     const nb_f2 e2 = nb_f2{eps2, eps2};
     uint32_t j0 = by * j_per_split;
     uint32_t j1 = j0 + j_per_split;
@@ -833,9 +847,10 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
 #undef NB_OCT
 #undef NB_ACC2
 #undef NB_ACC4
+        Oct A, B;
+        if (nb8) request8(A, pj);
+        load_i_rows();
         if (nb8) {
-            Oct A, B;
-            request8(A, pj);
             for (uint32_t it = 0; it < nb8; ++it) {
                 wait8(A);
                 request8(B, pj + 4);
@@ -847,9 +862,10 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
             }
             j += nb8 * 8;
         }
-    } else if (nb8) {
+    } else {
         Quad A, B;
-        request(A, pj);
+        if (nb8) request(A, pj);
+        load_i_rows();
         for (uint32_t it = 0; it < nb8; ++it) {
             wait_for(A);
             request(B, pj + 4);
