@@ -801,6 +801,7 @@ int nb_step(nb_sim* s, uint32_t nsteps)
     if (!(s->dt > 0.0)) return NB_OK;   // `if (dt > 0)` gate, nbody3d.js:474
     NB_HIP(s, hipSetDevice(s->device));
     const bool exchange = s->xfn || s->rccl;
+    ensure_pairs(s);      // the j-packed step's position copy, if something outside the step rewrote the positions or G
     // Multi-step calls on the engine's own stream replay a captured graph of
     // kGraphChunk steps (no exchange, no per-kernel timing requested).
     if (s->own_stream && s->graphs_ok && !exchange && !s->timing && nsteps >= kGraphChunk) {

@@ -93,12 +93,21 @@ def test_pair_copy_follows_uploads_restores_G_and_raw_pointers():
         t.init(b, v); t.simulate(16, 1e-3, 1.0)
         for x, y in zip(s.read(), t.read()):
             assert x.tobytes() == y.tobytes()
+        # the same through graph replays (an upload between two replays of the same captured graph)
+        s.simulate(40); t.simulate(40)
+        for wander in (33, 32):              # the restore lands on either buffer parity: with or without a re-capture
+            state = s.read()
+            s.simulate(wander)
+            s.restore(*state)
+            s.simulate(48); t.simulate(48)
+            for x, y in zip(s.read(), t.read()):
+                assert x.tobytes() == y.tobytes(), wander
         # G is folded into the pair copy: a change must rebuild it
         s.simulate(3, 1e-3, 0.25); t.simulate(3, 1e-3, 0.25)
         for x, y in zip(s.read(), t.read()):
             assert x.tobytes() == y.tobytes()
         got = s.read()
-    rb, rv, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 16)
+    rb, rv, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 16 + 40 + 48 + 48)
     rb, rv, ra = oracle.run_f64(rb, rv, ra, 1e-3, 0.25, 3)
     assert rel_pos_err(got[0], rb, 1.0) < 2e-5
     # a raw device pointer handed out: the engine assumes the caller wrote through it
