@@ -390,7 +390,10 @@ struct PkCore {
         // (Tried and dropped: issuing a stage's ds_read_b128s one stage ahead through asm statements.
         // One wave alone ran the loop 25 % faster, four per SIMD 3-7 % slower -- the statements fence
         // the scheduler at every stage -- and the step time did not move: at these sizes the waves
-        // wait on the next tile's global loads, not on LDS.  profiles/r02/ubench4_*.txt)
+        // wait on the next tile's global loads, not on LDS.  profiles/r02/ubench4_*.txt.  Tried again after the
+        // LDS-DMA staging removed that wait, as ONE asm statement of eight ds_read_b128 per chunk, a whole chunk
+        // ahead, no destination in flight across the back edge: 1-3 % SLOWER from N = 2,002 to 6,000, equal at
+        // 8,192 -- profiles/r02/ab_lds_read_pipelining.txt.)
         auto math = [&](const float4* p) {
             nb_f2 bx[JB], by[JB], bz[JB], bm[JB];
 #pragma unroll
