@@ -124,6 +124,7 @@ const void* scalar_kernel(int ipl, int ls)
 
 const void* sgpr_kernel(int ipl, int ws)
 {
+    if (ipl == 4 && ws == 5) return (const void*)&nb::nb_force_pk_sgpr<2, 4, true>;     // 64-bit pair loads
     if (ipl == 4) return ws == 4 ? (const void*)&nb::nb_force_pk_sgpr<2, 4> : (const void*)&nb::nb_force_pk_sgpr<2, 1>;
     if (ipl == 8 && ws == 5) return (const void*)&nb::nb_force_pk_sgpr<4, 4, true>;     // A/B arm: 64-bit pair loads
     if (ipl == 8) return ws == 4 ? (const void*)&nb::nb_force_pk_sgpr<4, 4> : (const void*)&nb::nb_force_pk_sgpr<4, 1>;
@@ -253,6 +254,11 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         // 8 bodies).  Measured +0.4..1.2 % on 8,192-body waves, -1.2 % on 2,048-body ones
         // (profiles/r02/sweep_sgpr_pair_loads.txt): only offered to long loops (below).
         cands.push_back({{kPkSgpr, 8, 1, 5}, 32.5 * 8 * 0.993});
+        // 4 bodies per lane: the two v_mov per body weigh twice as much (2 of 58 instructions), but twice the scalar
+        // requests per body only pay on larger systems running in several rounds: N = 40,002 / 50,000 +1.1..2.0 % with
+        // >= 1.5 rounds of workgroups, N = 65,536 +-0.5 %, N = 24,000..32,768 -0.2..-10 % at every split count,
+        // N = 16,384 -9 % (profiles/r02/sweep_pairs_ng2.txt, sweep_pairs_ng2_b.txt): offered from N = 40,000 (below)
+        if (n >= 40000) cands.push_back({{kPkSgpr, 4, 1, 5}, 33.2 * 4 * 0.987});
         // registers-only fused step: no tile hand-over at all (64 issue cycles per j, nothing to wait for)
         if (may_fuse && n <= 1024) cands.push_back({{kDirect, 2, 64, 1}, 64.0});
         if (may_fuse && n <= 1536) cands.push_back({{kDirect, 2, 64, 2}, 64.0});   // at 2,048 the 2,048-body LDS stage is 5 % ahead
@@ -298,8 +304,9 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
             for (uint32_t q = js_lo; q <= js_top; ++q) {
                 const uint32_t len = split_len(q), used = ceil_div(n, len);
                 if (c.sh.kind == kPkSgpr && len / sgpr_ws(c.sh.x) < 256) continue;   // SGPR loop wants >= 256 bodies per wave
-                if (c.sh.kind == kPkSgpr && c.sh.x == 5 && len / 4 < 6144) continue;        // pair loads: long loops only
+                if (c.sh.kind == kPkSgpr && c.sh.x == 5 && len / 4 < (c.sh.ipl == 8 ? 6144u : 320u)) continue;   // pair loads: long loops only
                 const uint64_t blocks = (uint64_t)iblocks * used;
+                if (c.sh.kind == kPkSgpr && c.sh.x == 5 && c.sh.ipl == 4 && 2 * blocks < 3 * slots) continue;   // >= 1.5 rounds
                 const uint64_t full = blocks / slots, rem = blocks % slots;
                 const double tile = c.sh.kind == kPkSgpr ? 256.0 : 256.0 * c.sh.x;
                 const double wave_len = c.sh.kind == kPkSgpr ? (double)len / sgpr_ws(c.sh.x) : (double)len;

@@ -46,7 +46,7 @@ def sregs(operand_text):
 
 def test_no_instruction_touches_a_requested_sgpr_before_its_wait():
     bodies = kernel_bodies()
-    assert set(bodies) == {(2, 1, 0), (2, 4, 0), (4, 1, 0), (4, 4, 0), (4, 4, 1)}, "expected all five nb_force_pk_sgpr instantiations"
+    assert set(bodies) == {(2, 1, 0), (2, 4, 0), (2, 4, 1), (4, 1, 0), (4, 4, 0), (4, 4, 1)}, "expected all six nb_force_pk_sgpr instantiations"
     for ng, lines in bodies.items():
         pending = set()
         requests = waits = 0

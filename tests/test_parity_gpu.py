@@ -58,7 +58,7 @@ def test_single_step_matches_oracle_acceleration(variant, jsplit):
 
 @pytest.mark.parametrize("name,steps", [("plummer1024", 100), ("cube1000", 20), ("disk771", 50), ("galaxy_ref", 30)])
 @pytest.mark.parametrize("variant,jsplit", [(0, 0), (2, 1), (1, 2), (164, 1), (22, 1), (24, 2), (28, 1), (38, 2),
-                                            (308014, 2), (402644, 0), (404161, 0), (408041, 0), (601014, 1), (601018, 3), (601016, 2)])
+                                            (308014, 2), (304015, 3), (402644, 0), (404161, 0), (408041, 0), (601014, 1), (601018, 3), (601016, 2)])
 def test_golden_trajectories(manifest, name, steps, variant, jsplit):
     """BASELINE.json config 1 (Plummer N=1024, dt=1e-3, 100 steps) and the
     ragged-N / harsh-mass-ratio fixtures, against fp64 and fp32 oracle vectors."""
