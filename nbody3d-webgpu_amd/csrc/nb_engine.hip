@@ -242,7 +242,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 for (int tl : {1, 4, 8}) {
                     if (tl == 4 && ls < 16) continue;
                     if (tl == 8 && ls < 32) continue;
-                    const double cyc = 34.0 * ipl * (ipl == 2 ? 1.05 : 1.0);
+                    const double cyc = 34.0 * ipl * (ipl == 2 ? 0.97 : 1.0);   // 2 per lane: one address op per 8 j-bodies beside the math (the mass v_mov is gone)
                     cands.push_back({{kPkLds, ipl, ls, tl}, cyc});
                     if (may_fuse) cands.push_back({{kFused, ipl, ls, tl}, cyc});
                 }

@@ -336,6 +336,31 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
 //   what the short loops of small systems need).
 typedef float nb_f2 __attribute__((ext_vector_type(2)));
 
+// a.hi * b, both halves: v_pk_mul_f32 with the HIGH half of `a` broadcast (op_sel:[1,0] op_sel_hi:[1,1]).  hipcc
+// folds a low-half broadcast into a packed op by itself but copies a high half into a fresh register first
+// (one v_mov_b32 per j-body for the mass, which sits in the high half of the (z, m) pair: 1 instruction in 15
+// of the two-bodies-per-lane loop).
+// The multiply consumes a v_rsq_f32 result, and gfx950 needs one wait state between a transcendental and a
+// VALU instruction that reads its result; hipcc inserts it for its own instructions but not in front of an asm
+// statement (seen: the scheduler sank each v_rsq_f32 right in front of its asm consumer -- wrong sums).  So the
+// reciprocal square roots of a stage and its mass multiplies are BOTH volatile asm: volatile statements keep
+// their program order, all 2*NC v_rsq_f32 of a stage come before its NC multiplies (NC >= 4 chains), and the
+// nearest producer of a multiply's operand is at least three instructions away.  tests/test_isa_guard.py checks
+// every packed kernel for an adjacent pair.
+__device__ __forceinline__ nb_f2 rsq_ordered(const nb_f2 a)
+{
+    nb_f2 o;
+    asm volatile("v_rsq_f32 %0, %1" : "=v"(o.x) : "v"(a.x));
+    asm volatile("v_rsq_f32 %0, %1" : "=v"(o.y) : "v"(a.y));
+    return o;
+}
+__device__ __forceinline__ nb_f2 mul_hi_bcast_ordered(const nb_f2 a, const nb_f2 b)
+{
+    nb_f2 o;
+    asm volatile("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(o) : "v"(a), "v"(b));
+    return o;
+}
+
 template <int NG, int LS, int TL>
 struct PkCore {
     static constexpr int TILE = kTile * TL;
@@ -350,6 +375,7 @@ struct PkCore {
     static constexpr int UNROLL = NG >= 4 ? UNR : (UNR < 2 ? UNR : 2);
     static_assert(LS >= 1 && LS <= 64 && (LS & (LS - 1)) == 0, "LS must be a power of two <= 64");
     static_assert(TL == 1 || TL == 4 || TL == 8, "TL is 1, 4 or 8");
+    static_assert(NC >= 4, "the ordered rsq / multiply statements of a stage rely on >= 4 chains");
 
     // Accumulates G * sum_{j in [j0, j1)} m_j r_ij / (|r_ij|^2 + eps2)^{3/2} for the lane's 2*NG bodies over the
     // lane's share of j (every LS-th body of each tile).  G multiplies the finished sums (as in
@@ -395,11 +421,12 @@ struct PkCore {
         // ahead, no destination in flight across the back edge: 1-3 % SLOWER from N = 2,002 to 6,000, equal at
         // 8,192 -- profiles/r02/ab_lds_read_pipelining.txt.)
         auto math = [&](const float4* p) {
-            nb_f2 bx[JB], by[JB], bz[JB], bm[JB];
+            nb_f2 bx[JB], by[JB], bz[JB], bzm[JB];
 #pragma unroll
             for (int u = 0; u < JB; ++u) {
                 const float4 b = p[u * LS];
-                bx[u] = nb_f2{b.x, b.x}; by[u] = nb_f2{b.y, b.y}; bz[u] = nb_f2{b.z, b.z}; bm[u] = nb_f2{b.w, b.w};
+                bx[u] = nb_f2{b.x, b.x}; by[u] = nb_f2{b.y, b.y}; bz[u] = nb_f2{b.z, b.z};
+                bzm[u] = nb_f2{b.z, b.w};      // the (z, m) register pair of the ds_read_b128 result, as it lies
             }
             nb_f2 dx[NC], dy[NC], dz[NC], d2[NC], r[NC];
 #pragma unroll
@@ -419,9 +446,18 @@ struct PkCore {
 #pragma unroll
             for (int c = 0; c < NC; ++c) r[c] = r[c] * d2[c];
 #pragma unroll
-            for (int c = 0; c < NC; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+            for (int c = 0; c < NC; ++c) {
+                if constexpr (NG == 1) r[c] = rsq_ordered(r[c]);
+                else r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+            }
+            // m_j * inv.  One i-pair per lane: the explicit high-half broadcast (no v_mov for the mass; -2..-3.4 % per
+            // step from N = 3,000 to 10,000).  More pairs per lane: the plain product -- the v_mov is 1 instruction in
+            // 29 / 57 there and the ordered statements cost the scheduler more than that (N = 8,192, 4 per lane: +2 %).
 #pragma unroll
-            for (int c = 0; c < NC; ++c) r[c] = bm[c / NG] * r[c];
+            for (int c = 0; c < NC; ++c) {
+                if constexpr (NG == 1) r[c] = mul_hi_bcast_ordered(bzm[c / NG], r[c]);
+                else r[c] = nb_f2{bzm[c / NG].y, bzm[c / NG].y} * r[c];
+            }
             // accumulate in ascending j for every group (same order as the plain loop)
 #pragma unroll
             for (int c = 0; c < NC; ++c) ax[c % NG] = __builtin_elementwise_fma(r[c], dx[c], ax[c % NG]);

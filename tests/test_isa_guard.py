@@ -164,3 +164,30 @@ def test_jpk_scalar_requests_and_the_asynchronous_sink_register():
         ops = [l.split(";")[0].strip().split(" ")[0] for l in m.group(0).splitlines()]
         ops = [o for o in ops if o.startswith("v_")]
         assert ops.count("v_rsq_f32_e32") == 16 and sum(o.startswith("v_pk_") for o in ops) == 96 and len(ops) == 112, (ws, len(ops))
+
+
+def test_no_packed_multiply_reads_a_reciprocal_square_root_issued_right_before_it():
+    """The one-pair-per-lane LDS kernels multiply the mass in with an asm v_pk_mul_f32 (high-half broadcast) whose
+    operand comes out of v_rsq_f32.  gfx950 needs a wait state between a transcendental and the VALU instruction
+    that reads its result, and hipcc does not insert one in front of an asm statement: in every packed kernel, no
+    v_pk_mul_f32 ... op_sel:[1,0] may directly follow a v_rsq_f32 that wrote one of its source registers."""
+    if shutil.which("/opt/rocm/bin/hipcc") is None and shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    if not os.path.exists(ASM):
+        subprocess.check_call(["make", "-C", CSRC, "-s", "asm"])
+    text = open(ASM).read()
+    kernels = asm_muls = 0
+    for m in re.finditer(r"^(_ZN2nb(?:13nb_step_fused|11nb_force_pk)ILi1ELi\d+ELi\d+EEE\w+):\s*;.*?$(.*?)s_endpgm", text, re.S | re.M):
+        kernels += 1
+        prev_op, prev_dst = None, set()
+        for ln in m.group(2).splitlines():
+            code = ln.split(";")[0].strip()
+            if not code or code.startswith(".") or code.endswith(":"):
+                continue
+            op, _, rest = code.partition(" ")
+            if op == "v_pk_mul_f32" and "op_sel:[1,0] op_sel_hi:[1,1]" in rest:
+                asm_muls += 1
+                srcs = vregs(",".join(rest.split("op_sel")[0].split(",")[1:]))
+                assert not (prev_op is not None and prev_op.startswith("v_rsq_f32") and (prev_dst & srcs)), (m.group(1), code)
+            prev_op, prev_dst = op, vregs(rest.split(",")[0])
+    assert kernels >= 20 and asm_muls >= 4 * kernels, (kernels, asm_muls)
