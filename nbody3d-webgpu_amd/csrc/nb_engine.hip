@@ -242,7 +242,9 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                 for (int tl : {1, 4, 8}) {
                     if (tl == 4 && ls < 16) continue;
                     if (tl == 8 && ls < 32) continue;
-                    const double cyc = 34.0 * ipl * (ipl == 2 ? 0.97 : 1.0);   // 2 per lane: one address op per 8 j-bodies beside the math (the mass v_mov is gone)
+                    // 2 per lane: lane-sharing shapes carry no mass v_mov any more (0.97, refit on shape_scan_after_hi_broadcast.txt);
+                    // one lane per body keeps the round-2 figure (1.05): 0.97 there pulled N = 12,000 .. 32,768 off the SGPR kernel (-1..-6 %)
+                    const double cyc = 34.0 * ipl * (ipl == 2 ? (ls == 1 ? 1.05 : 0.97) : 1.0);
                     cands.push_back({{kPkLds, ipl, ls, tl}, cyc});
                     if (may_fuse) cands.push_back({{kFused, ipl, ls, tl}, cyc});
                 }
