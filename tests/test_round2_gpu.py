@@ -375,3 +375,18 @@ def test_integrate_pass_measures_the_integrator_alone():
         with pytest.raises(Exception) as e:
             fused.integrate_pass(1)
         assert "NB_ERR_STATE" in str(e.value)
+
+
+# ---- the automatic launch shape ----------------------------------------------------------------
+
+@pytest.mark.parametrize("n,family", [(512, "fused_regs"), (1024, "fused_regs"), (2002, "fused_lds"), (4096, "fused_lds"),
+                                      (8192, "fused_lds"), (12000, "sgpr"), (16384, "sgpr"), (20000, "sgpr"), (32768, "sgpr"),
+                                      (40002, "sgpr"), (65536, "sgpr"), (131072, "sgpr"), (262144, "sgpr_ipl8_ws4"),
+                                      (500010, "sgpr"), (1048576, "sgpr")])
+def test_default_launch_shape_family_by_size(n, family):
+    """choose_shape's pick per system size, as measured best in profiles/r02/size_scan_final_4k_65k.txt: a refit of one
+    model constant once moved N = 12,000 .. 32,768 onto a shape 1-6 % slower without any test noticing."""
+    with Simulation(n) as s:
+        assert family in s.variant, (n, s.variant)
+    with Simulation(n, shard=(0, (n // 2 + 255) // 256 * 256 if n > 512 else n)) as s:      # a rank's shard never fuses
+        assert "fused" not in s.variant, (n, s.variant)
