@@ -14,9 +14,9 @@ import re
 import sys
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-SIZES = [1024, 2048, 3000, 4096, 5000, 6000, 7000, 8192, 10000, 12000, 14000, 16384, 20000, 32768, 40002, 65536]
-GRID = {"NB_MODEL_TILE_LATENCY": [3000, 2600, 2200, 1800], "NB_MODEL_HANDOVER": [500, 350, 200, 0],
-        "NB_MODEL_LANES_SCALE": [1.0, 1.04, 1.08, 1.12], "NB_MODEL_BOUNDARY": [3e-6, 4e-6]}
+SIZES = [int(x) for x in os.environ.get("NB_FIT_SIZES", "1024,2048,3000,4096,5000,6000,7000,8192,10000,12000,14000,16384,20000,32768,40002,65536").split(",")]
+GRID = {"NB_MODEL_TILE_LATENCY": [3000, 2200], "NB_MODEL_HANDOVER": [350, 250, 150, 50, 0],
+        "NB_MODEL_LANES_SCALE": [1.0, 1.03, 1.06, 1.09, 1.12], "NB_MODEL_BOUNDARY": [3e-6, 4e-6, 5e-6]}
 
 
 def picks():
