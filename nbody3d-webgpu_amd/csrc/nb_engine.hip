@@ -249,19 +249,14 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                     cands.push_back({{kPkLds, ipl, ls, tl}, cyc});
                     if (may_fuse) cands.push_back({{kFused, ipl, ls, tl}, cyc});
                 }
-        // SGPR loop: 8 bodies per lane measured ~2 % ahead of 4 (profiles/r02/shape_scan_*.txt)
+        // SGPR loop, bodies fetched as quads (s_load_dwordx4).  Since z is taken from the (z, m) SGPR pair by an explicit
+        // low-half broadcast and the loop body is one basic block, it carries NO VALU instruction beside the pair
+        // arithmetic (224 / 448 per 8 bodies at 4 / 8 bodies per lane; the mass moves by s_mov_b32).  The 64-bit
+        // pair-load form (X = 5: twice the scalar requests, measured ahead only while the quad form still copied z and
+        // m through VGPRs) is now behind it at every size -- N=262,144: 14.58 vs 14.70 ms, N=40,002: 351 vs 357 us
+        // (profiles/r02/ab_sgpr_zbcast.txt) -- and stays selectable as an A/B arm only.
         for (int ipl : {8, 4})
-            for (int ws : {1, 4}) cands.push_back({{kPkSgpr, ipl, 1, ws}, (ipl == 8 ? 32.5 : 33.2) * ipl});
-        // the same loop with every body loaded as two SGPR pairs (8 s_load_dwordx2 per 4 bodies): the backend
-        // then folds z and the mass into the packed ops too (no v_mov: 448 instead of 456 VALU instructions per
-        // 8 bodies).  Measured +0.4..1.2 % on 8,192-body waves, -1.2 % on 2,048-body ones
-        // (profiles/r02/sweep_sgpr_pair_loads.txt): only offered to long loops (below).
-        cands.push_back({{kPkSgpr, 8, 1, 5}, 32.5 * 8 * 0.993});
-        // 4 bodies per lane: the two v_mov per body weigh twice as much (2 of 58 instructions), but twice the scalar
-        // requests per body only pay on larger systems running in several rounds: N = 40,002 / 50,000 +1.1..2.0 % with
-        // >= 1.5 rounds of workgroups, N = 65,536 +-0.5 %, N = 24,000..32,768 -0.2..-10 % at every split count,
-        // N = 16,384 -9 % (profiles/r02/sweep_pairs_ng2.txt, sweep_pairs_ng2_b.txt): offered from N = 40,000 (below)
-        if (n >= 40000) cands.push_back({{kPkSgpr, 4, 1, 5}, 33.2 * 4 * 0.987});
+            for (int ws : {1, 4}) cands.push_back({{kPkSgpr, ipl, 1, ws}, (ipl == 8 ? 32.0 : 32.2) * ipl});
         // registers-only fused step: no tile hand-over at all (64 issue cycles per j, nothing to wait for)
         if (may_fuse && n <= 1024) cands.push_back({{kDirect, 2, 64, 1}, 64.0});
         if (may_fuse && n <= 1536) cands.push_back({{kDirect, 2, 64, 2}, 64.0});   // at 2,048 the 2,048-body LDS stage is 5 % ahead

@@ -842,8 +842,20 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
             for (int c = 0; c < NG; ++c) dx[c] = bx - xi[c];
 #pragma unroll
             for (int c = 0; c < NG; ++c) dy[c] = by2 - yi[c];
+            // z_j - z_i with the LOW half of the (z, m) SGPR pair broadcast, spelled out: left to itself hipcc folds the
+            // (x, y) pair of a body that arrived as an SGPR quad into the packed ops but copies z and the mass to VGPRs
+            // first (2 v_mov_b32 per body: 2 instructions in 58 at four bodies per lane).  With z taken straight from the
+            // pair the mass moves by s_mov_b32 -- a scalar-unit instruction -- and the loop carries no VALU copy at all.
+            // Pure function of its inputs and not fed by a transcendental: plain (non-volatile) asm, no hazard to mind.
+            if constexpr (!PAIRS) {
+                const nb_f2 bzm = nb_f2{b.z, b.w};
 #pragma unroll
-            for (int c = 0; c < NG; ++c) dz[c] = bz - zi[c];
+                for (int c = 0; c < NG; ++c)
+                    asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(dz[c]) : "s"(bzm), "v"(zi[c]));
+            } else {
+#pragma unroll
+                for (int c = 0; c < NG; ++c) dz[c] = bz - zi[c];
+            }
 #pragma unroll
             for (int c = 0; c < NG; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);
 #pragma unroll
@@ -941,15 +953,19 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
         Quad A, B;
         if (nb8) request(A, pj);
         load_i_rows();
+        // branch-free body: the request after the wave's last 8 bodies re-reads its last 4 (a scalar select on the
+        // pointer, never past the range) -- with a conditional request the second eval sat in its own basic block and
+        // its SGPR operands were copied to VGPRs at the block boundary
         for (uint32_t it = 0; it < nb8; ++it) {
             wait_for(A);
             request(B, pj + 4);
             eval4(f4(A.q0), f4(A.q1), f4(A.q2), f4(A.q3));
             wait_for(B);
+            request(A, it + 1 < nb8 ? pj + 8 : pj + 4);
             pj += 8;
-            if (it + 1 < nb8) request(A, pj);
             eval4(f4(B.q0), f4(B.q1), f4(B.q2), f4(B.q3));
         }
+        if (nb8) wait_for(A);          // the spare request has landed (in dead registers) before anything else counts lgkm
         j += nb8 * 8;
     }
     for (; j < j1; ++j)      // < 8 bodies left (only when n is not a multiple of 8): one at a time
