@@ -346,14 +346,17 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
         // The j-packed fused step (force_variant K = 6; whole-system f32 handles): 64 i-bodies per workgroup of ws
         // waves, the j-pairs split over ws waves x q workgroups.  One scalar request (4 pairs, 256 issue cycles)
         // is in flight per wave and returns after ~1,100 cycles, so a SIMD needs > 4 resident waves to stay
-        // busy.  NOT offered by the automatic choice: through the engine it is within +-2 % of the SGPR two-kernel
-        // step from N = 8,192 to 65,536 (best case N = 16,384: 67.4 vs 68.7 us) and behind it in between
-        // (profiles/r02/shape_scan_jpk.txt, ubench5_*.txt); this model only picks the split count of a pinned shape.
-        if (may_fuse && pinned && sh.kind == kJpk) {
+        // busy.  Since its partial rows go out write-through (no release fence per workgroup) its split forms are the
+        // fastest step from N ~ 8,000 to ~ 18,000 (through the engine: 8,192 19.9 vs 20.4 us, 10,000 28.7 vs 31.7,
+        // 12,000 39.1 vs 41.2, 14,000 50.8 vs 51.4, 16,384 64.5 vs 65.3; level at 20,000 and behind above and below:
+        // profiles/r02/shape_scan_jpk_sc1.txt).  The automatic choice offers it from 7,000 to 12,500, where it wins by 5-10 %
+        // whatever split count this model lands on; from 13,000 to 20,000 the margin is 1-2 % with the best split and the
+        // model's split choice is off by more than that (size_scan_jpk_auto.txt), so the SGPR step stays there.
+        if (may_fuse && (pinned ? sh.kind == kJpk : (!(cfg.flags & NB_FLAG_LDS_ONLY) && n >= 7000 && n <= 12500))) {
             const uint32_t units = ((ceil_div(ceil_div(n, 2u), 4u) + 1u) & ~1u);
             for (int x : {4, 8, 6}) {
                 const Shape jsh{kJpk, 1, 1, x};
-                if (sh.x != x) continue;
+                if (pinned && sh.x != x) continue;
                 const int ws = jpk_ws(x);
                 int occ = 0;
                 if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel_of(false, jsh), 64 * ws, 0) != hipSuccess || occ < 1) {
@@ -374,7 +377,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
                     double cyc = full * round_cycles(occ);
                     if (rem) cyc += round_cycles((double)ceil_div((uint32_t)rem, (uint32_t)n_cu));
                     const double rounds = (double)full + (rem ? 1 : 0);
-                    const double t = cyc / kClock / (1.0 - 0.03 / rounds) + (q > 1 ? 2.5e-6 : 0.0);
+                    const double t = cyc / kClock / (1.0 - 0.03 / rounds) + (q > 1 ? 1.0e-6 : 0.0);
                     scored.push_back({jsh, q, t});
                     if (t < best_t) best_t = t;
                 }

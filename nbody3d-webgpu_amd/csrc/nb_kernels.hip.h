@@ -1036,15 +1036,20 @@ __device__ __forceinline__ void jstep_finish(float sx, float sy, float sz, const
     // j split over gridDim.y workgroups (systems with fewer than ~4 i-blocks per CU): every workgroup
     // stores its 64 partial sums, and the one that arrives LAST at the i-block's ticket adds all of them
     // in ascending split order (deterministic) and integrates -- the in-launch split reduction of
-    // cdna_hip_programming.md §5 (plain stores, drain, agent-scope release, relaxed ticket; the last arriver:
+    // cdna_hip_programming.md §5 in its write-through form (sc1 stores, drain, relaxed ticket; the last arriver:
     // agent-scope acquire, then plain vector loads).  One launch per step at any split count, no K2.
     const uint32_t nsplit = gridDim.y;
     if (nsplit > 1) {
         float4* const mine = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 64 + lane;
-        *mine = float4{sx, sy, sz, 0.0f};
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // The partial row goes out WRITE-THROUGH (sc1: past this XCD's L2 once drained), so the workgroup needs no release
+        // fence.  A release fence is a buffer_wbl2 -- a write-back of the whole L2 -- per workgroup: with it every split form of
+        // this kernel was 2-8 us slower per step (N=12,000: 46.3 -> 38.3 us, N=8,192: 22.0 -> 19.8; profiles/r02/
+        // ubench5_sc1_vs_fence.txt).  The last arriver still acquires (buffer_inv sc1) before its plain loads.
+        {
+            const nb_v4f pv = nb_v4f{sx, sy, sz, 0.0f};
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(mine), "v"(pv) : "memory");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         uint32_t drawn = 0;
         if (lane == 0) drawn = __hip_atomic_fetch_add(ticket + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         drawn = __builtin_amdgcn_readfirstlane(drawn);

@@ -157,6 +157,10 @@ def test_sharded_and_f64_handles_never_take_the_pair_kernel():
     b, v = ic.plummer(n, seed=47)
     with Simulation(n, force_variant=code(8), shard=(0, 4096)) as s:
         assert "jpairs" not in s.variant, s.variant
+    with Simulation(n, shard=(0, 4096)) as s:                     # nor by the automatic choice (n = 8,192 is inside its range)
+        assert "jpairs" not in s.variant, s.variant
+    with Simulation(n) as s:
+        assert "jpairs" in s.variant or "fused_lds" in s.variant, s.variant
     with Simulation(n, precision="f64", force_variant=code(8)) as s:
         assert "jpairs" not in s.variant and s.variant.startswith("f64"), s.variant
     with Simulation(n, force_variant=code(8), flags=capi.NB_FLAG_NO_FUSE) as s:

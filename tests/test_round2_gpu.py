@@ -382,7 +382,7 @@ def test_integrate_pass_measures_the_integrator_alone():
 # ---- the automatic launch shape ----------------------------------------------------------------
 
 @pytest.mark.parametrize("n,family", [(512, "fused_regs"), (1024, "fused_regs"), (2002, "fused_lds"), (4096, "fused_lds"),
-                                      (8192, "fused_lds"), (10000, "fused_lds"), (13000, "sgpr"), (16384, "sgpr"), (20000, "sgpr"), (32768, "sgpr"),
+                                      (6000, "fused_lds"), (8192, "fused"), (10000, "fused_jpairs"), (12000, "fused_jpairs"), (13000, "sgpr"), (16384, "sgpr"), (20000, "sgpr"), (32768, "sgpr"),
                                       (40002, "sgpr"), (65536, "sgpr"), (131072, "sgpr"), (262144, "sgpr_ipl8_ws4"),
                                       (500010, "sgpr"), (1048576, "sgpr")])
 def test_default_launch_shape_family_by_size(n, family):
