@@ -436,7 +436,8 @@ def main():
                     tj.get("kernel_variant") == sim.variant):
                 traffic, traffic_src = tj.get("bytes_per_launch"), "profiles/k1_hbm_traffic.json (" + tj.get("source", "") + ")"
         fused = "fused" in sim.variant
-        out["roofline"] = {"kernel": ("nb_step_fused" if fused else "nb_force") + "<%s> (%s)" % (args.precision, sim.variant),
+        kname = "nb_step_jpk" if "jpairs" in sim.variant else "nb_step_direct" if "fused_regs" in sim.variant else "nb_step_fused" if fused else "nb_force"
+        out["roofline"] = {"kernel": kname + "<%s> (%s)" % (args.precision, sim.variant),
                            "bound": "valu",
                            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": f_ms, "launches": launches,
