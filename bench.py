@@ -73,6 +73,9 @@ def parse():
                     help="start the all-gather asynchronously and hide it behind the next step's own-row force work")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the distributed exchange path even with one rank (plumbing test)")
+    ap.add_argument("--no-also", action="store_true",
+                    help="skip the secondary single-GPU measurements (BASELINE configs 2 and 5, the reference's default "
+                         "N=40,002 system) that the default 1-GPU headline run appends under the `also` key")
     return ap.parse_args()
 
 
@@ -243,6 +246,69 @@ def sampled_rows_check(bodies64, accel, rows, G, tol):
             "pass": bool(worst < tol)}
 
 
+def also_measurements(Simulation, ic, device):
+    """Secondary measurements appended to the default 1-GPU headline line (same process, same gates): the other
+    single-GPU BASELINE configs and the reference's own default workload, each with its own sampled-row check
+    against an fp64 direct sum.  ~1.5 s of GPU time in all; the headline fields are computed before this runs.
+
+      config 2   N=65,536 uniform cube, fp32: the default shape, and the "LDS tile=256" kernel BASELINE names (variant 28)
+      config 5   N=262,144 Plummer, fp64
+      default    the reference's UI defaults (index.html:68-74, nbody3d.js:62-64,163-177): 2 galaxies x 20,000 + 2 = N 40,002,
+                 G = dt = 1e-4, central masses 1e7 -- built by js/ic.js::galaxies under Node, digest-checked against the
+                 reference generator's own output (tests/golden/galaxy40002_params.json)
+    """
+    out = []
+
+    def run(label, bodies, vel, dt, G, precision, variant, warm, steps, k1_steps):
+        n = bodies.shape[0]
+        np_dtype = np.float64 if precision == "f64" else np.float32
+        roof = PEAK_FP32_TFLOPS * 1e12 / FLOPS_PER_PAIR * (0.5 if precision == "f64" else 1.0)
+        entry = {"workload": label, "n": n, "dtype": precision}
+        try:
+            with Simulation(n, precision=precision, device=device, force_variant=variant) as sim:
+                sim.init(bodies.astype(np_dtype), vel.astype(np_dtype))
+                sim.set_params(dt, G)
+                sim.simulate(1)
+                acc = sim.read(bodies=False, vel=False)[2]
+                rows = np.unique(np.linspace(0, n - 1, 4).astype(np.int64))
+                chk = sampled_rows_check(bodies.astype(np.float64), acc, rows, G, 1e-11 if precision == "f64" else 2e-5)
+                sim.simulate(warm)
+                sim.sync()
+                t0 = time.perf_counter()
+                sim.simulate(steps)
+                sim.sync()
+                wall = time.perf_counter() - t0
+                sim.enable_timing(True)
+                sim.simulate(k1_steps)
+                f_ms, i_ms, _, launches = sim.step_times()
+                sim.enable_timing(False)
+                rate = n * (n - 1) * steps / wall
+                entry.update({"kernel_variant": sim.variant, "ms_per_step": 1e3 * wall / steps, "steps": steps,
+                              "pairs_per_s": rate, "frac": rate / roof,
+                              "k1_avg_launch_ms": f_ms, "k1_frac": FLOPS_PER_PAIR * n * (n - 1) / (f_ms * 1e-3) / 1e12 /
+                              (PEAK_FP32_TFLOPS * (0.5 if precision == "f64" else 1.0)) if f_ms > 0 else None,
+                              "max_rel_err_vs_fp64_direct_sum": chk["max_rel_err_vs_fp64_direct_sum"],
+                              "tolerance": chk["tolerance"], "pass": chk["pass"]})
+                if not chk["pass"]:
+                    entry.update({"withheld_frac": entry["frac"], "frac": None, "pairs_per_s": None})
+        except Exception as e:      # a secondary measurement never takes the headline down silently: it fails the run
+            entry.update({"error": str(e), "pass": False, "frac": None})
+        out.append(entry)
+
+    cb, cv = ic.uniform_cube(65536, seed=2)
+    run("config 2: N=65536 uniform cube, fp32, default shape", cb, cv, 1e-3, 1.0, "f32", 0, 150, 250, 20)
+    run("config 2: N=65536 uniform cube, fp32, LDS tile=256 kernel (variant 28)", cb, cv, 1e-3, 1.0, "f32", 28, 150, 250, 20)
+    pb, pv = ic.plummer(N_HEADLINE, seed=1)
+    run("config 5: N=262144 Plummer sphere, fp64", pb, pv, 1e-3, 1.0, "f64", 0, 1, 3, 3)
+    try:
+        gb, gv, gp = ic.reference_galaxies(os.path.join(ROOT, "tests", "golden", "galaxy40002_params.json"))
+        run("reference default: N=40002, 2 galaxies x 20000 + central masses 1e7, G=dt=1e-4 (index.html:68-74), fp32",
+            gb, gv, 1e-4, gp["G"], "f32", 0, 400, 700, 40)
+    except Exception as e:
+        out.append({"workload": "reference default: N=40002 galaxies", "error": str(e), "pass": False, "frac": None})
+    return out
+
+
 def main():
     args = parse()
     if "RANK" not in os.environ and args.gpus > 1:
@@ -254,9 +320,21 @@ def main():
 
     import torch
     from nbody3d_amd import Simulation, capi, ic
-    if not os.path.exists(capi.library_path()) and rank == 0:
-        import __graft_entry__
-        __graft_entry__.build()       # fresh checkout: compile the engine (never a CPU fallback)
+    if not os.path.exists(capi.library_path()):
+        # fresh checkout: rank 0 compiles the engine (never a CPU fallback); the other ranks wait until it has finished
+        # (the process group does not exist yet, so the rendezvous is a stamp file of this launch, written after the build)
+        import tempfile
+        stamp = os.path.join(tempfile.gettempdir(), "nb_engine_built_%s" % os.environ.get("MASTER_PORT", "0"))   # per launch
+        if rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+            open(stamp, "w").write("ok\n")
+        else:
+            t_wait = time.time()
+            while not (os.path.exists(stamp) and os.path.exists(capi.library_path())):
+                if time.time() - t_wait > 900:
+                    sys.exit("bench.py: rank %d: the engine library was not built within 15 min" % rank)
+                time.sleep(0.5)
     from nbody3d_amd.shard import (ShardPlan, torch_allgather_hook, torch_allgather_overlapped_hooks,
                                    torch_allgather_via_host_hook)
 
@@ -274,8 +352,11 @@ def main():
     dist = None
     if world > 1 or args.force_dist:
         import torch.distributed as dist
-        if "MASTER_ADDR" not in os.environ:      # --force-dist without a launcher
-            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29533", RANK="0", WORLD_SIZE="1")
+        if "MASTER_ADDR" not in os.environ:      # --force-dist without a launcher: a free port, not a fixed one
+            with socket.socket() as sk:
+                sk.bind(("127.0.0.1", 0))
+                free_port = sk.getsockname()[1]
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port), RANK="0", WORLD_SIZE="1")
         if rehearsal:
             dist.init_process_group("gloo")
         else:
@@ -296,23 +377,52 @@ def main():
     if dist is not None:
         sim = None
         if args.exchange == "native":
-            # the engine owns stream and buffers; the only thing the host moves is the ncclUniqueId
+            # the engine owns stream and buffers; the only thing the host moves is the ncclUniqueId.
+            # Every rank must take the SAME path: ncclCommInitRank blocks until all ranks have called it, so the ranks
+            # first agree that each of them CAN call it (librccl loads, the handle exists, the partition is the one
+            # ncclAllGather needs), then all call it, then agree on the outcome; one failure anywhere sends every rank
+            # to the torch path together (a lone rank falling back would leave the others in mismatched collectives).
+            def agree(flag):
+                t = torch.tensor([1 if flag else 0], device="cuda", dtype=torch.int32)
+                dist.all_reduce(t, op=dist.ReduceOp.MIN)
+                return bool(t.item())
+
+            why = None
             try:
+                my_uid = capi.rccl_unique_id()          # loads librccl on EVERY rank (rank 0's id is the one used)
+                sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count), **kw)
+                if plan.padded_n != world * plan.count or plan.begin != rank * plan.count:
+                    raise RuntimeError("partition is not nranks equal row blocks")
+            except Exception as e:
+                why = "precondition: " + str(e)
+            if agree(why is None):
                 uid = torch.zeros(capi.NB_RCCL_ID_BYTES, dtype=torch.uint8, device="cuda")
                 if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(capi.rccl_unique_id()), dtype=torch.uint8))
+                    uid.copy_(torch.frombuffer(bytearray(my_uid), dtype=torch.uint8))
                 dist.broadcast(uid, src=0)
-                sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count), **kw)
-                sim.rccl_attach(bytes(uid.cpu().numpy().tobytes()), world, rank, overlap=overlap)
+                try:
+                    sim.rccl_attach(bytes(uid.cpu().numpy().tobytes()), world, rank, overlap=overlap)
+                except Exception as e:
+                    why = "attach: " + str(e)
+                if not agree(why is None) and why is None:
+                    why = "attach failed on another rank"
+            elif why is None:
+                why = "precondition failed on another rank"
+            if why is None:
                 nr, rk, ver = sim.rccl_info()
+                shp = sim.shape_info()
                 exchange = {"kind": "rccl-native in-place ncclAllGather on the engine stream" +
                                     (" (overlapped: own-row force work first)" if overlap else ""),
-                            "rccl_nranks": nr, "rccl_rank": rk, "rccl_version": ver}
-            except Exception as e:     # keep the run alive on torch's collective, and say so
+                            "rccl_nranks": nr, "rccl_rank": rk, "rccl_version": ver,
+                            "overlap_requested": bool(overlap),
+                            # the overlapped form only hides the gather when some j-partitions lie inside the rank's own rows
+                            "overlap_engaged": bool(overlap and shp["own_splits"] > 0),
+                            "own_splits": shp["own_splits"], "jsplit": shp["jsplit"]}
+            else:                      # keep the run alive on torch's collective -- every rank together -- and say so
                 if sim is not None:
                     sim.close()
                 sim = None
-                exchange = {"native_attach_failed": str(e)}
+                exchange = {"native_attach_failed": why}
         if sim is None:
             # torch owns the replicated bodies array so its collective runs on it directly
             stream = torch.cuda.current_stream()
@@ -326,6 +436,9 @@ def main():
             elif overlap:
                 sim.set_exchange_overlapped(*torch_allgather_overlapped_hooks(t_bodies, plan))
                 exchange["kind"] = "torch.distributed all_gather_into_tensor (nccl = RCCL), async, via exchange hooks"
+                shp = sim.shape_info()
+                exchange.update({"overlap_requested": True, "overlap_engaged": shp["own_splits"] > 0,
+                                 "own_splits": shp["own_splits"], "jsplit": shp["jsplit"]})
             else:
                 sim.set_exchange(torch_allgather_hook(t_bodies, plan))
                 exchange["kind"] = "torch.distributed all_gather_into_tensor (nccl = RCCL) via exchange hook"
@@ -466,6 +579,11 @@ def main():
     if rank == 0 and not args.no_check:
         out["check"] = fixture_check()
         ok = ok and out["check"]["pass"]
+    default_run = (world == 1 and dist is None and not args.n and args.workload == "plummer" and args.precision == "f32"
+                   and not args.variant and not args.jsplit and not args.flags)
+    if default_run and not args.no_also:
+        out["also"] = also_measurements(Simulation, ic, local_rank)
+        ok = ok and all(e.get("pass") for e in out["also"])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(bodies, G, args.cpu_seconds)
     if dist is not None:

@@ -66,6 +66,11 @@ typedef enum nb_precision { NB_F32 = 0, NB_F64 = 1 } nb_precision;
                                 once its i-block is reduced, so a partial that is ever read stale (a missing
                                 release / acquire between workgroups) shows as NaN instead of a small error */
 
+#define NB_FLAG_JPK_FENCED 32u /* the j-packed step (K = 6) hands its partial sums between workgroups with a plain store +
+                                  agent-scope RELEASE on the ticket (the form the compiler's memory model guarantees on any
+                                  part / partition mode) instead of write-through (sc1) stores + a relaxed ticket: the
+                                  conservative fallback, 2-8 us per step slower; bit-identical results */
+
 /* nb_array: selector for nb_device_ptr */
 typedef enum nb_array { NB_BODIES = 0, NB_VEL = 1, NB_ACCEL = 2 } nb_array;
 
@@ -263,6 +268,14 @@ int nb_integrate_pass(nb_sim *s, uint32_t reps, double *avg_ms);
 /* Name of the force-kernel variant a handle resolved to (for reports), e.g.
  * "f32pk_fused_lds1024_ipl2_ls64" or "f32pk_sgpr_ipl8_ws4_js8".  Valid until nb_destroy. */
 const char *nb_variant_name(nb_sim *s);
+
+/* Launch-shape facts of a handle (for reports and tests): the number of j-partitions the force pass runs
+ * (grid.y), the bodies per partition, and which partitions lie ENTIRELY inside the handle's own rows -- the
+ * part of the next force pass that the overlapped exchange (NB_RCCL_OVERLAP / nb_set_exchange_overlapped)
+ * issues before it waits for the other ranks' rows.  own_splits == 0 means the overlapped forms degenerate to
+ * begin-then-wait on this handle.  Any out pointer may be NULL. */
+int nb_shape_info(nb_sim *s, uint32_t *jsplit, uint32_t *j_per_split, uint32_t *own_split0,
+                  uint32_t *own_splits);
 
 /* ---- viewer frame feed ------------------------------------------------
  * The reference's render pass reads bodyBuffer and velBuffer in place every frame

@@ -460,6 +460,7 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
             const ncclResult_t r2 = api->GroupEnd();
             if (r == ncclSuccess) r = r2;
             if (r != ncclSuccess) return mfail(m, NB_ERR_COMM, std::string("nb_multi_step: ncclAllGather: ") + api->GetErrorString(r));
+            for (nb_sim* s : m->shard) s->gm_ok = false;     // the other shards' rows of the (x, y, z, G*m) copy are stale now
             continue;
         }
         // all-gather by direct copies: shard e pulls the new rows of every other shard d
@@ -476,6 +477,7 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
             NB_MHIP(m, hipEventRecord(m->ev_copied[e], dst->stream));
         }
         m->copied_pending = true;
+        for (nb_sim* s : m->shard) s->gm_ok = false;         // as above
     }
     return NB_OK;
 }

@@ -215,16 +215,37 @@ void name_variant(nb_sim* s, const Shape& sh)
 //   there are at most 128 splits.
 struct Cand { Shape sh; double cyc_iter; };   // SIMD cycles of one wave per loop iteration (= LS j-bodies)
 
-void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
+// Constants of the launch-shape model.  A release build compiles them in; a calibration build (make TUNING=1:
+// -DNB_TUNING, used by tools/fit_model.py) reads the NB_MODEL_* environment variables ONCE per process instead.
+struct ModelKnobs {
+    double tile_latency = 3000.0, prologue = 3000.0, hand_over = 350.0, lanes_scale = 1.0;
+    double boundary = 4e-6;    // K1 -> K2 boundary + the K2 launch (refit on shape_scan_final_2k_16k.txt:
+                               // worst regret 8.5 -> 4.8 %, mean 1.6 -> 1.0 % over 14 sizes; fused shapes now to N = 12,000)
+    double sustained = 0.958;  // share of hipDeviceProp_t::clockRate the chip holds under this kernel's load
+                               // (2.24-2.29 of 2.4 GHz measured, profiles/r02/rocprof_f32_default: GRBM_GUI_ACTIVE)
+};
+const ModelKnobs& model_knobs()
+{
+    static const ModelKnobs k = [] {
+        ModelKnobs m;
+#ifdef NB_TUNING
+        auto knob = [](const char* name, double dflt) { const char* e = getenv(name); return e && *e ? atof(e) : dflt; };
+        m.tile_latency = knob("NB_MODEL_TILE_LATENCY", m.tile_latency); m.prologue = knob("NB_MODEL_PROLOGUE", m.prologue);
+        m.hand_over = knob("NB_MODEL_HANDOVER", m.hand_over); m.lanes_scale = knob("NB_MODEL_LANES_SCALE", m.lanes_scale);
+        m.boundary = knob("NB_MODEL_BOUNDARY", m.boundary); m.sustained = knob("NB_MODEL_SUSTAINED", m.sustained);
+#endif
+        return m;
+    }();
+    return k;
+}
+
+void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
 {
     const uint32_t sc = s->sc, n = s->n;
     const uint32_t kMaxSplit = 128, kMinSplitLen = 128;
-    // model constants; the NB_MODEL_* environment variables override them for calibration runs (tools/fit_model.py)
-    auto knob = [](const char* name, double dflt) { const char* e = getenv(name); return e && *e ? atof(e) : dflt; };
-    const double kTileLatency = knob("NB_MODEL_TILE_LATENCY", 3000.0), kPrologue = knob("NB_MODEL_PROLOGUE", 3000.0), kClock = 2.3e9;
-    const double kHandOver = knob("NB_MODEL_HANDOVER", 350.0), kLanesScale = knob("NB_MODEL_LANES_SCALE", 1.0);
-    const double kBoundary = knob("NB_MODEL_BOUNDARY", 4e-6);   // K1 -> K2 boundary + the K2 launch (refit on shape_scan_final_2k_16k.txt:
-                                                                    // worst regret 8.5 -> 4.8 %, mean 1.6 -> 1.0 % over 14 sizes; fused shapes now to N = 12,000)
+    const ModelKnobs& mk = model_knobs();
+    const double kTileLatency = mk.tile_latency, kPrologue = mk.prologue, kClock = clock_hz * mk.sustained;
+    const double kHandOver = mk.hand_over, kLanesScale = mk.lanes_scale, kBoundary = mk.boundary;
     auto split_len = [&](uint32_t js) { return ceil_div(ceil_div(n, js), 8u) * 8u; };
     // an explicit shard (even one that covers every row: a 1-rank distributed run) keeps the
     // two-kernel step, whose position array stays put for the exchange
@@ -422,14 +443,15 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu)
     s->j_per_split = split_len(js);
     s->jsplit = ceil_div(n, s->j_per_split);   // a split may end up empty after rounding
     s->swap_acc = !s->fused && s->jsplit == 1;
-    // j-splits that lie entirely inside this shard's own rows (overlapped exchange)
+    // j-splits that lie ENTIRELY inside this shard's own rows: what the overlapped exchange issues before it waits for
+    // the other ranks' rows (an in-place all-gather never writes the rank's own rows).  The shard need not be a whole
+    // number of splits: a split that straddles a shard boundary simply belongs to the second launch.
     s->own_split0 = 0; s->own_splits = 0;
-    if (sc < n && s->sb % s->j_per_split == 0) {
+    if (sc < n) {
         const uint32_t end = s->sb + sc;
-        if (end % s->j_per_split == 0 || end == n) {
-            s->own_split0 = s->sb / s->j_per_split;
-            s->own_splits = ceil_div(end, s->j_per_split) - s->own_split0;
-        }
+        const uint32_t first = ceil_div(s->sb, s->j_per_split);
+        const uint32_t last = end == n ? s->jsplit : end / s->j_per_split;     // one past the last whole split inside
+        if (last > first) { s->own_split0 = first; s->own_splits = last - first; }
     }
     name_variant(s, sh);
 }
@@ -442,6 +464,29 @@ Shape shape_of(const nb_sim* s)
     if (s->sgpr) return {kPkSgpr, s->ipl, 1, s->ws};
     if (s->packed) return {kPkLds, s->ipl, s->ls, s->tl};
     return {kScalar, s->ipl, s->ls, 1};
+}
+
+// The packed f32 K1 forms stream their j-bodies as (x, y, z, G*m) rows (nb_internal.h, `gm`).
+bool streams_gm(const nb_sim* s) { return !s->f64 && s->packed && !s->jpk; }
+bool gm_active(const nb_sim* s) { return streams_gm(s) && (float)s->G != 1.0f; }
+const void* jstream(const nb_sim* s, int k) { return gm_active(s) ? s->gm[k] : s->bodies[k]; }
+
+// Makes gm[cur] current (allocates on first use; a no-op for G == 1 and for the kernels that fold G themselves).
+int ensure_gm(nb_sim* s)
+{
+    if (!gm_active(s)) { s->gm_ok = false; return NB_OK; }      // steps taken meanwhile leave any old copy behind
+    const size_t bytes = (size_t)16 * s->n;
+    for (int k = 0; k < (s->fused ? 2 : 1); ++k)
+        if (!s->gm[k]) NB_HIP(s, hipMalloc(&s->gm[k], bytes));
+    if (s->gm_ok && s->gm_G == s->G) return NB_OK;
+    const float4* b = (const float4*)s->bodies[s->cur];
+    float4* g = (float4*)s->gm[s->cur];
+    uint32_t n = s->n;
+    float G = (float)s->G;
+    void* args[] = {&b, &g, &n, &G};
+    NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_gm_pack<0>, dim3(ceil_div(n, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
+    s->gm_ok = true; s->gm_G = s->G;
+    return NB_OK;
 }
 
 // part: 0 = all splits, 1 = only the splits inside this shard's own rows,
@@ -465,12 +510,12 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
     else if (part == 2) { win.hole_begin = s->own_split0; win.hole_count = s->own_splits; ny = s->jsplit - s->own_splits; }
     if (ny == 0) return;
     dim3 grid(ceil_div(s->sc, ipb_of(sh)), ny), block(nb::kBlock);
-    const V4* b = (const V4*)s->bodies[s->cur];
+    const V4* b = (const V4*)jstream(s, s->cur);    // packed f32 forms: rows (x, y, z, G*m); scalar template: (x, y, z, m) and G
     V4* p = (V4*)s->partial;
     T G = (T)s->G, e2 = (T)s->eps2;
     uint32_t n = s->n, sb = s->sb, sc = s->sc, jps = s->j_per_split;
-    const void* zr = s->zero_row;     // trailing parameter of the packed LDS-tile kernels only (LDS-DMA source for j past the range)
-    void* args[] = {&b, &p, &n, &sb, &sc, &G, &e2, &jps, &win, &zr};   // the other kernels declare nine parameters and never see it
+    const V4* zr = (const V4*)s->zero_row;          // LDS-DMA source for j past the range (packed LDS-tile kernels)
+    void* args[] = {&b, &p, &n, &sb, &sc, &G, &e2, &jps, &win, &zr};   // every K1 form declares exactly these ten parameters
     launch_kernel(kernel_of(s->f64, sh), grid, block, args, s->stream, t0, t1);
 }
 
@@ -498,7 +543,7 @@ void launch_jpk(nb_sim* s, hipEvent_t t0, hipEvent_t t1)
     float4 *bout = (float4*)s->bodies[s->cur ^ 1], *pout = (float4*)s->pairs[s->cur ^ 1];
     float4 *v = (float4*)s->vel, *a = (float4*)s->acc, *part = (float4*)s->jpartial;
     uint32_t* tk = s->tickets;
-    uint32_t n = s->n, upw = s->junits, poison = s->poison ? 1u : 0u;
+    uint32_t n = s->n, upw = s->junits, poison = (s->poison ? 1u : 0u) | (s->jpk_fenced ? 2u : 0u);
     float G = (float)s->G, e2 = (float)s->eps2, dt = (float)s->dt;
     void* args[] = {&bin, &pin, &bout, &pout, &v, &a, &part, &tk, &n, &upw, &poison, &G, &e2, &dt};
     launch_kernel(kernel_of(false, sh), grid, block, args, s->stream, t0, t1);
@@ -510,13 +555,13 @@ void launch_fused(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullptr)
     if (s->jpk) { ensure_pairs(s); launch_jpk(s, t0, t1); return; }
     const Shape sh = shape_of(s);
     dim3 grid(ceil_div(s->n, ipb_of(sh))), block(nb::kBlock);
-    const float4* bin = (const float4*)s->bodies[s->cur];
-    float4* bout = (float4*)s->bodies[s->cur ^ 1];
+    const float4 *bin = (const float4*)s->bodies[s->cur], *jin = (const float4*)jstream(s, s->cur);
+    float4 *bout = (float4*)s->bodies[s->cur ^ 1], *gout = gm_active(s) ? (float4*)s->gm[s->cur ^ 1] : nullptr;
     float4 *v = (float4*)s->vel, *a = (float4*)s->acc;
     uint32_t n = s->n;
     float G = (float)s->G, e2 = (float)s->eps2, dt = (float)s->dt;
-    const void* zr = s->zero_row;
-    void* args[] = {&bin, &bout, &v, &a, &n, &G, &e2, &dt, &zr};
+    const float4* zr = (const float4*)s->zero_row;
+    void* args[] = {&bin, &jin, &bout, &gout, &v, &a, &n, &G, &e2, &dt, &zr};   // nb_step_fused and nb_step_direct: the same eleven
     launch_kernel(kernel_of(false, sh), grid, block, args, s->stream, t0, t1);
     s->cur ^= 1;
 }
@@ -527,12 +572,14 @@ void launch_integrate(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullpt
     using V4 = typename nb::vec4<T>::type;
     V4 *b = (V4*)s->bodies[s->cur], *v = (V4*)s->vel;
     uint32_t sb = s->sb, sc = s->sc, js = s->jsplit;
-    T dt = (T)s->dt;
+    T dt = (T)s->dt, G = (T)s->G;
+    // the j-stream rows of the new positions; a handle whose rows are exchanged rebuilds the whole copy after the gather instead
+    V4* gout = gm_active(s) && !(s->xfn || s->rccl) ? (V4*)s->gm[s->cur] : nullptr;
     if (s->swap_acc) {
         // jsplit == 1: the single partial array IS a_new; K2 reads it beside a_old and the two
         // buffers swap roles (no 16-B store of a per body: 96 B per body in all)
         const V4 *ao = (const V4*)s->acc, *an = (const V4*)s->partial;
-        void* args[] = {&b, &v, &ao, &an, &sb, &sc, &dt};
+        void* args[] = {&b, &v, &ao, &an, &sb, &sc, &dt, &gout, &G};
         launch_kernel((const void*)&nb::nb_integrate_swap<T>, dim3(ceil_div(sc, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
         std::swap(s->acc, s->partial);
         s->acc_parity ^= 1;
@@ -542,7 +589,7 @@ void launch_integrate(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullpt
     const int R = js >= 32 ? 8 : js >= 8 ? 4 : 1;
     V4* a = (V4*)s->acc;
     const V4* p = (const V4*)s->partial;
-    void* args[] = {&b, &v, &a, &p, &sb, &sc, &js, &dt};
+    void* args[] = {&b, &v, &a, &p, &sb, &sc, &js, &dt, &gout, &G};
     const void* fn = R == 8 ? (const void*)&nb::nb_integrate<T, 8> : R == 4 ? (const void*)&nb::nb_integrate<T, 4> : (const void*)&nb::nb_integrate<T, 1>;
     launch_kernel(fn, dim3(ceil_div(sc * (uint32_t)R, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
 }
@@ -581,6 +628,7 @@ bool ensure_graph(nb_sim* s, int which)
     void *acc0 = s->acc, *par0 = s->partial;
     const int cur0 = s->cur, par_bit0 = s->acc_parity;
     ensure_pairs(s);             // not part of the captured steps
+    if (ensure_gm(s) != NB_OK) { s->graphs_ok = false; return false; }
     if (hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal) != hipSuccess) { s->graphs_ok = false; return false; }
     for (uint32_t k = 0; k < kGraphSteps[which]; ++k) launch_step(s);
     hipGraph_t g = nullptr;
@@ -632,6 +680,7 @@ void free_frames(nb_sim* s)
         f = nb_frame_slot();
     }
     if (s->frame_stream) { (void)hipStreamDestroy(s->frame_stream); s->frame_stream = nullptr; }
+    s->frame_next = 0; s->frame_latest = -1;
 }
 
 }  // namespace
@@ -702,7 +751,8 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     if (cfg.ext_stream || (cfg.flags & NB_FLAG_EXT_STREAM)) { s->stream = (hipStream_t)cfg.ext_stream; s->own_stream = false; }
     else { NB_HIPC(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
 
-    choose_shape(s, cfg, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256);
+    choose_shape(s, cfg, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256,
+                 prop.clockRate > 0 ? 1e3 * prop.clockRate : 2.4e9);     // clockRate is in kHz
     if (!kernel_of(s->f64, shape_of(s))) return bail(NB_ERR_INVALID, "nb_create: no kernel for shape " + s->variant);
 
     const size_t row = 4 * s->esz;
@@ -729,6 +779,7 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
         }
         NB_HIPC(hipDeviceSynchronize());
         s->poison = (cfg.flags & NB_FLAG_POISON) != 0;
+        s->jpk_fenced = (cfg.flags & NB_FLAG_JPK_FENCED) != 0;
     }
     NB_HIPC(hipMalloc(&s->zero_row, 64));                     // a zero-mass body at the origin: what the LDS-DMA staging
     NB_HIPC(hipMemsetAsync(s->zero_row, 0, 64, s->stream));   // of the packed tile kernels reads for rows past the range (stream-ordered)
@@ -758,6 +809,7 @@ void nb_destroy(nb_sim* s)
     if (s->acc) (void)hipFree(s->acc);
     if (s->partial) (void)hipFree(s->partial);
     for (auto& p : s->pairs) if (p) (void)hipFree(p);
+    for (auto& p : s->gm) if (p) (void)hipFree(p);
     if (s->jpartial) (void)hipFree(s->jpartial);
     if (s->tickets) (void)hipFree(s->tickets);
     if (s->diag) (void)hipFree(s->diag);
@@ -790,6 +842,7 @@ int nb_upload(nb_sim* s, const void* bodies, const void* vel, const void* accel)
     }
     s->uploaded = true;
     s->pairs_ok = false;
+    s->gm_ok = false;
     return NB_OK;
 }
 
@@ -810,6 +863,8 @@ int nb_step(nb_sim* s, uint32_t nsteps)
     NB_HIP(s, hipSetDevice(s->device));
     const bool exchange = s->xfn || s->rccl;
     ensure_pairs(s);      // the j-packed step's position copy, if something outside the step rewrote the positions or G
+    if (gm_active(s) && !s->gm_ok) { if (int rc = finish_gather(s)) return rc; }
+    if (int rc = ensure_gm(s)) return rc;   // the packed K1 forms' (x, y, z, G*m) j-stream, likewise
     // Multi-step calls on the engine's own stream replay a captured graph of
     // kGraphChunk steps (no exchange, no per-kernel timing requested).
     if (s->own_stream && s->graphs_ok && !exchange && !s->timing && nsteps >= kGraphChunk) {
@@ -822,6 +877,13 @@ int nb_step(nb_sim* s, uint32_t nsteps)
         }
     }
     for (uint32_t k = 0; k < nsteps; ++k) {
+        if (exchange && gm_active(s) && !s->gm_ok) {
+            // G != 1 on a handle whose rows are exchanged: the other ranks' rows of the j-stream copy are rebuilt from the
+            // gathered positions (one small launch per step; the overlapped form waits here, so it only overlaps at G == 1,
+            // which every multi-GPU configuration of BASELINE.json uses)
+            if (int rc = finish_gather(s)) return rc;
+            if (int rc = ensure_gm(s)) return rc;
+        }
         nb_events ev;
         const bool rec = s->timing && get_events(s, &ev) == 0;
         hipEvent_t* e = rec ? ev.e : nullptr;
@@ -845,6 +907,7 @@ int nb_step(nb_sim* s, uint32_t nsteps)
         }
         NB_HIP(s, hipGetLastError());
         ++s->steps_done;
+        if (exchange) s->gm_ok = false;
         if (s->rccl) {
             if (int rc = nbi::rccl_exchange_begin(s)) return rc;
             if (nbi::rccl_overlapped(s)) {
@@ -895,7 +958,7 @@ int nb_device_ptr(nb_sim* s, int which, void** out)
 {
     if (!s || !out) return NB_ERR_INVALID;
     switch (which) {
-        case NB_BODIES: *out = s->bodies[s->cur]; s->pairs_ok = false; break;   // the caller may write through it
+        case NB_BODIES: *out = s->bodies[s->cur]; s->pairs_ok = false; s->gm_ok = false; break;   // the caller may write through it
         case NB_VEL: *out = s->vel; break;
         case NB_ACCEL: *out = s->acc; break;
         default: return fail(s, NB_ERR_INVALID, "nb_device_ptr: unknown array");
@@ -994,6 +1057,16 @@ int nb_integrate_pass(nb_sim* s, uint32_t reps, double* avg_ms)
 
 const char* nb_variant_name(nb_sim* s) { return s ? s->variant.c_str() : ""; }
 
+int nb_shape_info(nb_sim* s, uint32_t* jsplit, uint32_t* j_per_split, uint32_t* own_split0, uint32_t* own_splits)
+{
+    if (!s) return NB_ERR_INVALID;
+    if (jsplit) *jsplit = s->jsplit;
+    if (j_per_split) *j_per_split = s->j_per_split;
+    if (own_split0) *own_split0 = s->own_split0;
+    if (own_splits) *own_splits = s->own_splits;
+    return NB_OK;
+}
+
 int nb_diagnostics(nb_sim* s, double out[5])
 {
     if (!s || !out) return NB_ERR_INVALID;
@@ -1026,20 +1099,42 @@ int nb_frame_request(nb_sim* s)
     NB_HIP(s, hipSetDevice(s->device));
     if (int rc = finish_gather(s)) return rc;     // other ranks' rows must have landed
     if (!s->frame_stream) {
-        NB_HIP(s, hipStreamCreateWithFlags(&s->frame_stream, hipStreamNonBlocking));
+        // all or nothing: the stream is only published once every slot has its buffers and events -- a failed
+        // allocation (4 x 20*n bytes pinned + device) returns an error and leaves the handle without a frame feed,
+        // so that a later request starts over instead of packing into null buffers
+        hipStream_t fs = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&fs, hipStreamNonBlocking);
+        int slot = 0;
         for (auto& f : s->frame) {
+            if (e != hipSuccess) break;
+#ifdef NB_TUNING    // calibration / test build only: fail the k-th slot's allocation (tests/test_round3_gpu.py)
+            if (const char* inj = getenv("NB_TEST_FAIL_FRAME_SLOT")) { if (atoi(inj) == slot) { e = hipErrorOutOfMemory; break; } }
+#endif
+            ++slot; (void)slot;
             // one allocation per side (bodies[4n] then speed[n]): ONE device-to-host copy per frame
-            NB_HIP(s, hipHostMalloc((void**)&f.h_bodies, sizeof(float) * 5 * s->n, hipHostMallocDefault));
+            e = hipHostMalloc((void**)&f.h_bodies, sizeof(float) * 5 * s->n, hipHostMallocDefault);
+            if (e != hipSuccess) break;
             f.h_speed = f.h_bodies + (size_t)4 * s->n;
             memset(f.h_speed, 0, sizeof(float) * s->n);
-            NB_HIP(s, hipMalloc((void**)&f.d_bodies, sizeof(float) * 5 * s->n));
+            e = hipMalloc((void**)&f.d_bodies, sizeof(float) * 5 * s->n);
+            if (e != hipSuccess) break;
             f.d_speed = f.d_bodies + (size_t)4 * s->n;
-            NB_HIP(s, hipMemsetAsync(f.d_speed, 0, sizeof(float) * s->n, s->stream));   // ordered before the pack kernel
-            NB_HIP(s, hipEventCreate(&f.packed));     // stamped by hipExtLaunchKernel
-            NB_HIP(s, hipEventCreateWithFlags(&f.landed, hipEventDisableTiming));
+            e = hipMemsetAsync(f.d_speed, 0, sizeof(float) * s->n, s->stream);   // ordered before the pack kernel
+            if (e == hipSuccess) e = hipEventCreate(&f.packed);     // stamped by hipExtLaunchKernel
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&f.landed, hipEventDisableTiming);
         }
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipStreamSynchronize(s->stream);       // the memsets above
+            s->frame_stream = fs;                        // free_frames destroys it with the partly built slots
+            free_frames(s);
+            return fail(s, e == hipErrorOutOfMemory ? NB_ERR_NOMEM : NB_ERR_HIP,
+                        std::string("nb_frame_request: cannot set up the frame slots: ") + hipGetErrorString(e));
+        }
+        s->frame_stream = fs;
     }
     nb_frame_slot& f = s->frame[s->frame_next];
+    if (!f.h_bodies || !f.d_bodies || !f.packed || !f.landed) return fail(s, NB_ERR_STATE, "nb_frame_request: frame slot is not initialised");
     // the host copy issued from this slot kFrameSlots requests ago must have finished reading its
     // staging buffer (normally long done; a host that runs further ahead than that is held back
     // here, on the host side); the step stream itself never waits for a copy

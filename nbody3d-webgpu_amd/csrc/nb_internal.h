@@ -44,6 +44,13 @@ struct nb_sim {
     void* bodies[2] = {nullptr, nullptr};
     int cur = 0;
     bool own_bodies = false;
+    // The j-stream of the packed f32 K1 forms (LDS-tile, SGPR, fused, registers-only): rows (x, y, z, G*m), so that a pair
+    // multiplies (G*m_j)*inv as the reference does (nbody3d.js:236) at no per-pair cost.  With G == 1 it IS bodies[k]
+    // (no copy); otherwise gm[k] goes with bodies[k]: rebuilt by nb_gm_pack when the positions were written from outside the
+    // step (upload, exchange, raw pointer) or G changed, and kept current by K2 / the fused epilogues for the rows they write.
+    void* gm[2] = {nullptr, nullptr};
+    bool gm_ok = false;            // gm[cur] matches bodies[cur] and gm_G
+    double gm_G = 0.0;
     void* vel = nullptr;
     void* acc = nullptr;
     void* partial = nullptr;
@@ -71,6 +78,7 @@ struct nb_sim {
     uint32_t* tickets = nullptr;   // one arrival counter per i-block, zero between launches
     uint32_t junits = 0;           // 4-pair units per wave
     bool poison = false;           // NB_FLAG_POISON
+    bool jpk_fenced = false;       // NB_FLAG_JPK_FENCED: release-fenced ticket instead of write-through partial stores
     int acc_parity = 0;    // swap_acc: how often acc/partial have swapped roles (mod 2)
     bool swap_acc = false; // two-kernel step with jsplit == 1: K2 reads the partial as a_new and the
                            // acc/partial buffers swap roles (96 B per body)

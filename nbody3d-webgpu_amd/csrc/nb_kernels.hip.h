@@ -256,7 +256,8 @@ template <typename T, int IPL, int LS>
 __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type* __restrict__ bodies,
                                                   typename vec4<T>::type* __restrict__ partial, uint32_t n,
                                                   uint32_t i_begin, uint32_t i_count, T G, T eps2,
-                                                  uint32_t j_per_split, SplitWindow win)
+                                                  uint32_t j_per_split, SplitWindow win,
+                                                  const typename vec4<T>::type* __restrict__ /* zero_row: every K1 form takes the same ten parameters */)
 {
     using V4 = typename vec4<T>::type;
     static_assert(LS >= 1 && LS <= 64 && (LS & (LS - 1)) == 0, "LS must be a power of two <= 64");
@@ -394,11 +395,12 @@ struct PkCore {
     static_assert(TL == 1 || TL == 4 || TL == 8, "TL is 1, 4 or 8");
     static_assert(NC >= 4, "the ordered rsq / multiply statements of a stage rely on >= 4 chains");
 
-    // Accumulates G * sum_{j in [j0, j1)} m_j r_ij / (|r_ij|^2 + eps2)^{3/2} for the lane's 2*NG bodies over the
-    // lane's share of j (every LS-th body of each tile).  G multiplies the finished sums (as in
-    // nb_force_pk_sgpr: rounding only; identical bits when G = 1).
+    // Accumulates sum_{j in [j0, j1)} (G m_j) r_ij / (|r_ij|^2 + eps2)^{3/2} for the lane's 2*NG bodies over the
+    // lane's share of j (every LS-th body of each tile).  `bodies` is the j-stream: rows (x, y, z, G*m_j), so that
+    // every pair multiplies (G*m_j) * inv -- the reference's own product, nbody3d.js:236 -- at no per-pair cost
+    // (the engine keeps that copy beside the (x, y, z, m) state whenever G != 1: nb_gm_pack, K2 / the fused epilogues).
     static __device__ __forceinline__ void run(const float4* __restrict__ bodies, const float4* __restrict__ zero_row,
-                                               const uint32_t j0, const uint32_t j1, const float G, const float eps2,
+                                               const uint32_t j0, const uint32_t j1, const float eps2,
                                                const nb_f2 (&xi)[NG], const nb_f2 (&yi)[NG], const nb_f2 (&zi)[NG],
                                                nb_f2 (&ax)[NG], nb_f2 (&ay)[NG], nb_f2 (&az)[NG])
     {
@@ -547,9 +549,6 @@ struct PkCore {
                 az[g] = nb_f2{r[6 * g + 4], r[6 * g + 5]};
             }
         }
-        const nb_f2 g2 = nb_f2{G, G};
-#pragma unroll
-        for (int g = 0; g < NG; ++g) { ax[g] = g2 * ax[g]; ay[g] = g2 * ay[g]; az[g] = g2 * az[g]; }
         NB_STAMP(3);
     }
 };
@@ -564,7 +563,8 @@ struct PkCore {
 // stage register sets: allow them the 168-VGPR budget of 3 waves per SIMD instead of spilling
 #define NB_PK_WAVES_MIN(NG, TL) ((TL) == 8 ? 2 : ((NG) == 1 && (TL) == 4 ? 3 : 4))
 
-// K1, packed, j-tile in LDS.
+// K1, packed, j-tile in LDS.  `bodies` = the j-stream rows (x, y, z, G*m); the i-rows come from the same array
+// (only x, y, z are used).  G itself is unused here: every K1 form takes the same ten parameters.
 template <int NG, int LS, int TL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NB_PK_WAVES_MIN(NG, TL), NB_PK_WAVES(NG, TL))))
 void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial, uint32_t n, uint32_t i_begin,
@@ -594,7 +594,7 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
     const uint32_t j0 = by * j_per_split;
     uint32_t j1 = j0 + j_per_split;
     if (j1 > n) j1 = n;
-    PkCore<NG, LS, TL>::run(bodies, zero_row, j0, j1, G, eps2, xi, yi, zi, ax, ay, az);
+    PkCore<NG, LS, TL>::run(bodies, zero_row, j0, j1, eps2, xi, yi, zi, ax, ay, az);
 
     if (js == LS - 1) {
         float4* out = partial + (size_t)by * i_count;
@@ -615,10 +615,14 @@ void nb_force_pk(const float4* __restrict__ bodies, float4* __restrict__ partial
 // a different buffer, so no workgroup can stage a half-updated system (the reference's race,
 // nbody3d.js:283 vs :257).  vel/acc are only touched by their own lane: in place.
 // Bit-identical to nb_force_pk<NG,LS,TL> with jsplit = 1 followed by nb_integrate.
+//   bodies_in / bodies_out : the (x, y, z, m) state (ping-pong);
+//   jin                    : the j-stream (x, y, z, G*m) that goes with bodies_in (bodies_in itself when G == 1);
+//   gout                   : where the (x, y, z, G*m) rows of the NEW positions go (null when G == 1).
 template <int NG, int LS, int TL>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NB_PK_WAVES_MIN(NG, TL), NB_PK_WAVES(NG, TL))))
-void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bodies_out, float4* __restrict__ vel,
-                   float4* __restrict__ acc, uint32_t n, float G, float eps2, float dt, const float4* __restrict__ zero_row)
+void nb_step_fused(const float4* __restrict__ bodies_in, const float4* __restrict__ jin, float4* __restrict__ bodies_out,
+                   float4* __restrict__ gout, float4* __restrict__ vel, float4* __restrict__ acc, uint32_t n, float G,
+                   float eps2, float dt, const float4* __restrict__ zero_row)
 {
     constexpr int GROUPS = kBlock / LS;
     constexpr int IPB = GROUPS * 2 * NG;
@@ -651,7 +655,7 @@ void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bo
             v0[2 * g + 1] = ld4(vel + c1); a0[2 * g + 1] = ld4(acc + c1);
         }
     }
-    PkCore<NG, LS, TL>::run(bodies_in, zero_row, 0, n, G, eps2, xi, yi, zi, ax, ay, az);
+    PkCore<NG, LS, TL>::run(jin, zero_row, 0, n, eps2, xi, yi, zi, ax, ay, az);
 
     if (owner) {
 #pragma unroll
@@ -670,6 +674,7 @@ void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bo
                 vel[il] = nv;                                              // :281
                 bodies_out[il] = nx;                                       // :283 (other buffer)
                 acc[il] = na;                                              // :290
+                if (gout) gout[il] = float4{nx.x, nx.y, nx.z, G * nx.w};   // next step's j-stream row
             }
         }
     }
@@ -686,8 +691,9 @@ void nb_step_fused(const float4* __restrict__ bodies_in, float4* __restrict__ bo
 // Same j order per lane and same reduction as nb_step_fused<1,64,*>: bit-identical results.
 template <int MAXJ>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MAXJ > 16 ? 2 : 3, 4)))
-void nb_step_direct(const float4* __restrict__ bodies_in, float4* __restrict__ bodies_out, float4* __restrict__ vel,
-                    float4* __restrict__ acc, uint32_t n, float G, float eps2, float dt)
+void nb_step_direct(const float4* __restrict__ bodies_in, const float4* __restrict__ jin, float4* __restrict__ bodies_out,
+                    float4* __restrict__ gout, float4* __restrict__ vel, float4* __restrict__ acc, uint32_t n, float G,
+                    float eps2, float dt, const float4* __restrict__ /* zero_row: same parameter list as nb_step_fused */)
 {
     constexpr int GROUPS = kBlock / 64;     // one wave per pair of bodies
     constexpr int IPB = GROUPS * 2;
@@ -702,7 +708,7 @@ void nb_step_direct(const float4* __restrict__ bodies_in, float4* __restrict__ b
 #pragma unroll
     for (int k = 0; k < MAXJ; ++k) {
         const uint32_t j = (uint32_t)k * 64u + (uint32_t)js;
-        q[k] = *reinterpret_cast<const nb_v4f*>(bodies_in + (j < n ? j : n - 1));
+        q[k] = *reinterpret_cast<const nb_v4f*>(jin + (j < n ? j : n - 1));      // (x, y, z, G*m)
     }
     // pin all MAXJ loads HERE, ahead of the first stage: left alone the backend sinks the loads of
     // the later stages into those stages' (wave-uniform) branches and pays their latency there
@@ -720,7 +726,7 @@ void nb_step_direct(const float4* __restrict__ bodies_in, float4* __restrict__ b
             for (int u = 0; u < 4; ++u) {
                 const uint32_t j = (uint32_t)(k0 + u) * 64u + (uint32_t)js;
                 const nb_v4f b = q[k0 + u];
-                const float gm = j < n ? b.w : 0.0f;              // past the end: zero mass, contributes exactly 0 (G: below)
+                const float gm = j < n ? b.w : 0.0f;              // past the end: zero mass, contributes exactly 0
                 bx[u] = nb_f2{b.x, b.x}; by[u] = nb_f2{b.y, b.y}; bz[u] = nb_f2{b.z, b.z}; bm[u] = nb_f2{gm, gm};
             }
 #pragma unroll
@@ -753,17 +759,17 @@ void nb_step_direct(const float4* __restrict__ bodies_in, float4* __restrict__ b
     }
     float red[6] = {ax.x, ax.y, ay.x, ay.y, az.x, az.y};
     group_sum_all<64, 6>(red);
-#pragma unroll
-    for (int k = 0; k < 6; ++k) red[k] = G * red[k];        // G on the finished sums, exactly as PkCore::run
     if (js == 63) {
         float4 nx, nv, na;
         if (il0 < n) {
             leapfrog<float>(b0, v0, a0, red[0], red[2], red[4], dt, nx, nv, na);
             vel[il0] = nv; bodies_out[il0] = nx; acc[il0] = na;
+            if (gout) gout[il0] = float4{nx.x, nx.y, nx.z, G * nx.w};
         }
         if (il1 < n) {
             leapfrog<float>(b1, v1, a1, red[1], red[3], red[5], dt, nx, nv, na);
             vel[il1] = nv; bodies_out[il1] = nx; acc[il1] = na;
+            if (gout) gout[il1] = float4{nx.x, nx.y, nx.z, G * nx.w};
         }
     }
 }
@@ -772,8 +778,8 @@ void nb_step_direct(const float4* __restrict__ bodies_in, float4* __restrict__ b
 // "scalar-load (SGPR) j-broadcast A/B against the LDS tile").  j is wave-uniform, so
 // bodies[j] is fetched with s_load_dwordx4 through the scalar cache and the packed ops
 // take the (x,y | z,m) SGPR pairs directly (op_sel broadcast): no LDS tile, no barrier in the
-// loop, no v_mov for the mass.  G is applied once to the finished sums (G * sum(m r^-3 d)
-// instead of sum((G m) r^-3 d): rounding only).
+// loop, no v_mov for the mass.  `bodies` holds the j-stream rows (x, y, z, G*m): (G*m_j)*inv per pair is the
+// reference's own product (nbody3d.js:236); the parameter G is unused (same ten parameters as every K1 form).
 //   WS = 1: the 4 waves of a workgroup hold different i-bodies (256 lanes x 2*NG) and stream the
 //           same j-range;
 //   WS = 4: the 4 waves hold the SAME 64 x 2*NG i-bodies and each streams a quarter of the
@@ -787,7 +793,8 @@ void nb_step_direct(const float4* __restrict__ bodies_in, float4* __restrict__ b
 template <int NG, int WS, bool PAIRS = false>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NG >= 4 ? 4 : 6, NG >= 4 ? 4 : 6)))
 void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ partial, uint32_t n, uint32_t i_begin,
-                      uint32_t i_count, float G, float eps2, uint32_t j_per_split, SplitWindow win)
+                      uint32_t i_count, float G, float eps2, uint32_t j_per_split, SplitWindow win,
+                      const float4* __restrict__ /* zero_row */)
 {
     static_assert(WS == 1 || WS == 4, "WS is 1 or 4");
     constexpr int IPL = 2 * NG;
@@ -1000,8 +1007,8 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
     for (int g = 0; g < NG; ++g) {
         const uint32_t il0 = bxi * IPB + (2 * g) * LANES + lane;
         const uint32_t il1 = il0 + LANES;
-        if (il0 < i_count) out[il0] = float4{G * ax[g].x, G * ay[g].x, G * az[g].x, 0};
-        if (il1 < i_count) out[il1] = float4{G * ax[g].y, G * ay[g].y, G * az[g].y, 0};
+        if (il0 < i_count) out[il0] = float4{ax[g].x, ay[g].x, az[g].x, 0};
+        if (il1 < i_count) out[il1] = float4{ax[g].y, ay[g].y, az[g].y, 0};
     }
 }
 
@@ -1031,7 +1038,8 @@ __device__ __forceinline__ void jstep_finish(float sx, float sy, float sz, const
                                              const uint32_t i, const bool valid, const int lane, const uint32_t n,
                                              float4* __restrict__ bodies_out, float4* __restrict__ pairs_out,
                                              float4* __restrict__ vel, float4* __restrict__ acc, float4* partial,
-                                             uint32_t* ticket, const uint32_t poison, const float G, const float dt)
+                                             uint32_t* ticket, const uint32_t poison /* bit 0: NB_FLAG_POISON, bit 1: NB_FLAG_JPK_FENCED */,
+                                             const float G, const float dt)
 {
     // j split over gridDim.y workgroups (systems with fewer than ~4 i-blocks per CU): every workgroup
     // stores its 64 partial sums, and the one that arrives LAST at the i-block's ticket adds all of them
@@ -1045,13 +1053,18 @@ __device__ __forceinline__ void jstep_finish(float sx, float sy, float sz, const
         // fence.  A release fence is a buffer_wbl2 -- a write-back of the whole L2 -- per workgroup: with it every split form of
         // this kernel was 2-8 us slower per step (N=12,000: 46.3 -> 38.3 us, N=8,192: 22.0 -> 19.8; profiles/r02/
         // ubench5_sc1_vs_fence.txt).  The last arriver still acquires (buffer_inv sc1) before its plain loads.
-        {
+        uint32_t drawn = 0;
+        if (poison & 2u) {
+            // NB_FLAG_JPK_FENCED: the textbook form -- plain store, then an agent-scope RELEASE on the ticket (hipcc emits the
+            // L2 write-back itself).  Inside the compiler's memory model on any part / partition mode; 2-8 us per step slower.
+            *mine = float4{sx, sy, sz, 0.0f};
+            if (lane == 0) drawn = __hip_atomic_fetch_add(ticket + blockIdx.x, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
             const nb_v4f pv = nb_v4f{sx, sy, sz, 0.0f};
             asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(mine), "v"(pv) : "memory");
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) drawn = __hip_atomic_fetch_add(ticket + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        uint32_t drawn = 0;
-        if (lane == 0) drawn = __hip_atomic_fetch_add(ticket + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         drawn = __builtin_amdgcn_readfirstlane(drawn);
         if (drawn != nsplit - 1) return;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1075,7 +1088,7 @@ __device__ __forceinline__ void jstep_finish(float sx, float sy, float sz, const
             sx += p0.x; sy += p0.y; sz += p0.z;
             q += stride;
         }
-        if (poison) {     // validation mode (NB_FLAG_POISON): a partial that is ever read stale reads NaN
+        if (poison & 1u) {     // validation mode (NB_FLAG_POISON): a partial that is ever read stale reads NaN
             const float nan = __builtin_nanf("");
             q = partial + (size_t)blockIdx.x * 64 + lane;
             for (sp = 0; sp < nsplit; ++sp, q += stride) *q = float4{nan, nan, nan, nan};
@@ -1112,6 +1125,17 @@ __global__ __launch_bounds__(kBlock) void nb_pairs_pack(const float4* __restrict
     if (2 * p + 1 < n) b = ld4(bodies + 2 * p + 1);
     pairs[2 * p] = float4{a.x, b.x, a.y, b.y};
     pairs[2 * p + 1] = float4{a.z, b.z, G * a.w, G * b.w};
+}
+
+// (x, y, z, m) -> (x, y, z, G*m): the j-stream of the packed f32 K1 forms when G != 1 (rebuilt when the positions
+// were written from outside the step or G changed; the step itself keeps its own rows current).
+template <int UNUSED = 0>
+__global__ __launch_bounds__(kBlock) void nb_gm_pack(const float4* __restrict__ bodies, float4* __restrict__ gm, uint32_t n, float G)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const float4 b = ld4(bodies + i);
+    gm[i] = float4{b.x, b.y, b.z, G * b.w};
 }
 
 template <int WS>
@@ -1250,7 +1274,8 @@ __global__ __launch_bounds__(kBlock) void nb_integrate(typename vec4<T>::type* _
                                                       typename vec4<T>::type* __restrict__ vel,
                                                       typename vec4<T>::type* __restrict__ acc,
                                                       const typename vec4<T>::type* __restrict__ partial,
-                                                      uint32_t i_begin, uint32_t i_count, uint32_t jsplit, T dt)
+                                                      uint32_t i_begin, uint32_t i_count, uint32_t jsplit, T dt,
+                                                      typename vec4<T>::type* __restrict__ gout, T G)
 {
     using V4 = typename vec4<T>::type;
     const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
@@ -1290,6 +1315,7 @@ __global__ __launch_bounds__(kBlock) void nb_integrate(typename vec4<T>::type* _
     vel[il] = nv;                                                       // :281
     bodies[i_begin + il] = nx;                                          // :283
     acc[il] = na;                                                       // :290
+    if (gout) gout[i_begin + il] = V4{nx.x, nx.y, nx.z, G * nx.w};      // the packed f32 K1's j-stream row (G != 1 only)
 }
 
 // K2 for jsplit == 1 with the a_old / a_new buffers swapped by pointer (SURVEY.md §8(d) "K2
@@ -1300,7 +1326,8 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_swap(typename vec4<T>::ty
                                                            typename vec4<T>::type* __restrict__ vel,
                                                            const typename vec4<T>::type* __restrict__ aold,
                                                            const typename vec4<T>::type* __restrict__ anew,
-                                                           uint32_t i_begin, uint32_t i_count, T dt)
+                                                           uint32_t i_begin, uint32_t i_count, T dt,
+                                                           typename vec4<T>::type* __restrict__ gout, T G)
 {
     using V4 = typename vec4<T>::type;
     const uint32_t il = blockIdx.x * kBlock + threadIdx.x;
@@ -1310,6 +1337,7 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_swap(typename vec4<T>::ty
     leapfrog<T>(ld4(bodies + i_begin + il), ld4(vel + il), ld4(aold + il), a.x, a.y, a.z, dt, nx, nv, na);
     vel[il] = nv;
     bodies[i_begin + il] = nx;
+    if (gout) gout[i_begin + il] = V4{nx.x, nx.y, nx.z, G * nx.w};
 }
 
 // Viewer frame: what the reference's render pass reads every frame -- bodies

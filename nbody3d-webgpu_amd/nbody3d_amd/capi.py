@@ -15,13 +15,15 @@ import os
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.normpath(os.path.join(_PKG, "..", "csrc", "libnbody3d_hip.so"))
+# NB_ENGINE_LIB: load another build of the same library (the -DNB_TUNING calibration build of csrc/Makefile)
+_LIB_PATH = os.environ.get("NB_ENGINE_LIB") or os.path.normpath(os.path.join(_PKG, "..", "csrc", "libnbody3d_hip.so"))
 
 NB_F32, NB_F64 = 0, 1
 NB_FLAG_EXT_STREAM = 1
 NB_FLAG_LDS_ONLY = 4
 NB_FLAG_NO_FUSE = 8
 NB_FLAG_POISON = 16
+NB_FLAG_JPK_FENCED = 32
 NB_RCCL_ID_BYTES = 128
 NB_RCCL_OVERLAP = 1
 NB_MULTI_PEER, NB_MULTI_RCCL = 0, 1
@@ -58,7 +60,7 @@ SYMBOLS = ["nb_abi_version", "nb_device_count", "nb_create", "nb_destroy", "nb_u
            "nb_multi_download", "nb_multi_sync", "nb_multi_last_error", "nb_multi_variant_name",
            "nb_multi_diagnostics", "nb_multi_set_collective", "nb_multi_collective_info",
            "nb_rccl_unique_id", "nb_rccl_attach", "nb_rccl_detach", "nb_rccl_info",
-           "nb_step_times", "nb_integrate_pass", "nb_frame_request", "nb_frame_acquire"]
+           "nb_step_times", "nb_integrate_pass", "nb_frame_request", "nb_frame_acquire", "nb_shape_info"]
 
 _lib = None
 
@@ -119,6 +121,7 @@ def load_library():
     L.nb_step_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_uint32)]
     L.nb_integrate_pass.argtypes = [vp, C.c_uint32, C.POINTER(C.c_double)]
+    L.nb_shape_info.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
     L.nb_frame_request.argtypes = [vp]
     L.nb_frame_acquire.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
                                    C.POINTER(C.c_uint64)]
@@ -353,6 +356,13 @@ class Simulation:
     @property
     def variant(self):
         return self._L.nb_variant_name(self._h).decode()
+
+    def shape_info(self):
+        """{jsplit, j_per_split, own_split0, own_splits}: the force pass's j-partitions and those that lie entirely
+        inside this handle's own rows (what the overlapped exchange issues before waiting for the gather)."""
+        v = [C.c_uint32() for _ in range(4)]
+        self._check(self._L.nb_shape_info(self._h, *[C.byref(x) for x in v]))
+        return dict(zip(("jsplit", "j_per_split", "own_split0", "own_splits"), (x.value for x in v)))
 
     def diagnostics(self):
         """(kinetic, potential share, momentum[3]) of this handle's shard, fp64 on device."""

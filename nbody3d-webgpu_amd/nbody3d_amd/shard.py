@@ -46,7 +46,7 @@ class ShardPlan:
 
 
 def torch_allgather_hook(bodies_tensor, plan, group=None):
-    """Exchange hook for Simulation.set_exchange: in-place all-gather of each
+    """Exchange hook for Simulation.set_exchange: IN-PLACE all-gather of each
     rank's rows of ``bodies_tensor`` (shape (padded_n, 4), the tensor whose
     storage the engine uses as its replicated bodies array).
 
@@ -58,16 +58,15 @@ def torch_allgather_hook(bodies_tensor, plan, group=None):
     """
     import torch.distributed as dist
 
+    # IN PLACE, as in all three exchange kinds (this hook, the overlapped pair below, the engine's native
+    # ncclAllGather): the input is the view of this rank's rows inside the output tensor (input pointer =
+    # output pointer + rank * rows, the in-place form RCCL documents for ncclAllGather), so the collective never
+    # rewrites the rank's own rows and no per-step device copy is needed.  Covered with 2 and 3 ranks over gloo
+    # (tests/test_shard_gloo.py) and with one rank on the nccl backend (bench.py --force-dist --exchange torch).
     mine = bodies_tensor[plan.begin: plan.begin + plan.count]
-    # The send buffer is a separate 16*N/world-byte tensor refreshed by a device copy per step
-    # (microseconds) instead of an alias of the receive buffer: in-place all-gather is legal
-    # for RCCL itself, but nothing in torch.distributed's contract promises it for
-    # all_gather_into_tensor, and this path cannot be exercised with >1 rank on the dev box.
-    send = mine.clone()
 
     def hook(bodies_ptr, esz, n, sb, sc, stream):
-        send.copy_(mine)
-        dist.all_gather_into_tensor(bodies_tensor, send, group=group)
+        dist.all_gather_into_tensor(bodies_tensor, mine, group=group)
         return 0
 
     return hook

@@ -10,6 +10,11 @@
  * repo: only the produced arrays (data) and this script are committed.
  *
  *   node tests/golden/make_galaxy_fixture.js        (needs /root/reference)
+ *   node tests/golden/make_galaxy_fixture.js full   the reference's DEFAULT system (index.html:68-74: 2 galaxies x
+ *                                                   20,000 bodies -> N = 40,002): only galaxy40002_params.json is
+ *                                                   written -- the SHA-256 of the two arrays, their first and last rows
+ *                                                   and the galaxy list -- which pins js/ic.js::galaxies at full size
+ *                                                   (tests/test_round3_cpu.py) without committing 1.3 MB of state
  *
  * The galaxy list is drawn the way main() draws it (nbody3d.js:167-175) from
  * the same seeded stream, with the UI inputs fixed below.
@@ -20,7 +25,9 @@ const vm = require('vm');
 
 const REF = '/root/reference';
 const OUT = __dirname;
-const PARAMS = { seed: 20250725, numGalaxies: 2, minBodies: 380, maxBodies: 420, outerHeight: 1080, G: 1e-4 };
+const FULL = process.argv[2] === 'full';
+const PARAMS = FULL ? { seed: 40002, numGalaxies: 2, minBodies: 20000, maxBodies: 20000, outerHeight: 1080, G: 1e-4 }
+                    : { seed: 20250725, numGalaxies: 2, minBodies: 380, maxBodies: 420, outerHeight: 1080, G: 1e-4 };
 
 function mulberry32(a) {
   return function () {
@@ -80,11 +87,19 @@ const bodies = sandbox.result[0], vel = sandbox.result[1];
 const n = bodies.length / 4;
 if (n !== sandbox.nBodies) throw new Error('nBodies mismatch');
 for (let i = 0; i < bodies.length; i++) if (!isFinite(bodies[i]) || !isFinite(vel[i])) throw new Error('non-finite output');
-fs.writeFileSync(path.join(OUT, 'galaxy_ref_bodies0.f32'), Buffer.from(bodies.buffer, bodies.byteOffset, bodies.byteLength));
-fs.writeFileSync(path.join(OUT, 'galaxy_ref_vel0.f32'), Buffer.from(vel.buffer, vel.byteOffset, vel.byteLength));
-const meta = Object.assign({}, PARAMS, {
+const bBuf = Buffer.from(bodies.buffer, bodies.byteOffset, bodies.byteLength), vBuf = Buffer.from(vel.buffer, vel.byteOffset, vel.byteLength);
+if (!FULL) {
+  fs.writeFileSync(path.join(OUT, 'galaxy_ref_bodies0.f32'), bBuf);
+  fs.writeFileSync(path.join(OUT, 'galaxy_ref_vel0.f32'), vBuf);
+}
+const sha = function (buf) { return require('crypto').createHash('sha256').update(buf).digest('hex'); };
+const meta = Object.assign({}, PARAMS, FULL ? {
+  sha256_bodies0: sha(bBuf), sha256_vel0: sha(vBuf),
+  first_rows: { bodies: Array.from(bodies.slice(0, 8)), vel: Array.from(vel.slice(0, 8)) },
+  last_rows: { bodies: Array.from(bodies.slice(bodies.length - 8)), vel: Array.from(vel.slice(vel.length - 8)) },
+} : {}, {
   n: n, source: 'text of generateGalaxy (/root/reference/nbody3d.js:51-133) evaluated under node vm; prng mulberry32',
   galaxySettings: sandbox.galaxySettings.map(function (g) { return [Array.from(g[0]), Array.from(g[1]), Array.from(g[2]), g[3], g[4]]; }),
 });
-fs.writeFileSync(path.join(OUT, 'galaxy_ref_params.json'), JSON.stringify(meta, null, 1));
+fs.writeFileSync(path.join(OUT, FULL ? 'galaxy40002_params.json' : 'galaxy_ref_params.json'), JSON.stringify(meta, null, 1));
 console.log(JSON.stringify({ n: n, counts: meta.galaxySettings.map(function (g) { return g[4]; }) }));

@@ -11,7 +11,6 @@ import json
 import os
 import subprocess
 import sys
-import time
 
 import numpy as np
 import pytest
@@ -328,40 +327,6 @@ def test_frame_feed_values_equal_read(precision):
     rv32 = rv[:, :3].astype(np.float32)
     want = np.sqrt(rv32[:, 0] * rv32[:, 0] + rv32[:, 1] * rv32[:, 1] + rv32[:, 2] * rv32[:, 2])
     assert np.allclose(fs, want, rtol=2e-6, atol=0)
-
-
-def test_frame_feed_does_not_stall_the_step_stream():
-    """A snapshot every frame at the reference's default workload size (N=40,002, one step per
-    frame as render() does): throughput within 5 % of running without snapshots (measured: 1.6-2.5 %)."""
-    n = 40002
-    b, v = ic.uniform_cube(n, seed=62)
-    frames = 300
-
-    def loop(with_frames):
-        with Simulation(n) as sim:
-            sim.init(b, v)
-            sim.set_params(1e-4, 1e-4)
-            for _ in range(20):
-                sim.step()
-            sim.sync()
-            t0 = time.perf_counter()
-            for _ in range(frames):
-                sim.step()
-                if with_frames:
-                    sim.request_frame()
-                    sim.frame(wait=False)
-            sim.sync()
-            return time.perf_counter() - t0
-
-    loop(False)
-    loop(True)                                   # first use allocates the frame slots
-    base, feed = [], []
-    for _ in range(6):                           # interleaved, best of six each (rule 24: A/B in one process)
-        base.append(loop(False))
-        feed.append(loop(True))
-    # measured +1.6..2.4 % (DESIGN.md §7); the gate leaves room for a host hiccup in a 0.1 s window
-    # (it tripped once in ~10 suite runs at 3 % with best-of-three right after the step itself got 1.5 % faster)
-    assert min(feed) < 1.05 * min(base), (feed, base)     # gate well above the measurement: a timing gate must not be able to fail the suite on a busy box
 
 
 def test_integrate_pass_measures_the_integrator_alone():

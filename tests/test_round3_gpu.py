@@ -1,0 +1,423 @@
+"""GPU tests of the round-3 work, all through the C ABI:
+
+  * the reference's OWN default workload at full size -- 2 galaxies x 20,000 bodies + two 1e7 central masses =
+    N 40,002, G = dt = 1e-4 (/root/reference index.html:68-74, nbody3d.js:62-64,163-177), built by the bit-exact
+    generator port (js/ic.js under Node, digest-pinned to the reference generator's own output) -- on the default
+    launch shape and on the pinned kernel families: sampled rows against the fp64 oracle, Newton's third law, and a
+    30-step trajectory against the fp64 oracle;
+  * G != 1: every packed f32 kernel multiplies (G*m_j)*inv per pair, the reference's product (nbody3d.js:236), through
+    the (x, y, z, G*m) j-stream copy -- the step forms agree with each other as tightly as at G = 1, and the copy follows
+    uploads, G changes, graph replay, exchanges and raw pointers;
+  * the overlapped exchange engages with the MODEL-chosen split count on the shard shapes of BASELINE config 4;
+  * frame-slot allocation failure (fault injection in the -DNB_TUNING build), the fenced fallback of the j-packed step.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, ROOT, load_golden32, rel_pos_err
+from oracle import oracle
+from nbody3d_amd import MultiSimulation, Simulation, capi, ic
+
+pytestmark = pytest.mark.gpu
+
+TOL_ACC, TOL_TIGHT = 2e-5, 2e-5
+
+
+def run(b, v, steps, dt=1e-3, G=1.0, **kw):
+    with Simulation(b.shape[0], **kw) as sim:
+        sim.init(b, v)
+        sim.simulate(steps, dt, G)
+        return sim.read() + (sim.variant,)
+
+
+# ---- the reference's default workload, N = 40,002 ------------------------------------------------
+
+@pytest.fixture(scope="module")
+def galaxy40002():
+    b, v, gp = ic.reference_galaxies(os.path.join(GOLDEN, "galaxy40002_params.json"))
+    assert b.shape == (40002, 4) and gp["G"] == 1e-4
+    # the fp64 oracle, once: accelerations of the initial state on sampled rows, and the state after 30 calls
+    b64, v64 = b.astype(np.float64), v.astype(np.float64)
+    rows = np.sort(np.random.default_rng(3).choice(40002, 46, replace=False))
+    rows = np.unique(np.concatenate([[0, 20001, 20000, 40001, 255, 256, 39935, 39936], rows]))   # both central masses, tile edges, the tail
+    acc = {int(i): oracle.accel_f64(b64, gp["G"], i0=int(i), i1=int(i) + 1)[0, :3] for i in rows}
+    traj = oracle.run_f64(b64, v64, None, 1e-4, gp["G"], 30)
+    return {"b": b, "v": v, "G": gp["G"], "dt": 1e-4, "acc": acc, "traj": traj}
+
+
+# default shape; config 2's LDS tile=256 kernel; the SGPR kernel with 8 bodies per lane; the j-packed step with a split;
+# the fused LDS-tile step; the scalar template
+GALAXY_VARIANTS = [(0, 0, None), (28, 0, "pk_lds256"), (308014, 0, "sgpr_ipl8"), (304014, 21, "sgpr_ipl4"),
+                   (601018, 4, "jpairs"), (404324, 0, "fused_lds"), (2, 4, "f32_lds256")]
+
+
+@pytest.mark.parametrize("variant,jsplit,family", GALAXY_VARIANTS)
+def test_reference_default_workload_full_size(galaxy40002, variant, jsplit, family):
+    g = galaxy40002
+    b, v = g["b"], g["v"]
+    with Simulation(40002, force_variant=variant, jsplit=jsplit) as sim:
+        sim.init(b, v)
+        sim.simulate(1, g["dt"], g["G"])
+        b1, v1, a1 = sim.read()
+        sim.simulate(29)
+        b30, v30, a30 = sim.read()
+        name = sim.variant
+    if family:
+        assert family in name, name
+    # 1. single force evaluation: sampled rows (both 1e7 central masses, tile boundaries, the ragged tail) vs the fp64 oracle
+    for i, ref in g["acc"].items():
+        assert np.abs(a1[i, :3] - ref).max() < TOL_ACC * max(np.abs(ref).max(), 1e-3), (name, i)
+    assert not a1[:, 3].any() and np.array_equal(b1[:, 3], b[:, 3])
+    # 2. Newton's third law over the whole system (mass ratio 1e6)
+    ma = b[:, 3:4].astype(np.float64) * a1[:, :3]
+    assert np.all(np.abs(ma.sum(0)) < 1e-5 * np.abs(ma).sum(0)), name
+    # 3. 30 calls against the fp64 oracle: every row (positions), and velocities / accelerations
+    rb, rv, ra = g["traj"]
+    r_scale = float(np.sqrt((rb[:, :3] ** 2).sum(1)).mean())
+    assert rel_pos_err(b30, rb, r_scale) < TOL_TIGHT, (name, rel_pos_err(b30, rb, r_scale))
+    assert np.abs(v30[:, :3] - rv[:, :3]).max() < TOL_TIGHT * np.abs(rv[:, :3]).max(), name
+    scale = np.maximum(np.abs(ra[:, :3]).max(1), 1e-3)
+    assert (np.abs(a30[:, :3] - ra[:, :3]).max(1) / scale).max() < 5 * TOL_ACC, name
+
+
+def test_reference_default_workload_step_forms_agree(galaxy40002):
+    """At the reference's G = 1e-4 the default (two-kernel SGPR) step, the j-packed fused step and the LDS-tile kernel
+    differ by summation order only: with every kernel multiplying (G*m_j)*inv per pair they agree as tightly as at G = 1."""
+    g = galaxy40002
+    outs = [run(g["b"], g["v"], 10, g["dt"], g["G"], force_variant=fv, jsplit=js) for fv, js in ((0, 0), (601018, 4), (28, 0))]
+    for o in outs[1:]:
+        assert rel_pos_err(o[0], outs[0][0], 1.0) < 2e-6, (o[3], outs[0][3])
+        rel = np.abs(o[2][:, :3] - outs[0][2][:, :3]).max(1) / np.maximum(np.abs(outs[0][2][:, :3]).max(1), 1e-3)
+        assert rel.max() < 1e-5, (o[3], outs[0][3])
+
+
+# ---- G != 1: the (x, y, z, G*m) j-stream -----------------------------------------------------------
+
+@pytest.mark.parametrize("G", [1e-4, 0.37, 3.0])
+@pytest.mark.parametrize("n,fused,two", [(1000, 502641, 202644), (4096, 402644, 202644), (7001, 404324, 204324), (4096, 408161, 208161)])
+def test_fused_and_two_kernel_steps_stay_bit_identical_at_any_G(G, n, fused, two):
+    """Round 2 applied G to the finished sums in the packed kernels: identical bits only at G = 1.  Now the fused,
+    registers-only and two-kernel forms of one loop shape are bit-identical at every G, through graph replay (19 steps)."""
+    b, v = (ic.plummer(n, seed=71) if n % 256 == 0 else ic.uniform_cube(n, seed=71))
+    fb, fv, fa, fname = run(b, v, 19, G=G, force_variant=fused)
+    tb, tv, ta, tname = run(b, v, 19, G=G, force_variant=two, jsplit=1)
+    assert "fused" in fname and "fused" not in tname, (fname, tname)
+    assert fb.tobytes() == tb.tobytes() and fv.tobytes() == tv.tobytes() and fa.tobytes() == ta.tobytes(), (fname, tname, G)
+    rb, rv, ra = oracle.run_f64(b, v, None, 1e-3, G, 19)
+    assert rel_pos_err(fb, rb, 1.0) < TOL_TIGHT, fname
+
+
+@pytest.mark.parametrize("name,steps", [("galaxy_ref", 30), ("disk771", 50)])
+def test_g_not_one_fixtures_agree_across_kernel_families_and_with_the_fp32_oracle(manifest, name, steps):
+    """The two committed G = 1e-4 fixtures: LDS-tile, SGPR, fused, registers-only and j-packed steps against the fp32
+    oracle's vector and against each other.  Before the j-stream carried G*m the packed kernels sat ~2x further from the
+    j-packed step (which always folded G into the masses) than they do at G = 1."""
+    m = manifest[name]
+    b0, v0 = load_golden32(name + "_bodies0"), load_golden32(name + "_vel0")
+    ref32 = load_golden32("%s_s%d_bodies" % (name, steps))
+    outs = {}
+    for label, fv, js in (("lds", 22, 1), ("sgpr", 304014, 2), ("fused", 402644, 0), ("regs", 502641, 0), ("jpk", 601014, 2), ("scalar", 1, 1)):
+        bb, vv, aa, vname = run(b0, v0, steps, dt=m["dt"], G=m["G"], force_variant=fv, jsplit=js)
+        outs[label] = bb
+        assert rel_pos_err(bb, ref32, m["r_scale"]) < 2e-6, (vname, rel_pos_err(bb, ref32, m["r_scale"]))
+    for label, bb in outs.items():
+        assert rel_pos_err(bb, outs["jpk"], m["r_scale"]) < 2e-6, label
+    assert outs["fused"].tobytes() == outs["regs"].tobytes()
+
+
+@pytest.mark.parametrize("n,variant", [(1024, 0), (4096, 402644), (20000, 0), (20000, 28)])
+def test_j_stream_copy_follows_G_changes_uploads_graphs_and_raw_pointers(n, variant):
+    """The copy is rebuilt when G changes (1 -> 0.5 -> 1 -> 0.25), after a restore on either ping-pong parity, and after a
+    raw device pointer was handed out; graph replays (>= 16 steps) and single steps must give the same bits."""
+    b, v = ic.plummer(n, seed=72)
+    with Simulation(n, force_variant=variant) as a, Simulation(n, force_variant=variant) as c:
+        a.init(b, v)
+        c.init(b, v)
+        for G, k in ((1.0, 17), (0.5, 35), (1.0, 3), (0.25, 20)):
+            a.simulate(k, 1e-3, G)
+            for _ in range(k):
+                c.step(1e-3, G)
+        for x, y in zip(a.read(), c.read()):
+            assert x.tobytes() == y.tobytes(), a.variant
+        state = a.read()
+        a.simulate(5)                     # odd: a fused handle now lives in the other buffer pair
+        a.restore(*state)
+        a.simulate(21)
+        c.simulate(21)
+        for x, y in zip(a.read(), c.read()):
+            assert x.tobytes() == y.tobytes(), a.variant
+        a.device_ptr("bodies")            # the engine must assume the caller wrote through it
+        a.simulate(2)
+        c.simulate(2)
+        got, want = a.read(), c.read()
+        name = a.variant
+    for x, y in zip(got, want):
+        assert x.tobytes() == y.tobytes(), name
+    # (the trajectory itself is covered by the parity suites; here only that both ways of driving the handle agree)
+
+
+@pytest.mark.parametrize("g,variant", [(2, 22), (4, 308014), (8, 28)])
+def test_virtual_shards_at_G_not_one_equal_the_single_handle(g, variant):
+    """nb_multi with g shards on one GPU at G = 0.01: after every peer-copy all-gather each shard rebuilds the other shards'
+    rows of its (x, y, z, G*m) copy; bit-identical to one unsharded handle of the same launch shape."""
+    n, steps = 4096, 7
+    b, v = ic.plummer(n, seed=73)
+    kw = dict(force_variant=variant, jsplit=4)
+    with Simulation(n, flags=capi.NB_FLAG_NO_FUSE, **kw) as one:
+        one.init(b, v)
+        one.simulate(steps, 1e-3, 0.01)
+        ref = one.read()
+    with MultiSimulation(n, g, **kw) as ms:
+        ms.init(b, v)
+        ms.simulate(3, 1e-3, 0.01)
+        for _ in range(steps - 3):
+            ms.step()
+        got = ms.read()
+        name = ms.variant
+    for x, y in zip(got, ref):
+        assert x.tobytes() == y.tobytes(), name
+
+
+def test_overlapped_exchange_at_G_not_one_waits_and_stays_exact():
+    """G != 1 on a handle whose rows are exchanged: the step waits for the gather, rebuilds the j-stream copy and runs the
+    whole force pass (documented: the overlapped form only overlaps at G = 1).  Same bits as the unsharded handle."""
+    import torch
+    n, g, steps = 4096, 2, 5
+    per = n // g
+    b, v = ic.plummer(n, seed=74)
+    kw = dict(force_variant=22, jsplit=8)
+    with Simulation(n, **kw) as one:
+        one.init(b, v)
+        one.simulate(steps, 1e-3, 0.3)
+        ref = one.read()
+    stream = torch.cuda.current_stream().cuda_stream
+    bufs = [torch.empty((n, 4), device="cuda", dtype=torch.float32) for _ in range(g)]
+    sims = [Simulation(n, shard=(r * per, per), stream=stream, ext_bodies=bufs[r].data_ptr(), **kw) for r in range(g)]
+    snap = {}
+    try:
+        for r, s in enumerate(sims):
+            s.init(b, v)
+            s.set_params(1e-3, 0.3)
+
+            def wait(st, r=r):
+                for q in range(g):
+                    if q != r:
+                        bufs[r][q * per:(q + 1) * per].copy_(snap[q])
+                return 0
+
+            s.set_exchange_overlapped(lambda *a: 0, wait)
+        for _ in range(steps):
+            snap = {q: bufs[q][q * per:(q + 1) * per].clone() for q in range(g)}
+            for s in sims:
+                s.step()
+        for s in sims:
+            s.sync()
+        bodies = np.concatenate([bufs[r][r * per:(r + 1) * per].cpu().numpy() for r in range(g)])
+    finally:
+        for s in sims:
+            s.close()
+    assert bodies.tobytes() == ref[0].tobytes()
+
+
+# ---- the overlapped exchange with the model's own split count --------------------------------------
+
+@pytest.mark.parametrize("n,g", [(262144, 2), (262144, 4), (262144, 8), (1048576, 8), (40448, 2)])
+def test_model_chosen_split_count_leaves_own_row_splits_for_every_rank(n, g):
+    """BASELINE config 4's shard shapes (strong scaling at N=262,144 over 2/4/8 ranks, the weak-scaling end point
+    N=1,048,576 over 8): with NO jsplit pin, every rank's handle has j-partitions lying entirely inside its own rows, i.e.
+    NB_RCCL_OVERLAP / nb_set_exchange_overlapped really issue force work before waiting for the gather.  (Round 2 required
+    the shard to be a whole number of partitions: 24 and 44 partitions on the 1/4 and 1/8 shards gave own_splits = 0.)"""
+    n = (n // (256 * g)) * 256 * g
+    per = n // g
+    for r in sorted({0, 1, g // 2, g - 1}):
+        with Simulation(n, shard=(r * per, per)) as s:
+            info = s.shape_info()
+            name = s.variant
+        assert info["jsplit"] >= g, (name, info)
+        assert info["own_splits"] >= 1, (n, g, r, name, info)
+        lo, hi = info["own_split0"] * info["j_per_split"], (info["own_split0"] + info["own_splits"]) * info["j_per_split"]
+        assert r * per <= lo and min(hi, n) <= (r + 1) * per, (n, g, r, info)      # inside the rank's own rows
+        assert info["own_splits"] * info["j_per_split"] > per - 2 * info["j_per_split"]   # all but the straddlers
+
+
+@pytest.mark.parametrize("n,g,variant", [(16384, 4, 304014), (20480, 8, 304014), (12288, 3, 28), (65536, 8, 0)])
+def test_overlapped_exchange_with_model_chosen_splits_and_virtual_shards(n, g, variant):
+    """The overlapped hooks on ONE GPU with g shard handles and the split count the MODEL picks (no jsplit pin; shards that
+    are not a whole number of partitions): own-row partitions first, the straddling and foreign ones after wait().
+    Bit-identical to an unsharded handle running the same kernel with the same number of partitions."""
+    import torch
+    steps = 5
+    per = n // g
+    assert per * g == n and per % 256 == 0
+    b, v = ic.plummer(n, seed=75)
+    stream = torch.cuda.current_stream().cuda_stream
+    bufs = [torch.empty((n, 4), device="cuda", dtype=torch.float32) for _ in range(g)]
+    sims = [Simulation(n, shard=(r * per, per), stream=stream, ext_bodies=bufs[r].data_ptr(), force_variant=variant) for r in range(g)]
+    infos = [s.shape_info() for s in sims]
+    names = [s.variant for s in sims]
+    snap = {}
+    calls = {"begin": 0, "wait": 0}
+    try:
+        assert len(set(names)) == 1 and all(i["own_splits"] >= 1 for i in infos), (names, infos)
+        for r, s in enumerate(sims):
+            s.init(b, v)
+            s.set_params(1e-3, 1.0)
+
+            def begin(ptr, esz, nn, sb, sc, st):
+                calls["begin"] += 1
+                return 0
+
+            def wait(st, r=r):
+                calls["wait"] += 1
+                for q in range(g):
+                    if q != r:
+                        bufs[r][q * per:(q + 1) * per].copy_(snap[q])
+                return 0
+
+            s.set_exchange_overlapped(begin, wait)
+        for _ in range(steps):
+            snap = {q: bufs[q][q * per:(q + 1) * per].clone() for q in range(g)}
+            for s in sims:
+                s.step()
+        for s in sims:
+            s.sync()
+        bodies = np.concatenate([bufs[r][r * per:(r + 1) * per].cpu().numpy() for r in range(g)])
+        vel = np.zeros((n, 4), np.float32)
+        for r, s in enumerate(sims):
+            vel[r * per:(r + 1) * per] = s.read(bodies=False, accel=False)[1][r * per:(r + 1) * per]
+    finally:
+        for s in sims:
+            s.close()
+    assert calls["begin"] == g * steps and calls["wait"] == g * steps
+    # the unsharded twin: same kernel family / bodies per lane / waves, same number of j-partitions
+    js = infos[0]["jsplit"]
+    twin = variant
+    if variant == 0:
+        nm = names[0]
+        assert "sgpr_ipl" in nm, nm
+        twin = 300000 + int(nm.split("ipl")[1].split("_")[0]) * 1000 + 10 + (4 if "_ws4" in nm else 1)
+    with Simulation(n, force_variant=twin, jsplit=js, flags=capi.NB_FLAG_NO_FUSE) as one:
+        assert one.shape_info()["j_per_split"] == infos[0]["j_per_split"], (one.variant, names[0])
+        one.init(b, v)
+        one.simulate(steps, 1e-3, 1.0)
+        ref = one.read()
+    assert bodies.tobytes() == ref[0].tobytes(), names[0]
+    assert vel.tobytes() == ref[1].tobytes(), names[0]
+
+
+def test_shape_info_of_a_whole_system_handle():
+    with Simulation(262144) as s:
+        info = s.shape_info()
+        assert info["jsplit"] >= 1 and info["own_splits"] == 0 and "_js%d" % info["jsplit"] in s.variant
+        assert info["j_per_split"] * info["jsplit"] >= 262144
+    with Simulation(4096) as s:
+        assert s.shape_info()["own_splits"] == 0
+
+
+# ---- fault injection, fallbacks ----------------------------------------------------------------------
+
+FRAME_FAIL_SCRIPT = r"""
+import sys
+sys.path.insert(0, %(pkg)r)
+import numpy as np
+from nbody3d_amd import Simulation, capi, ic
+assert capi.library_path().endswith("_tuning.so")
+n = 3000
+b, v = ic.plummer(n, seed=5)
+with Simulation(n) as sim:
+    sim.init(b, v)
+    sim.simulate(3, 1e-3, 1.0)
+    for attempt in range(2):                      # a failed set-up must leave nothing half-built behind
+        try:
+            sim.request_frame()
+            print("NO-ERROR")
+        except capi.NBodyError as e:
+            print("ERR", e.code, str(e)[:90])
+        try:
+            sim.frame(wait=False)
+            print("NO-ERROR")
+        except capi.NBodyError as e:
+            print("ACQ", e.code)
+    sim.simulate(2)                               # the handle itself is still fine
+    got = sim.read()[0]
+with Simulation(n) as ref:
+    ref.init(b, v)
+    ref.simulate(5, 1e-3, 1.0)
+    print("SAME", got.tobytes() == ref.read()[0].tobytes())
+"""
+
+
+@pytest.mark.parametrize("slot", [0, 2])
+def test_frame_slot_allocation_failure_is_an_error_code_not_a_fault(slot):
+    """nb_frame_request published its stream before the four slots existed, so a failed allocation left
+    null buffers behind and the NEXT request packed into them (a GPU memory fault).  The set-up is all-or-nothing now; the
+    -DNB_TUNING build fails the k-th slot on request (NB_TEST_FAIL_FRAME_SLOT)."""
+    lib = os.path.join(ROOT, "nbody3d-webgpu_amd", "csrc", "libnbody3d_hip_tuning.so")
+    if not os.path.exists(lib):
+        subprocess.check_call(["make", "-C", os.path.dirname(lib), "-s", "tuning"])
+    env = dict(os.environ, NB_ENGINE_LIB=lib, NB_TEST_FAIL_FRAME_SLOT=str(slot))
+    p = subprocess.run([sys.executable, "-c", FRAME_FAIL_SCRIPT % {"pkg": os.path.join(ROOT, "nbody3d-webgpu_amd")}],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert p.returncode == 0, (p.stdout + p.stderr)[-2000:]
+    lines = p.stdout.split("\n")
+    assert sum(l.startswith("ERR 5") for l in lines) == 2 and "NO-ERROR" not in p.stdout, p.stdout      # NB_ERR_NOMEM, twice
+    assert sum(l.startswith("ACQ 4") for l in lines) == 2, p.stdout                                      # nothing requested: NB_ERR_STATE
+    assert "SAME True" in p.stdout, p.stdout
+
+
+def test_frame_feed_runs_ahead_without_blocking_and_snapshots_stay_exact():
+    """The functional half of the frame feed at the reference's default size (one snapshot per frame, as render() draws):
+    requests never need an acquire in between (a ring of four slots; the host is held back, never the step stream), every
+    acquired snapshot is a finished frame of an earlier-or-equal step, and the last one equals read().  (The wall-clock
+    comparison with and without snapshots lives in tools/feed_driver.py: a timing gate does not belong in a -x suite.)"""
+    n = 40002
+    b, v = ic.uniform_cube(n, seed=62)
+    with Simulation(n) as sim:
+        sim.init(b, v)
+        sim.set_params(1e-4, 1e-4)
+        last = -1
+        for k in range(60):
+            sim.step()
+            sim.request_frame()
+            if k % 7 == 3:
+                got = sim.frame(wait=False)
+                if got is not None:
+                    assert last <= got[2] <= k + 1
+                    last = got[2]
+        fb, fs, step = sim.frame(wait=True)
+        fb = fb.copy()
+        assert step == 60
+        assert fb.tobytes() == sim.read(vel=False, accel=False)[0].tobytes()
+
+
+@pytest.mark.parametrize("n,jsplit", [(8192, 4), (10000, 0)])
+def test_jpk_fenced_fallback_is_bit_identical(n, jsplit):
+    """NB_FLAG_JPK_FENCED: plain partial stores + an agent-scope release on the ticket instead of write-through stores +
+    a relaxed ticket -- the conservative fallback for parts / partition modes where the sc1 sequence might not hold."""
+    b, v = ic.plummer(n, seed=76)
+    fast = run(b, v, 40, force_variant=601018, jsplit=jsplit)
+    safe = run(b, v, 40, force_variant=601018, jsplit=jsplit, flags=capi.NB_FLAG_JPK_FENCED)
+    assert "jpairs" in fast[3] and fast[3] == safe[3]
+    for x, y in zip(fast[:3], safe[:3]):
+        assert x.tobytes() == y.tobytes(), fast[3]
+
+
+def test_default_shape_at_an_auto_selected_jpk_size_with_poisoned_partials():
+    """validate the DEFAULT path itself, not only pinned variants -- N = 10,000 with no shape pin lands on
+    the j-packed step with a split across workgroups; 400 steps through graph replay with every consumed partial
+    overwritten by NaN: finite, and bit-identical to the unpoisoned and to the fenced run."""
+    n = 10000
+    b, v = ic.plummer(n, seed=77)
+    p = run(b, v, 400, flags=capi.NB_FLAG_POISON)
+    q = run(b, v, 400)
+    r = run(b, v, 400, flags=capi.NB_FLAG_JPK_FENCED)
+    assert "jpairs" in q[3] and "_js1" != q[3][-4:], q[3]
+    for a in p[:3]:
+        assert np.isfinite(a).all(), p[3]
+    for x, y, z in zip(p[:3], q[:3], r[:3]):
+        assert x.tobytes() == y.tobytes() == z.tobytes(), q[3]
