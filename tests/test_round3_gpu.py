@@ -47,7 +47,8 @@ def galaxy40002():
     rows = np.unique(np.concatenate([[0, 20001, 20000, 40001, 255, 256, 39935, 39936], rows]))   # both central masses, tile edges, the tail
     acc = {int(i): oracle.accel_f64(b64, gp["G"], i0=int(i), i1=int(i) + 1)[0, :3] for i in rows}
     traj = oracle.run_f64(b64, v64, None, 1e-4, gp["G"], 30)
-    return {"b": b, "v": v, "G": gp["G"], "dt": 1e-4, "acc": acc, "traj": traj}
+    spread = json.load(open(os.path.join(GOLDEN, "galaxy40002_spread.json")))      # how far the fp32 ORACLE sits from the fp64 one here
+    return {"b": b, "v": v, "G": gp["G"], "dt": 1e-4, "acc": acc, "traj": traj, "spread": spread}
 
 
 # default shape; config 2's LDS tile=256 kernel; the SGPR kernel with 8 bodies per lane; the j-packed step with a split;
@@ -76,13 +77,18 @@ def test_reference_default_workload_full_size(galaxy40002, variant, jsplit, fami
     # 2. Newton's third law over the whole system (mass ratio 1e6)
     ma = b[:, 3:4].astype(np.float64) * a1[:, :3]
     assert np.all(np.abs(ma.sum(0)) < 1e-5 * np.abs(ma).sum(0)), name
-    # 3. 30 calls against the fp64 oracle: every row (positions), and velocities / accelerations
+    # 3. 30 calls against the fp64 oracle, every row.  Positions: the usual 2e-5.  Velocities and accelerations: this
+    #    system keeps O(5) positions (fp32 ulp 4.8e-7) for orbits 0.12 from a 1e7 mass, so the binary32 STATE alone moves
+    #    them by ~1e-4 in 30 calls -- the fp32 oracle itself sits 1.1e-4 / 5.5e-4 from the fp64 one (galaxy40002_spread.json,
+    #    tests/golden/measure_galaxy40002_spread.py); the engine is held to 2x that spread (it measures ~0.5x).
     rb, rv, ra = g["traj"]
-    r_scale = float(np.sqrt((rb[:, :3] ** 2).sum(1)).mean())
-    assert rel_pos_err(b30, rb, r_scale) < TOL_TIGHT, (name, rel_pos_err(b30, rb, r_scale))
-    assert np.abs(v30[:, :3] - rv[:, :3]).max() < TOL_TIGHT * np.abs(rv[:, :3]).max(), name
+    sp = g["spread"]["oracle_f32_vs_f64"]
+    assert rel_pos_err(b30, rb, g["spread"]["r_scale"]) < TOL_TIGHT, (name, rel_pos_err(b30, rb, g["spread"]["r_scale"]))
+    verr = np.abs(v30[:, :3] - rv[:, :3]).max() / np.abs(rv[:, :3]).max()
+    assert verr < 2 * sp["max_vel_err_over_vmax"], (name, verr)
     scale = np.maximum(np.abs(ra[:, :3]).max(1), 1e-3)
-    assert (np.abs(a30[:, :3] - ra[:, :3]).max(1) / scale).max() < 5 * TOL_ACC, name
+    aerr = (np.abs(a30[:, :3] - ra[:, :3]).max(1) / scale).max()
+    assert aerr < 2 * sp["max_rel_acc_err_per_row"], (name, aerr)
 
 
 def test_reference_default_workload_step_forms_agree(galaxy40002):

@@ -1,0 +1,26 @@
+#!/bin/bash
+# One parametrised GPU pass (replaces round 2's fourteen one-off gpu_*.sh scripts).  Run through gpurun:
+#   gpurun --timeout 1100 -- 'bash tools/gpu.sh tests bench'
+# Legs, in the order given: tests [pytest args] | new (only tests/test_round3_gpu.py) | smoke | bench | sizes N... | shapes N... |
+# prof (rocprofv3 kernel trace + PMC passes of the default bench line).  A leg that times out stops the pass:
+# no further GPU step is started after a kill.
+set -u
+mkdir -p gpurun_out
+step() { local name=$1 to=$2; shift 2; echo "== $name: $*"; timeout -k 10 "$to" "$@" > "gpurun_out/$name.txt" 2>&1; local rc=$?
+         echo "== $name rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name"; tail -5 "gpurun_out/$name.txt"; exit 1; fi; return 0; }
+while [ $# -gt 0 ]; do
+  leg=$1; shift
+  case $leg in
+    tests) step pytest_gpu 1100 python -m pytest tests -m gpu -x -q --durations=15; tail -25 gpurun_out/pytest_gpu.txt ;;
+    new)   step pytest_new 900 python -m pytest tests/test_round3_gpu.py -m gpu -x -q --durations=10; tail -25 gpurun_out/pytest_new.txt ;;
+    smoke) step smoke 300 python __graft_entry__.py smoke; tail -2 gpurun_out/smoke.txt ;;
+    bench) step bench 600 python bench.py; tail -1 gpurun_out/bench.txt | cut -c1-3000 ;;
+    sizes) args=(); while [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; do args+=("$1"); shift; done
+           step size_scan 900 python tools/size_scan.py "${args[@]}"; cat gpurun_out/size_scan.txt ;;
+    shapes) args=(); while [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; do args+=("$1"); shift; done
+           step shape_scan 1000 python tools/shape_scan.py "${args[@]}"; grep -c . gpurun_out/shape_scan.txt ;;
+    prof)  bash tools/gpu_prof.sh ;;
+    py)    script=$1; shift; step "$(basename "$script" .py)" 900 python "$script"; tail -40 "gpurun_out/$(basename "$script" .py).txt" ;;
+    *) echo "unknown leg $leg"; exit 2 ;;
+  esac
+done
