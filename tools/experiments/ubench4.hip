@@ -5,7 +5,7 @@
 // Reports, per shape and N: event-timed us per launch (un-stamped numbers come from
 // tools/shape_scan.py), the median phase lengths in shader cycles, and the spread of the entry
 // stamps over the grid (launch ramp).
-// Build: hipcc -O3 --offload-arch=gfx950 -DNB_STAMPS -I../nbody3d-webgpu_amd/csrc -o ubench4 ubench4.hip
+// Build: hipcc -O3 --offload-arch=gfx950 -DNB_STAMPS -I../../nbody3d-webgpu_amd/csrc -o ubench4 ubench4.hip
 #include "nb_kernels.hip.h"
 
 #include <algorithm>

@@ -1,7 +1,7 @@
 // ubench5.hip -- the j-packed SGPR step (nb_step_jpk<WS>) on its own: event-timed us per step for
 // N = 2k .. 40k and WS = 4 / 8 / 16, each checked against an fp64 direct sum of the first step
 // (max relative acceleration error over all bodies).  Product kernels, no stamps.
-// Build: hipcc -O3 --offload-arch=gfx950 -I../nbody3d-webgpu_amd/csrc -o ubench5 ubench5.hip
+// Build: hipcc -O3 --offload-arch=gfx950 -I../../nbody3d-webgpu_amd/csrc -o ubench5 ubench5.hip
 #include "nb_kernels.hip.h"
 
 namespace nb {
