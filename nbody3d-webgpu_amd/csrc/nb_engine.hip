@@ -50,7 +50,7 @@ using nbi::fail;
 
 uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
 
-enum Kind { kScalar = 1, kPkLds = 2, kPkSgpr = 3, kFused = 4, kDirect = 5, kJpk = 6 };   // kDirect: fused, registers only (x = MAXJ/16)
+enum Kind { kScalar = 1, kPkLds = 2, kPkSgpr = 3, kFused = 4, kDirect = 5, kJpk = 6, kSym = 7 };   // kDirect: fused, registers only (x = MAXJ/16)
 struct Shape { int kind, ipl, ls, x; };   // x: tile units (LDS kinds) or j-splitting waves (SGPR kind)
 
 bool pow2(int v) { return v >= 1 && (v & (v - 1)) == 0; }
@@ -142,6 +142,10 @@ const void* kernel_of(bool f64, const Shape& sh)
         case kDirect:
             if (f64 || sh.ipl != 2 || sh.ls != 64) return nullptr;
             return sh.x == 1 ? (const void*)&nb::nb_step_direct<16> : sh.x == 2 ? (const void*)&nb::nb_step_direct<32> : nullptr;
+        case kSym:
+            if (f64 || sh.ipl != 8 || sh.ls != 1) return nullptr;
+            return sh.x == 2 ? (const void*)&nb::nb_force_sym<2, 2> : sh.x == 4 ? (const void*)&nb::nb_force_sym<4, 2>
+                   : sh.x == 8 ? (const void*)&nb::nb_force_sym<8, 2> : nullptr;
         case kJpk:
             if (f64 || sh.ipl != 1 || sh.ls != 1) return nullptr;
             return sh.x == 4 ? (const void*)&nb::nb_step_jpk<4> : sh.x == 8 ? (const void*)&nb::nb_step_jpk<8>
@@ -154,6 +158,7 @@ const void* kernel_of(bool f64, const Shape& sh)
 uint32_t ipb_of(const Shape& sh)
 {
     if (sh.kind == kJpk) return 64;
+    if (sh.kind == kSym) return 512u * (uint32_t)sh.x;
     if (sh.kind == kPkSgpr) return (uint32_t)(nb::kBlock / sgpr_ws(sh.x)) * sh.ipl;
     return (uint32_t)(nb::kBlock / sh.ls) * sh.ipl;
 }
@@ -177,7 +182,7 @@ bool decode_variant(uint32_t v, Shape* out)
     }
     if (v < 100000) return false;
     Shape sh{(int)(v / 100000), (int)(v / 1000 % 100), (int)(v / 10 % 100), (int)(v % 10)};
-    if (sh.kind < kScalar || sh.kind > kJpk || !pow2(sh.ls)) return false;
+    if (sh.kind < kScalar || sh.kind > kSym || !pow2(sh.ls)) return false;
     if (sh.kind == kScalar) sh.x = 1;
     *out = sh;
     return true;
@@ -194,6 +199,8 @@ void name_variant(nb_sim* s, const Shape& sh)
         snprintf(buf, sizeof buf, "f32pk_fused_regs%d_ipl%d_ls%d", 64 * 16 * sh.x, sh.ipl, sh.ls);
     else if (sh.kind == kJpk)
         snprintf(buf, sizeof buf, "f32pk_fused_jpairs_ws%d_js%u", jpk_ws(sh.x), s->jsplit);
+    else if (sh.kind == kSym)
+        snprintf(buf, sizeof buf, "f32pk_sym_ws%d_seg%u_r%ut%u", sh.x, s->sym_plan[2], s->sym_plan[3], s->sym_layers - s->sym_plan[3]);
     else
         snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.kind == kPkLds ? "pk" : "",
                  nb::kTile * (sh.kind == kPkLds ? sh.x : 1), sh.ipl, sh.ls, s->jsplit);
@@ -294,6 +301,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
             if ((want.kind == kFused || want.kind == kDirect) && !may_fuse && !s->f64) want = {kPkLds, want.ipl, want.ls, 1};   // same loop, two kernels
             if (want.kind == kDirect && n > 1024u * (uint32_t)want.x) want = {kFused, 2, 64, 4};
             if (want.kind == kJpk && !may_fuse) want = {kPkSgpr, 4, 1, 4};      // whole-system f32 handles only
+            if (want.kind == kSym && (!whole || s->f64 || cfg.ext_bodies || n < 1024u * (uint32_t)want.x * 2u)) want = {kPkSgpr, 8, 1, 4};   // likewise; >= 4 super-blocks
             if (kernel_of(s->f64, want)) { sh = want; pinned = true; }
         }
     }
@@ -422,6 +430,33 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
         if (js < 1) js = 1;
     }
     if (sh.kind == kFused || sh.kind == kDirect) js = 1;
+    if (sh.kind == kSym) {
+        // super-blocks of S = 512 * WS rows on a ring; workgroup (g, q) sweeps `seg` chunks of 128 travelers of g's list
+        // (H or H+1 super-blocks ahead on the ring, then g itself in resident-only mode).  cfg.jsplit, if given, is the
+        // number of segments per super-block; otherwise enough segments for ~2 workgroups per resident slot.
+        const uint32_t S = 512u * (uint32_t)sh.x, cps = S / 128u;
+        const uint32_t nsb = ceil_div(n, S), H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
+        const uint32_t total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (H + 1) * cps;     // + the resident-only chunks of g itself
+        int occ = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel_of(false, sh), 64 * sh.x, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 16 / sh.x; }
+        const uint32_t slots = (uint32_t)occ * (uint32_t)n_cu;
+        uint32_t q = cfg.jsplit ? cfg.jsplit : ceil_div(2u * slots, nsb);
+        if (q < 1) q = 1;
+        uint32_t seg = ceil_div(total_hi, q);
+        if (seg < 1) seg = 1;
+        nb::SymPlan pl;
+        pl.np = nsb * S; pl.nsb = nsb; pl.seg = seg;
+        pl.q_hi = ceil_div(total_hi, seg); pl.q_lo = ceil_div(total_lo, seg);
+        pl.n_hi = n_hi; pl.H = H; pl.r_layer0 = 0; pl.t_layer0 = pl.q_hi;
+        static_assert(sizeof(pl) == sizeof(s->sym_plan), "nb_sim::sym_plan mirrors nb::SymPlan");
+        memcpy(s->sym_plan, &pl, sizeof pl);
+        s->sym = true; s->sym_np = pl.np; s->sym_layers = pl.q_hi + H + (n_hi ? 1u : 0u);
+        s->ipl = 8; s->ls = 1; s->packed = true; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
+        s->ws = sh.x; s->tl = 1;
+        s->jsplit = pl.q_hi; s->j_per_split = seg * 128u; s->swap_acc = false; s->own_split0 = 0; s->own_splits = 0;
+        name_variant(s, sh);
+        return;
+    }
     s->ipl = sh.ipl; s->ls = sh.ls;
     s->packed = sh.kind != kScalar; s->sgpr = sh.kind == kPkSgpr;
     s->fused = sh.kind == kFused || sh.kind == kDirect || sh.kind == kJpk;
@@ -458,6 +493,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
 
 Shape shape_of(const nb_sim* s)
 {
+    if (s->sym) return {kSym, 8, 1, s->ws};
     if (s->jpk) return {kJpk, 1, 1, s->ws};
     if (s->direct) return {kDirect, s->ipl, s->ls, s->tl};
     if (s->fused) return {kFused, s->ipl, s->ls, s->tl};
@@ -475,9 +511,12 @@ const void* jstream(const nb_sim* s, int k) { return gm_active(s) ? s->gm[k] : s
 int ensure_gm(nb_sim* s)
 {
     if (!gm_active(s)) { s->gm_ok = false; return NB_OK; }      // steps taken meanwhile leave any old copy behind
-    const size_t bytes = (size_t)16 * s->n;
+    const size_t bytes = (size_t)16 * (s->sym ? s->sym_np : s->n);
     for (int k = 0; k < (s->fused ? 2 : 1); ++k)
-        if (!s->gm[k]) NB_HIP(s, hipMalloc(&s->gm[k], bytes));
+        if (!s->gm[k]) {
+            NB_HIP(s, hipMalloc(&s->gm[k], bytes));
+            if (s->sym) NB_HIP(s, hipMemsetAsync(s->gm[k], 0, bytes, s->stream));     // zero-mass rows past n
+        }
     if (s->gm_ok && s->gm_G == s->G) return NB_OK;
     const float4* b = (const float4*)s->bodies[s->cur];
     float4* g = (float4*)s->gm[s->cur];
@@ -504,6 +543,16 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
 {
     using V4 = typename nb::vec4<T>::type;
     const Shape sh = shape_of(s);
+    if (s->sym) {
+        nb::SymPlan pl;
+        memcpy(&pl, s->sym_plan, sizeof pl);
+        const float4* b = (const float4*)jstream(s, s->cur);
+        float4* p = (float4*)s->partial;
+        float e2 = (float)s->eps2;
+        void* args[] = {&b, &p, &pl, &e2};
+        launch_kernel(kernel_of(false, sh), dim3(pl.n_hi * pl.q_hi + (pl.nsb - pl.n_hi) * pl.q_lo), dim3(64 * sh.x), args, s->stream, t0, t1);
+        return;
+    }
     nb::SplitWindow win{0, 0xffffffffu, 0};
     uint32_t ny = s->jsplit;
     if (part == 1) { win.base = s->own_split0; ny = s->own_splits; }
@@ -575,6 +624,21 @@ void launch_integrate(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullpt
     T dt = (T)s->dt, G = (T)s->G;
     // the j-stream rows of the new positions; a handle whose rows are exchanged rebuilds the whole copy after the gather instead
     V4* gout = gm_active(s) && !(s->xfn || s->rccl) ? (V4*)s->gm[s->cur] : nullptr;
+    if (s->sym) {
+        if constexpr (std::is_same<T, float>::value) {
+            nb::SymPlan pl;
+            memcpy(&pl, s->sym_plan, sizeof pl);
+            float4 *bb = (float4*)b, *vv = (float4*)v, *aa = (float4*)s->acc, *gg = (float4*)gout;
+            const float4* pp = (const float4*)s->partial;
+            uint32_t n = s->n;
+            float fdt = (float)s->dt, fG = (float)s->G;
+            void* args[] = {&bb, &vv, &aa, &pp, &n, &pl, &fdt, &gg, &fG};
+            const void* fn = s->ws == 2 ? (const void*)&nb::nb_integrate_sym<2, 8> : s->ws == 4 ? (const void*)&nb::nb_integrate_sym<4, 8>
+                                                                                   : (const void*)&nb::nb_integrate_sym<8, 8>;
+            launch_kernel(fn, dim3(ceil_div(n * 8u, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
+        }
+        return;
+    }
     if (s->swap_acc) {
         // jsplit == 1: the single partial array IS a_new; K2 reads it beside a_old and the two
         // buffers swap roles (no 16-B store of a per body: 96 B per body in all)
@@ -758,13 +822,16 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     const size_t row = 4 * s->esz;
     if (cfg.ext_bodies) { s->bodies[0] = cfg.ext_bodies; s->own_bodies = false; }
     else {
-        NB_HIPC(hipMalloc(&s->bodies[0], row * s->n));
+        const size_t rows = s->sym ? s->sym_np : s->n;        // the symmetric pass reads whole super-blocks: zero-mass rows past n
+        NB_HIPC(hipMalloc(&s->bodies[0], row * rows));
+        if (s->sym) NB_HIPC(hipMemset(s->bodies[0], 0, row * rows));
         s->own_bodies = true;
         if (s->fused) NB_HIPC(hipMalloc(&s->bodies[1], row * s->n));
     }
     NB_HIPC(hipMalloc(&s->vel, row * s->sc));
     NB_HIPC(hipMalloc(&s->acc, row * s->sc));
-    if (!s->fused) NB_HIPC(hipMalloc(&s->partial, row * s->sc * s->jsplit));
+    if (s->sym) NB_HIPC(hipMalloc(&s->partial, row * (size_t)s->sym_np * s->sym_layers));
+    else if (!s->fused) NB_HIPC(hipMalloc(&s->partial, row * s->sc * s->jsplit));
     if (s->jpk) {
         // pairs: whole 4-pair units (128 B) plus one spare the loop's last request may touch; everything past the
         // system stays zero (zero-mass bodies at the origin).  Partials: 64 rows per (split, i-block).
@@ -1036,7 +1103,7 @@ int nb_integrate_pass(nb_sim* s, uint32_t reps, double* avg_ms)
     const double dt = s->dt > 0 ? s->dt : 1e-3;
     const double keep = s->dt;
     s->dt = dt;
-    if (s->steps_done == 0) NB_HIP(s, hipMemsetAsync(s->partial, 0, 4 * s->esz * s->sc * s->jsplit, s->stream));
+    if (s->steps_done == 0) NB_HIP(s, hipMemsetAsync(s->partial, 0, s->sym ? (size_t)16 * s->sym_np * s->sym_layers : 4 * s->esz * s->sc * s->jsplit, s->stream));
     hipEvent_t e0, e1;
     NB_HIP(s, hipEventCreate(&e0));
     NB_HIP(s, hipEventCreate(&e1));

@@ -83,6 +83,11 @@ struct nb_sim {
     bool swap_acc = false; // two-kernel step with jsplit == 1: K2 reads the partial as a_new and the
                            // acc/partial buffers swap roles (96 B per body)
     uint32_t jsplit = 1, j_per_split = 0;
+    // nb_force_sym: the symmetric force pass (each unordered pair once, both accelerations); whole-system f32 handles.
+    // bodies / gm are allocated with sym_np >= n rows (zero-mass padding); `partial` holds sym_layers x sym_np rows.
+    bool sym = false;
+    uint32_t sym_np = 0, sym_layers = 0;
+    uint32_t sym_plan[9] = {0};    // nb::SymPlan, kept as plain words here (nb_comm.hip does not see the kernels' types)
     std::string variant, err;
     nb_exchange_fn xfn = nullptr;
     nb_exchange_wait_fn xwait = nullptr;   // non-null: two-phase (overlapped) exchange

@@ -1012,6 +1012,221 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
     }
 }
 
+// ---- symmetric force pass (Newton's third law inside a wave) -----------------------------------
+// Every kernel above evaluates each ORDERED pair on its own: 12 v_pk + 2 v_rsq_f32 per two pairs, the instruction-mix
+// ceiling of 62.5 % of the fp32 vector rate.  r = x_j - x_i, r^2, the cube and the reciprocal square root are the same
+// numbers for (i, j) and (j, i) (IEEE subtraction is exactly antisymmetric), so this pass computes them ONCE per
+// unordered pair and accumulates both accelerations -- the per-pair products (G m_j) inv r and (G m_i) inv (-r) are
+// bit for bit the reference's (nbody3d.js:233-236); only the order of the additions differs:
+//   * a lane keeps 8 RESIDENT bodies (4 packed groups, as nb_force_pk_sgpr<4,..>); J = 2 TRAVELING bodies per lane --
+//     a chunk of 128 bodies per wave -- rotate through the 64 lanes with v_mov_b32_dpp wave_ror:1 (full rate on gfx950:
+//     tools/experiments/ubench6.hip), their six packed sums traveling with them; after 64 steps every resident of the
+//     wave has met every traveler of the chunk and the travelers are back in their home lanes;
+//   * per (traveler, packed group): 3 v_pk_add, 3 v_pk_fma, 2 v_pk_mul, 2 v_rsq_f32, v_pk_mul + 3 v_pk_fma for the
+//     resident side, v_pk_mul + 3 v_pk_fma (negated) for the traveler side = 16 packed + 2 transcendental per FOUR
+//     interactions, + 10 v_mov_b32_dpp per traveler and step: 90 issue slots per 16 interactions against 128 --
+//     measured 74.7 % of the fp32 roofline for the bare loop (profiles/r03/ubench6_*.txt) against 60 %;
+//   * coverage: the bodies form nsb SUPER-BLOCKS of S = 512*WS rows (one 512-row block per wave of a workgroup).
+//     Workgroup (g, q) keeps super-block g resident and sweeps segment q of g's chunk list: the chunks of the H =
+//     (nsb-1)/2 super-blocks that follow g on the ring (plus the antipodal one for g < nsb/2 when nsb is even) --
+//     every unordered pair of different super-blocks exactly once -- and then the chunks of super-block g ITSELF in
+//     resident-only mode (traveler sums discarded: every ordered pair inside g once; the self term is exactly 0);
+//   * sums: a wave's resident sums go to layer (r_layer0 + q); the traveler sums of a chunk are added over the WS waves
+//     in wave order through LDS (one barrier per chunk, double buffered) and go to layer (t_layer0 + ring distance - 1).
+//     nb_integrate_sym adds a body's layers in ascending order: deterministic, no float atomics.
+// Rows [n, np) of `bodies` are zero-mass bodies at the origin (np = nsb * S).
+struct SymPlan {
+    uint32_t np, nsb;          // padded rows, super-blocks
+    uint32_t seg;              // chunks per workgroup
+    uint32_t q_hi, q_lo;       // segments per super-block: g < n_hi (the ones with the antipodal partner) / the others
+    uint32_t n_hi, H;          // n_hi = nsb/2 when nsb is even, else 0; H = (nsb-1)/2
+    uint32_t r_layer0, t_layer0;
+};
+
+__device__ __forceinline__ float wave_rot1(float v)
+{
+    const int iv = __builtin_bit_cast(int, v);      // old = src: every lane is written, no init move
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x13C /* wave_ror:1 */, 0xF, 0xF, false));
+}
+
+template <int WS, int J>
+__global__ __launch_bounds__(64 * WS) __attribute__((amdgpu_waves_per_eu(4, 4)))
+void nb_force_sym(const float4* __restrict__ bodies, float4* __restrict__ partial, const SymPlan pl, const float eps2)
+{
+    constexpr int NG = 4;                      // packed groups: 8 residents per lane
+    constexpr uint32_t S = 512u * WS;          // rows per super-block
+    constexpr uint32_t CH = 64u * J;           // travelers per chunk
+    constexpr uint32_t CPS = S / CH;           // chunks per super-block
+    __shared__ float red[2][WS][3 * J][64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    uint32_t g, q;
+    {
+        const uint32_t bid = blockIdx.x, first = pl.n_hi * pl.q_hi;
+        if (bid < first) { g = bid / pl.q_hi; q = bid % pl.q_hi; }
+        else { const uint32_t r = bid - first; g = pl.n_hi + r / pl.q_lo; q = r % pl.q_lo; }
+    }
+    const uint32_t ring = (pl.H + (g < pl.n_hi ? 1u : 0u)) * CPS;     // symmetric chunks of g; CPS resident-only chunks follow
+    const uint32_t c0 = q * pl.seg;
+    uint32_t c1 = c0 + pl.seg;
+    if (c1 > ring + CPS) c1 = ring + CPS;
+
+    nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
+    {
+        const float4* rb = bodies + (size_t)g * S + w * 512u + lane;
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+            const float4 b0 = ld4(rb + (2 * c) * 64), b1 = ld4(rb + (2 * c + 1) * 64);
+            xi[c] = nb_f2{b0.x, b1.x}; yi[c] = nb_f2{b0.y, b1.y}; zi[c] = nb_f2{b0.z, b1.z}; mi[c] = nb_f2{b0.w, b1.w};
+            ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
+        }
+    }
+    const nb_f2 e2 = nb_f2{eps2, eps2};
+
+    for (uint32_t k = c0; k < c1; ++k) {
+        const bool sym = k < ring;                                   // wave-uniform
+        const uint32_t d = k / CPS;                                  // ring distance - 1 (symmetric chunks)
+        uint32_t tb = g + 1 + d;
+        if (tb >= pl.nsb) tb -= pl.nsb;
+        const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
+        float tx[J], ty[J], tz[J], tm[J];
+        nb_f2 bx[J], by[J], bz[J];
+#pragma unroll
+        for (int u = 0; u < J; ++u) {
+            const float4 t = ld4(bodies + tstart + u * 64 + lane);
+            tx[u] = t.x; ty[u] = t.y; tz[u] = t.z; tm[u] = t.w;
+            bx[u] = nb_f2{0, 0}; by[u] = nb_f2{0, 0}; bz[u] = nb_f2{0, 0};
+        }
+        for (int st = 0; st < 64; ++st) {
+#pragma unroll
+            for (int u = 0; u < J; ++u) {
+                const nb_f2 px = nb_f2{tx[u], tx[u]}, py = nb_f2{ty[u], ty[u]}, pz = nb_f2{tz[u], tz[u]}, pm = nb_f2{tm[u], tm[u]};
+                nb_f2 dx[NG], dy[NG], dz[NG], d2[NG], r[NG], si[NG], sj[NG];
+#pragma unroll
+                for (int c = 0; c < NG; ++c) dx[c] = px - xi[c];                                   // :233
+#pragma unroll
+                for (int c = 0; c < NG; ++c) dy[c] = py - yi[c];
+#pragma unroll
+                for (int c = 0; c < NG; ++c) dz[c] = pz - zi[c];
+#pragma unroll
+                for (int c = 0; c < NG; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);   // :234
+#pragma unroll
+                for (int c = 0; c < NG; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+                for (int c = 0; c < NG; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+                for (int c = 0; c < NG; ++c) r[c] = d2[c] * d2[c];                                 // :235
+#pragma unroll
+                for (int c = 0; c < NG; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+                for (int c = 0; c < NG; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+#pragma unroll
+                for (int c = 0; c < NG; ++c) si[c] = pm * r[c];          // (G m_t) inv: resident side, :236
+#pragma unroll
+                for (int c = 0; c < NG; ++c) sj[c] = mi[c] * r[c];       // (G m_i) inv: traveler side
+#pragma unroll
+                for (int c = 0; c < NG; ++c) ax[c] = __builtin_elementwise_fma(si[c], dx[c], ax[c]);
+#pragma unroll
+                for (int c = 0; c < NG; ++c) ay[c] = __builtin_elementwise_fma(si[c], dy[c], ay[c]);
+#pragma unroll
+                for (int c = 0; c < NG; ++c) az[c] = __builtin_elementwise_fma(si[c], dz[c], az[c]);
+#pragma unroll
+                for (int c = 0; c < NG; ++c) bx[u] = __builtin_elementwise_fma(-sj[c], dx[c], bx[u]);   // x_i - x_t = -(x_t - x_i), exactly
+#pragma unroll
+                for (int c = 0; c < NG; ++c) by[u] = __builtin_elementwise_fma(-sj[c], dy[c], by[u]);
+#pragma unroll
+                for (int c = 0; c < NG; ++c) bz[u] = __builtin_elementwise_fma(-sj[c], dz[c], bz[u]);
+            }
+            // the travelers and their sums move on by one lane
+#pragma unroll
+            for (int u = 0; u < J; ++u) {
+                tx[u] = wave_rot1(tx[u]); ty[u] = wave_rot1(ty[u]); tz[u] = wave_rot1(tz[u]); tm[u] = wave_rot1(tm[u]);
+                bx[u] = nb_f2{wave_rot1(bx[u].x), wave_rot1(bx[u].y)};
+                by[u] = nb_f2{wave_rot1(by[u].x), wave_rot1(by[u].y)};
+                bz[u] = nb_f2{wave_rot1(bz[u].x), wave_rot1(bz[u].y)};
+            }
+        }
+        if (sym) {
+            // traveler sums of the chunk: added over the workgroup's waves in wave order, stored by one of them
+            const int buf = (k - c0) & 1;
+#pragma unroll
+            for (int u = 0; u < J; ++u) {
+                red[buf][w][3 * u + 0][lane] = bx[u].x + bx[u].y;
+                red[buf][w][3 * u + 1][lane] = by[u].x + by[u].y;
+                red[buf][w][3 * u + 2][lane] = bz[u].x + bz[u].y;
+            }
+            __syncthreads();
+            if (w == k % WS) {
+                float4* out = partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart + lane;
+#pragma unroll
+                for (int u = 0; u < J; ++u) {
+                    float sx = red[buf][0][3 * u + 0][lane], sy = red[buf][0][3 * u + 1][lane], sz = red[buf][0][3 * u + 2][lane];
+#pragma unroll
+                    for (int ww = 1; ww < WS; ++ww) { sx += red[buf][ww][3 * u + 0][lane]; sy += red[buf][ww][3 * u + 1][lane]; sz += red[buf][ww][3 * u + 2][lane]; }
+                    out[u * 64] = float4{sx, sy, sz, 0};
+                }
+            }
+        }
+    }
+    // resident sums of this segment
+    float4* out = partial + (size_t)(pl.r_layer0 + q) * pl.np + (size_t)g * S + w * 512u + lane;
+#pragma unroll
+    for (int c = 0; c < NG; ++c) {
+        out[(2 * c) * 64] = float4{ax[c].x, ay[c].x, az[c].x, 0};
+        out[(2 * c + 1) * 64] = float4{ax[c].y, ay[c].y, az[c].y, 0};
+    }
+}
+
+// K2 for the symmetric pass: a body's acceleration is the sum of its resident layers (one per segment of its
+// super-block's chunk list) and its traveler layers (one per ring distance), in ascending layer order.
+template <int WS, int R>
+__global__ __launch_bounds__(kBlock) void nb_integrate_sym(float4* __restrict__ bodies, float4* __restrict__ vel, float4* __restrict__ acc,
+                                                          const float4* __restrict__ partial, uint32_t n, const SymPlan pl, float dt,
+                                                          float4* __restrict__ gout, float G)
+{
+    constexpr uint32_t S = 512u * WS;
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t il = gid / R, r = gid % R;
+    const bool valid = il < n;
+    float sx = 0, sy = 0, sz = 0;
+    if (valid) {
+        const uint32_t b = il / S;
+        const uint32_t nr = b < pl.n_hi ? pl.q_hi : pl.q_lo;
+        const uint32_t nt = pl.H + ((pl.n_hi && b >= pl.n_hi) ? 1u : 0u);
+        const uint32_t total = nr + nt;
+        auto row = [&](uint32_t e) { return partial + (size_t)(e < nr ? pl.r_layer0 + e : pl.t_layer0 + (e - nr)) * pl.np + il; };
+        uint32_t e = r;
+        for (; e + 3 * R < total; e += 4 * R) {
+            const float4 p0 = ld4(row(e)), p1 = ld4(row(e + R)), p2 = ld4(row(e + 2 * R)), p3 = ld4(row(e + 3 * R));
+            sx += p0.x; sy += p0.y; sz += p0.z;
+            sx += p1.x; sy += p1.y; sz += p1.z;
+            sx += p2.x; sy += p2.y; sz += p2.z;
+            sx += p3.x; sy += p3.y; sz += p3.z;
+        }
+        for (; e < total; e += R) {
+            const float4 p0 = ld4(row(e));
+            sx += p0.x; sy += p0.y; sz += p0.z;
+        }
+    }
+    if constexpr (R > 1) {
+#pragma unroll
+        for (int m = 1; m < R; m <<= 1) {
+            sx += __shfl_xor(sx, m, 64);
+            sy += __shfl_xor(sy, m, 64);
+            sz += __shfl_xor(sz, m, 64);
+        }
+    }
+    if (!valid || r != 0) return;
+    float4 nx, nv, na;
+    leapfrog<float>(ld4(bodies + il), ld4(vel + il), ld4(acc + il), sx, sy, sz, dt, nx, nv, na);
+    vel[il] = nv;                                                       // :281
+    bodies[il] = nx;                                                    // :283
+    acc[il] = na;                                                       // :290
+    if (gout) gout[il] = float4{nx.x, nx.y, nx.z, G * nx.w};
+}
+
 // ---- j-packed SGPR step (mid-size systems) ----------------------------------------------------
 // The packed kernels above vectorise across TWO i-BODIES of a lane, so a lane owns at least two
 // bodies and a system of N bodies offers N/128 waves of i-work: to fill 1,024 SIMDs below
