@@ -142,10 +142,15 @@ const void* kernel_of(bool f64, const Shape& sh)
         case kDirect:
             if (f64 || sh.ipl != 2 || sh.ls != 64) return nullptr;
             return sh.x == 1 ? (const void*)&nb::nb_step_direct<16> : sh.x == 2 ? (const void*)&nb::nb_step_direct<32> : nullptr;
-        case kSym:
-            if (f64 || sh.ipl != 8 || sh.ls != 1) return nullptr;
-            return sh.x == 2 ? (const void*)&nb::nb_force_sym<2, 2> : sh.x == 4 ? (const void*)&nb::nb_force_sym<4, 2>
-                   : sh.x == 8 ? (const void*)&nb::nb_force_sym<8, 2> : nullptr;
+        case kSym:       // ipl = residents per lane (8 or 16), x = waves per workgroup
+            if (f64 || sh.ls != 1) return nullptr;
+            if (sh.ipl == 8)
+                return sh.x == 1 ? (const void*)&nb::nb_force_sym<1, 4, 2> : sh.x == 2 ? (const void*)&nb::nb_force_sym<2, 4, 2>
+                       : sh.x == 4 ? (const void*)&nb::nb_force_sym<4, 4, 2> : sh.x == 8 ? (const void*)&nb::nb_force_sym<8, 4, 2> : nullptr;
+            if (sh.ipl == 16)
+                return sh.x == 1 ? (const void*)&nb::nb_force_sym<1, 8, 2> : sh.x == 2 ? (const void*)&nb::nb_force_sym<2, 8, 2>
+                       : sh.x == 4 ? (const void*)&nb::nb_force_sym<4, 8, 2> : nullptr;
+            return nullptr;
         case kJpk:
             if (f64 || sh.ipl != 1 || sh.ls != 1) return nullptr;
             return sh.x == 4 ? (const void*)&nb::nb_step_jpk<4> : sh.x == 8 ? (const void*)&nb::nb_step_jpk<8>
@@ -158,7 +163,7 @@ const void* kernel_of(bool f64, const Shape& sh)
 uint32_t ipb_of(const Shape& sh)
 {
     if (sh.kind == kJpk) return 64;
-    if (sh.kind == kSym) return 512u * (uint32_t)sh.x;
+    if (sh.kind == kSym) return 64u * (uint32_t)sh.ipl * (uint32_t)sh.x;
     if (sh.kind == kPkSgpr) return (uint32_t)(nb::kBlock / sgpr_ws(sh.x)) * sh.ipl;
     return (uint32_t)(nb::kBlock / sh.ls) * sh.ipl;
 }
@@ -200,7 +205,7 @@ void name_variant(nb_sim* s, const Shape& sh)
     else if (sh.kind == kJpk)
         snprintf(buf, sizeof buf, "f32pk_fused_jpairs_ws%d_js%u", jpk_ws(sh.x), s->jsplit);
     else if (sh.kind == kSym)
-        snprintf(buf, sizeof buf, "f32pk_sym_ws%d_seg%u_r%ut%u", sh.x, s->sym_plan[2], s->sym_plan[3], s->sym_layers - s->sym_plan[3]);
+        snprintf(buf, sizeof buf, "f32pk_sym_ipl%d_ws%d_r%ut%u", sh.ipl, sh.x, s->sym_plan[2], s->sym_layers - s->sym_plan[2]);
     else
         snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.kind == kPkLds ? "pk" : "",
                  nb::kTile * (sh.kind == kPkLds ? sh.x : 1), sh.ipl, sh.ls, s->jsplit);
@@ -301,7 +306,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
             if ((want.kind == kFused || want.kind == kDirect) && !may_fuse && !s->f64) want = {kPkLds, want.ipl, want.ls, 1};   // same loop, two kernels
             if (want.kind == kDirect && n > 1024u * (uint32_t)want.x) want = {kFused, 2, 64, 4};
             if (want.kind == kJpk && !may_fuse) want = {kPkSgpr, 4, 1, 4};      // whole-system f32 handles only
-            if (want.kind == kSym && (!whole || s->f64 || cfg.ext_bodies || n < 1024u * (uint32_t)want.x * 2u)) want = {kPkSgpr, 8, 1, 4};   // likewise; >= 4 super-blocks
+            if (want.kind == kSym && (!whole || s->f64 || cfg.ext_bodies || !kernel_of(false, want) || n < 4u * ipb_of(want))) want = {kPkSgpr, 8, 1, 4};   // likewise; >= 4 super-blocks
             if (kernel_of(s->f64, want)) { sh = want; pinned = true; }
         }
     }
@@ -431,29 +436,35 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
     }
     if (sh.kind == kFused || sh.kind == kDirect) js = 1;
     if (sh.kind == kSym) {
-        // super-blocks of S = 512 * WS rows on a ring; workgroup (g, q) sweeps `seg` chunks of 128 travelers of g's list
-        // (H or H+1 super-blocks ahead on the ring, then g itself in resident-only mode).  cfg.jsplit, if given, is the
-        // number of segments per super-block; otherwise enough segments for ~2 workgroups per resident slot.
-        const uint32_t S = 512u * (uint32_t)sh.x, cps = S / 128u;
+        // super-blocks of S rows on a ring; workgroup (g, q) sweeps segment q of Q of g's chunk list (the H or H+1
+        // super-blocks ahead on the ring, then g itself in resident-only mode).  cfg.jsplit, if given, is Q.
+        // One wave per SIMD already issues this loop at ~90 % of its rate (profiles/r03/symsweep_*.txt: 256 workgroups of 4
+        // waves run as fast per pair as 1,024), so what matters is that every SIMD gets the same number of equal
+        // waves: time ~ ceil(nsb * Q * WS / SIMDs) * ceil(chunks / Q) chunk-sweeps; Q minimises that (ties: fewest layers).
+        const uint32_t S = ipb_of(sh), cps = S / 128u;
         const uint32_t nsb = ceil_div(n, S), H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
         const uint32_t total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (H + 1) * cps;     // + the resident-only chunks of g itself
-        int occ = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel_of(false, sh), 64 * sh.x, 0) != hipSuccess || occ < 1) { (void)hipGetLastError(); occ = 16 / sh.x; }
-        const uint32_t slots = (uint32_t)occ * (uint32_t)n_cu;
-        uint32_t q = cfg.jsplit ? cfg.jsplit : ceil_div(2u * slots, nsb);
+        uint32_t q = cfg.jsplit;
+        if (q == 0) {
+            double best = 1e300;
+            for (uint32_t c = 1; c <= total_hi && c <= 512; ++c) {
+                // rounds of waves over the chip's SIMDs (a workgroup's WS waves sit on different SIMDs) x chunks per workgroup,
+                // + ~15 % of a sweep per workgroup (residents in, sums out)
+                const double t = (double)ceil_div(nsb * c * (uint32_t)sh.x, 4u * (uint32_t)n_cu) * (ceil_div(total_hi, c) + 0.15);
+                if (t < best * 0.999) { best = t; q = c; }
+            }
+        }
+        if (q > total_hi) q = total_hi;
         if (q < 1) q = 1;
-        uint32_t seg = ceil_div(total_hi, q);
-        if (seg < 1) seg = 1;
         nb::SymPlan pl;
-        pl.np = nsb * S; pl.nsb = nsb; pl.seg = seg;
-        pl.q_hi = ceil_div(total_hi, seg); pl.q_lo = ceil_div(total_lo, seg);
-        pl.n_hi = n_hi; pl.H = H; pl.r_layer0 = 0; pl.t_layer0 = pl.q_hi;
+        pl.np = nsb * S; pl.nsb = nsb; pl.q = q; pl.total_hi = total_hi; pl.total_lo = total_lo;
+        pl.n_hi = n_hi; pl.H = H; pl.r_layer0 = 0; pl.t_layer0 = q;
         static_assert(sizeof(pl) == sizeof(s->sym_plan), "nb_sim::sym_plan mirrors nb::SymPlan");
         memcpy(s->sym_plan, &pl, sizeof pl);
-        s->sym = true; s->sym_np = pl.np; s->sym_layers = pl.q_hi + H + (n_hi ? 1u : 0u);
-        s->ipl = 8; s->ls = 1; s->packed = true; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
+        s->sym = true; s->sym_np = pl.np; s->sym_layers = q + H + (n_hi ? 1u : 0u);
+        s->ipl = sh.ipl; s->ls = 1; s->packed = true; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
         s->ws = sh.x; s->tl = 1;
-        s->jsplit = pl.q_hi; s->j_per_split = seg * 128u; s->swap_acc = false; s->own_split0 = 0; s->own_splits = 0;
+        s->jsplit = q; s->j_per_split = ceil_div(total_hi, q) * 128u; s->swap_acc = false; s->own_split0 = 0; s->own_splits = 0;
         name_variant(s, sh);
         return;
     }
@@ -493,7 +504,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
 
 Shape shape_of(const nb_sim* s)
 {
-    if (s->sym) return {kSym, 8, 1, s->ws};
+    if (s->sym) return {kSym, s->ipl, 1, s->ws};
     if (s->jpk) return {kJpk, 1, 1, s->ws};
     if (s->direct) return {kDirect, s->ipl, s->ls, s->tl};
     if (s->fused) return {kFused, s->ipl, s->ls, s->tl};
@@ -547,10 +558,11 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
         nb::SymPlan pl;
         memcpy(&pl, s->sym_plan, sizeof pl);
         const float4* b = (const float4*)jstream(s, s->cur);
-        float4* p = (float4*)s->partial;
+        nb::SymRow* p = (nb::SymRow*)s->partial;       // 12-byte rows
         float e2 = (float)s->eps2;
-        void* args[] = {&b, &p, &pl, &e2};
-        launch_kernel(kernel_of(false, sh), dim3(pl.n_hi * pl.q_hi + (pl.nsb - pl.n_hi) * pl.q_lo), dim3(64 * sh.x), args, s->stream, t0, t1);
+        uint32_t n = s->n;
+        void* args[] = {&b, &p, &pl, &n, &e2};
+        launch_kernel(kernel_of(false, sh), dim3(pl.nsb * pl.q), dim3(64 * sh.x), args, s->stream, t0, t1);
         return;
     }
     nb::SplitWindow win{0, 0xffffffffu, 0};
@@ -629,13 +641,11 @@ void launch_integrate(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullpt
             nb::SymPlan pl;
             memcpy(&pl, s->sym_plan, sizeof pl);
             float4 *bb = (float4*)b, *vv = (float4*)v, *aa = (float4*)s->acc, *gg = (float4*)gout;
-            const float4* pp = (const float4*)s->partial;
-            uint32_t n = s->n;
+            const nb::SymRow* pp = (const nb::SymRow*)s->partial;
+            uint32_t n = s->n, S = ipb_of(shape_of(s));
             float fdt = (float)s->dt, fG = (float)s->G;
-            void* args[] = {&bb, &vv, &aa, &pp, &n, &pl, &fdt, &gg, &fG};
-            const void* fn = s->ws == 2 ? (const void*)&nb::nb_integrate_sym<2, 8> : s->ws == 4 ? (const void*)&nb::nb_integrate_sym<4, 8>
-                                                                                   : (const void*)&nb::nb_integrate_sym<8, 8>;
-            launch_kernel(fn, dim3(ceil_div(n * 8u, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
+            void* args[] = {&bb, &vv, &aa, &pp, &n, &pl, &S, &fdt, &gg, &fG};
+            launch_kernel((const void*)&nb::nb_integrate_sym<8>, dim3(ceil_div(n * 8u, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
         }
         return;
     }
@@ -830,7 +840,7 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     }
     NB_HIPC(hipMalloc(&s->vel, row * s->sc));
     NB_HIPC(hipMalloc(&s->acc, row * s->sc));
-    if (s->sym) NB_HIPC(hipMalloc(&s->partial, row * (size_t)s->sym_np * s->sym_layers));
+    if (s->sym) NB_HIPC(hipMalloc(&s->partial, (size_t)12 * s->sym_np * s->sym_layers));   // (x, y, z) rows
     else if (!s->fused) NB_HIPC(hipMalloc(&s->partial, row * s->sc * s->jsplit));
     if (s->jpk) {
         // pairs: whole 4-pair units (128 B) plus one spare the loop's last request may touch; everything past the
@@ -1103,7 +1113,7 @@ int nb_integrate_pass(nb_sim* s, uint32_t reps, double* avg_ms)
     const double dt = s->dt > 0 ? s->dt : 1e-3;
     const double keep = s->dt;
     s->dt = dt;
-    if (s->steps_done == 0) NB_HIP(s, hipMemsetAsync(s->partial, 0, s->sym ? (size_t)16 * s->sym_np * s->sym_layers : 4 * s->esz * s->sc * s->jsplit, s->stream));
+    if (s->steps_done == 0) NB_HIP(s, hipMemsetAsync(s->partial, 0, s->sym ? (size_t)12 * s->sym_np * s->sym_layers : 4 * s->esz * s->sc * s->jsplit, s->stream));
     hipEvent_t e0, e1;
     NB_HIP(s, hipEventCreate(&e0));
     NB_HIP(s, hipEventCreate(&e1));

@@ -1027,18 +1027,20 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
 //     interactions, + 10 v_mov_b32_dpp per traveler and step: 90 issue slots per 16 interactions against 128 --
 //     measured 74.7 % of the fp32 roofline for the bare loop (profiles/r03/ubench6_*.txt) against 60 %;
 //   * coverage: the bodies form nsb SUPER-BLOCKS of S = 512*WS rows (one 512-row block per wave of a workgroup).
-//     Workgroup (g, q) keeps super-block g resident and sweeps segment q of g's chunk list: the chunks of the H =
+//     Workgroup (g, q) keeps super-block g resident and sweeps segment q (of Q nearly equal ones) of g's chunk list: the chunks of the H =
 //     (nsb-1)/2 super-blocks that follow g on the ring (plus the antipodal one for g < nsb/2 when nsb is even) --
 //     every unordered pair of different super-blocks exactly once -- and then the chunks of super-block g ITSELF in
 //     resident-only mode (traveler sums discarded: every ordered pair inside g once; the self term is exactly 0);
 //   * sums: a wave's resident sums go to layer (r_layer0 + q); the traveler sums of a chunk are added over the WS waves
 //     in wave order through LDS (one barrier per chunk, double buffered) and go to layer (t_layer0 + ring distance - 1).
-//     nb_integrate_sym adds a body's layers in ascending order: deterministic, no float atomics.
+//     nb_integrate_sym adds a body's layers in ascending order: deterministic, no float atomics.  A partial row is
+//     12 bytes (x, y, z: one global_store_dwordx3 per lane): the layers are the pass's memory traffic.
 // Rows [n, np) of `bodies` are zero-mass bodies at the origin (np = nsb * S).
+struct SymRow { float x, y, z; };   // 12-byte partial row (an ext_vector_type(3) would be padded to 16)
 struct SymPlan {
     uint32_t np, nsb;          // padded rows, super-blocks
-    uint32_t seg;              // chunks per workgroup
-    uint32_t q_hi, q_lo;       // segments per super-block: g < n_hi (the ones with the antipodal partner) / the others
+    uint32_t q;                // segments per super-block's chunk list (workgroups per super-block)
+    uint32_t total_hi, total_lo;   // chunks in the list of a super-block g < n_hi (it has the antipodal partner) / of the others
     uint32_t n_hi, H;          // n_hi = nsb/2 when nsb is even, else 0; H = (nsb-1)/2
     uint32_t r_layer0, t_layer0;
 };
@@ -1049,33 +1051,31 @@ __device__ __forceinline__ float wave_rot1(float v)
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x13C /* wave_ror:1 */, 0xF, 0xF, false));
 }
 
-template <int WS, int J>
-__global__ __launch_bounds__(64 * WS) __attribute__((amdgpu_waves_per_eu(4, 4)))
-void nb_force_sym(const float4* __restrict__ bodies, float4* __restrict__ partial, const SymPlan pl, const float eps2)
+// NG packed groups = 2*NG residents per lane (NG = 4: 128 VGPRs, 4 waves per SIMD; NG = 8: the rotation is amortised over
+// twice the pairs -- one wave per SIMD already issues this loop at ~90 % of its rate, so 2 waves per SIMD are enough);
+// WS waves per workgroup, each with its own 128*NG resident rows; J travelers per lane.
+template <int WS, int NG, int J>
+__global__ __launch_bounds__(64 * WS) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : 4)))
+void nb_force_sym(const float4* __restrict__ bodies, SymRow* __restrict__ partial, const SymPlan pl, const uint32_t n, const float eps2)
 {
-    constexpr int NG = 4;                      // packed groups: 8 residents per lane
-    constexpr uint32_t S = 512u * WS;          // rows per super-block
+    constexpr uint32_t RB = 128u * NG;         // resident rows per wave
+    constexpr uint32_t S = RB * WS;            // rows per super-block
     constexpr uint32_t CH = 64u * J;           // travelers per chunk
     constexpr uint32_t CPS = S / CH;           // chunks per super-block
-    __shared__ float red[2][WS][3 * J][64];
+    __shared__ float red[WS > 1 ? 2 : 1][WS > 1 ? WS : 1][3 * J][64];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-    uint32_t g, q;
-    {
-        const uint32_t bid = blockIdx.x, first = pl.n_hi * pl.q_hi;
-        if (bid < first) { g = bid / pl.q_hi; q = bid % pl.q_hi; }
-        else { const uint32_t r = bid - first; g = pl.n_hi + r / pl.q_lo; q = r % pl.q_lo; }
-    }
+    const uint32_t g = blockIdx.x / pl.q, q = blockIdx.x % pl.q;
     const uint32_t ring = (pl.H + (g < pl.n_hi ? 1u : 0u)) * CPS;     // symmetric chunks of g; CPS resident-only chunks follow
-    const uint32_t c0 = q * pl.seg;
-    uint32_t c1 = c0 + pl.seg;
-    if (c1 > ring + CPS) c1 = ring + CPS;
+    const uint32_t total = ring + CPS;
+    // segment q of Q: chunk ranges of (nearly) equal length, [q * total / Q, (q + 1) * total / Q)
+    const uint32_t c0 = (uint32_t)(((uint64_t)q * total) / pl.q), c1 = (uint32_t)(((uint64_t)(q + 1) * total) / pl.q);
 
     nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
     {
-        const float4* rb = bodies + (size_t)g * S + w * 512u + lane;
+        const float4* rb = bodies + (size_t)g * S + w * RB + lane;
 #pragma unroll
         for (int c = 0; c < NG; ++c) {
             const float4 b0 = ld4(rb + (2 * c) * 64), b1 = ld4(rb + (2 * c + 1) * 64);
@@ -1085,12 +1085,14 @@ void nb_force_sym(const float4* __restrict__ bodies, float4* __restrict__ partia
     }
     const nb_f2 e2 = nb_f2{eps2, eps2};
 
+    uint32_t done = 0;                                               // symmetric chunks processed: alternates the LDS buffer
     for (uint32_t k = c0; k < c1; ++k) {
         const bool sym = k < ring;                                   // wave-uniform
         const uint32_t d = k / CPS;                                  // ring distance - 1 (symmetric chunks)
         uint32_t tb = g + 1 + d;
         if (tb >= pl.nsb) tb -= pl.nsb;
         const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
+        if (tstart >= n) continue;       // a chunk of padding rows only (zero mass): exerts nothing, and nobody reads its sums
         float tx[J], ty[J], tz[J], tm[J];
         nb_f2 bx[J], by[J], bz[J];
 #pragma unroll
@@ -1103,41 +1105,45 @@ void nb_force_sym(const float4* __restrict__ bodies, float4* __restrict__ partia
 #pragma unroll
             for (int u = 0; u < J; ++u) {
                 const nb_f2 px = nb_f2{tx[u], tx[u]}, py = nb_f2{ty[u], ty[u]}, pz = nb_f2{tz[u], tz[u]}, pm = nb_f2{tm[u], tm[u]};
-                nb_f2 dx[NG], dy[NG], dz[NG], d2[NG], r[NG], si[NG], sj[NG];
+                // stage-major over groups of four (as every packed kernel here); NG = 8 runs two such groups
 #pragma unroll
-                for (int c = 0; c < NG; ++c) dx[c] = px - xi[c];                                   // :233
+                for (int c0g = 0; c0g < NG; c0g += 4) {
+                    nb_f2 dx[4], dy[4], dz[4], d2[4], r[4], si[4], sj[4];
 #pragma unroll
-                for (int c = 0; c < NG; ++c) dy[c] = py - yi[c];
+                    for (int c = 0; c < 4; ++c) dx[c] = px - xi[c0g + c];                                   // :233
 #pragma unroll
-                for (int c = 0; c < NG; ++c) dz[c] = pz - zi[c];
+                    for (int c = 0; c < 4; ++c) dy[c] = py - yi[c0g + c];
 #pragma unroll
-                for (int c = 0; c < NG; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);   // :234
+                    for (int c = 0; c < 4; ++c) dz[c] = pz - zi[c0g + c];
 #pragma unroll
-                for (int c = 0; c < NG; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+                    for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
 #pragma unroll
-                for (int c = 0; c < NG; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+                    for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
 #pragma unroll
-                for (int c = 0; c < NG; ++c) r[c] = d2[c] * d2[c];                                 // :235
+                    for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
 #pragma unroll
-                for (int c = 0; c < NG; ++c) r[c] = r[c] * d2[c];
+                    for (int c = 0; c < 4; ++c) r[c] = d2[c] * d2[c];                                       // :235
 #pragma unroll
-                for (int c = 0; c < NG; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+                    for (int c = 0; c < 4; ++c) r[c] = r[c] * d2[c];
 #pragma unroll
-                for (int c = 0; c < NG; ++c) si[c] = pm * r[c];          // (G m_t) inv: resident side, :236
+                    for (int c = 0; c < 4; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
 #pragma unroll
-                for (int c = 0; c < NG; ++c) sj[c] = mi[c] * r[c];       // (G m_i) inv: traveler side
+                    for (int c = 0; c < 4; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
 #pragma unroll
-                for (int c = 0; c < NG; ++c) ax[c] = __builtin_elementwise_fma(si[c], dx[c], ax[c]);
+                    for (int c = 0; c < 4; ++c) sj[c] = mi[c0g + c] * r[c];       // (G m_i) inv: traveler side
 #pragma unroll
-                for (int c = 0; c < NG; ++c) ay[c] = __builtin_elementwise_fma(si[c], dy[c], ay[c]);
+                    for (int c = 0; c < 4; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
 #pragma unroll
-                for (int c = 0; c < NG; ++c) az[c] = __builtin_elementwise_fma(si[c], dz[c], az[c]);
+                    for (int c = 0; c < 4; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
 #pragma unroll
-                for (int c = 0; c < NG; ++c) bx[u] = __builtin_elementwise_fma(-sj[c], dx[c], bx[u]);   // x_i - x_t = -(x_t - x_i), exactly
+                    for (int c = 0; c < 4; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
 #pragma unroll
-                for (int c = 0; c < NG; ++c) by[u] = __builtin_elementwise_fma(-sj[c], dy[c], by[u]);
+                    for (int c = 0; c < 4; ++c) bx[u] = __builtin_elementwise_fma(-sj[c], dx[c], bx[u]);   // x_i - x_t = -(x_t - x_i), exactly
 #pragma unroll
-                for (int c = 0; c < NG; ++c) bz[u] = __builtin_elementwise_fma(-sj[c], dz[c], bz[u]);
+                    for (int c = 0; c < 4; ++c) by[u] = __builtin_elementwise_fma(-sj[c], dy[c], by[u]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bz[u] = __builtin_elementwise_fma(-sj[c], dz[c], bz[u]);
+                }
             }
             // the travelers and their sums move on by one lane
 #pragma unroll
@@ -1149,64 +1155,70 @@ void nb_force_sym(const float4* __restrict__ bodies, float4* __restrict__ partia
             }
         }
         if (sym) {
-            // traveler sums of the chunk: added over the workgroup's waves in wave order, stored by one of them
-            const int buf = (k - c0) & 1;
+            SymRow* out = partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart + lane;
+            if constexpr (WS == 1) {
 #pragma unroll
-            for (int u = 0; u < J; ++u) {
-                red[buf][w][3 * u + 0][lane] = bx[u].x + bx[u].y;
-                red[buf][w][3 * u + 1][lane] = by[u].x + by[u].y;
-                red[buf][w][3 * u + 2][lane] = bz[u].x + bz[u].y;
-            }
-            __syncthreads();
-            if (w == k % WS) {
-                float4* out = partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart + lane;
+                for (int u = 0; u < J; ++u) out[u * 64] = SymRow{bx[u].x + bx[u].y, by[u].x + by[u].y, bz[u].x + bz[u].y};
+            } else {
+                // traveler sums of the chunk: added over the workgroup's waves in wave order, stored by one of them.
+                // One barrier per chunk: the buffers alternate, and the wave that reads buffer b passes the NEXT
+                // barrier only after its reads, which is before anybody writes b again.
+                const int buf = done++ & 1;
 #pragma unroll
                 for (int u = 0; u < J; ++u) {
-                    float sx = red[buf][0][3 * u + 0][lane], sy = red[buf][0][3 * u + 1][lane], sz = red[buf][0][3 * u + 2][lane];
+                    red[buf][w][3 * u + 0][lane] = bx[u].x + bx[u].y;
+                    red[buf][w][3 * u + 1][lane] = by[u].x + by[u].y;
+                    red[buf][w][3 * u + 2][lane] = bz[u].x + bz[u].y;
+                }
+                __syncthreads();
+                if (w == done % WS) {
 #pragma unroll
-                    for (int ww = 1; ww < WS; ++ww) { sx += red[buf][ww][3 * u + 0][lane]; sy += red[buf][ww][3 * u + 1][lane]; sz += red[buf][ww][3 * u + 2][lane]; }
-                    out[u * 64] = float4{sx, sy, sz, 0};
+                    for (int u = 0; u < J; ++u) {
+                        float sx = red[buf][0][3 * u + 0][lane], sy = red[buf][0][3 * u + 1][lane], sz = red[buf][0][3 * u + 2][lane];
+#pragma unroll
+                        for (int ww = 1; ww < WS; ++ww) { sx += red[buf][ww][3 * u + 0][lane]; sy += red[buf][ww][3 * u + 1][lane]; sz += red[buf][ww][3 * u + 2][lane]; }
+                        out[u * 64] = SymRow{sx, sy, sz};
+                    }
                 }
             }
         }
     }
     // resident sums of this segment
-    float4* out = partial + (size_t)(pl.r_layer0 + q) * pl.np + (size_t)g * S + w * 512u + lane;
+    SymRow* out = partial + (size_t)(pl.r_layer0 + q) * pl.np + (size_t)g * S + w * RB + lane;
 #pragma unroll
     for (int c = 0; c < NG; ++c) {
-        out[(2 * c) * 64] = float4{ax[c].x, ay[c].x, az[c].x, 0};
-        out[(2 * c + 1) * 64] = float4{ax[c].y, ay[c].y, az[c].y, 0};
+        out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
+        out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
     }
 }
 
 // K2 for the symmetric pass: a body's acceleration is the sum of its resident layers (one per segment of its
 // super-block's chunk list) and its traveler layers (one per ring distance), in ascending layer order.
-template <int WS, int R>
+template <int R>
 __global__ __launch_bounds__(kBlock) void nb_integrate_sym(float4* __restrict__ bodies, float4* __restrict__ vel, float4* __restrict__ acc,
-                                                          const float4* __restrict__ partial, uint32_t n, const SymPlan pl, float dt,
+                                                          const SymRow* __restrict__ partial, uint32_t n, const SymPlan pl, uint32_t S, float dt,
                                                           float4* __restrict__ gout, float G)
 {
-    constexpr uint32_t S = 512u * WS;
     const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t il = gid / R, r = gid % R;
     const bool valid = il < n;
     float sx = 0, sy = 0, sz = 0;
     if (valid) {
         const uint32_t b = il / S;
-        const uint32_t nr = b < pl.n_hi ? pl.q_hi : pl.q_lo;
+        const uint32_t nr = pl.q;
         const uint32_t nt = pl.H + ((pl.n_hi && b >= pl.n_hi) ? 1u : 0u);
         const uint32_t total = nr + nt;
         auto row = [&](uint32_t e) { return partial + (size_t)(e < nr ? pl.r_layer0 + e : pl.t_layer0 + (e - nr)) * pl.np + il; };
         uint32_t e = r;
         for (; e + 3 * R < total; e += 4 * R) {
-            const float4 p0 = ld4(row(e)), p1 = ld4(row(e + R)), p2 = ld4(row(e + 2 * R)), p3 = ld4(row(e + 3 * R));
+            const SymRow p0 = *row(e), p1 = *row(e + R), p2 = *row(e + 2 * R), p3 = *row(e + 3 * R);
             sx += p0.x; sy += p0.y; sz += p0.z;
             sx += p1.x; sy += p1.y; sz += p1.z;
             sx += p2.x; sy += p2.y; sz += p2.z;
             sx += p3.x; sy += p3.y; sz += p3.z;
         }
         for (; e < total; e += R) {
-            const float4 p0 = ld4(row(e));
+            const SymRow p0 = *row(e);
             sx += p0.x; sy += p0.y; sz += p0.z;
         }
     }
