@@ -94,6 +94,17 @@ def _jsplit(variant_name):
         return 1
 
 
+def _k2_bytes_per_body(variant_name):
+    """Bytes the integrate kernel moves per body: the algorithmic 96 plus the partial sums it adds up --
+    16 B per j-split of the ordered-pair kernels, 12 B per resident / traveler layer of the symmetric pass."""
+    import re
+    m = re.search(r"_r(\d+)t(\d+)$", variant_name)
+    if "sym" in variant_name and m:
+        return 96.0 + 12.0 * (int(m.group(1)) + int(m.group(2)))
+    js = _jsplit(variant_name)
+    return 96.0 if js == 1 else 96.0 + 16.0 * js
+
+
 def spawn_ranks(args):
     """`bench.py --gpus N` without a launcher: this process stays GPU-free (no HIP call, no torch
     import) and starts the N ranks as a child `python -m torch.distributed.run`; it exits with
@@ -549,20 +560,24 @@ def main():
                     tj.get("kernel_variant") == sim.variant):
                 traffic, traffic_src = tj.get("bytes_per_launch"), "profiles/k1_hbm_traffic.json (" + tj.get("source", "") + ")"
         fused = "fused" in sim.variant
-        kname = "nb_step_jpk" if "jpairs" in sim.variant else "nb_step_direct" if "fused_regs" in sim.variant else "nb_step_fused" if fused else "nb_force"
+        kname = ("nb_force_symw" if "symw" in sim.variant else "nb_force_sym" if "_sym_" in sim.variant else "nb_step_jpk" if "jpairs" in sim.variant
+                 else "nb_step_direct" if "fused_regs" in sim.variant else "nb_step_fused" if fused else "nb_force")
         out["roofline"] = {"kernel": kname + "<%s> (%s)" % (args.precision, sim.variant),
                            "bound": "valu",
                            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": f_ms, "launches": launches,
                            "flops_per_pair": FLOPS_PER_PAIR,
                            "note": "compute-bound on the fp32 vector-FMA rate (157.3 TFLOP/s spec, equal to the "
-                                   "dense f32 MFMA peak); not HBM and not MFMA: rsqrt-bound scalar FMA",
+                                   "dense f32 MFMA peak); not HBM and not MFMA: rsqrt-bound scalar FMA.  achieved = 20 flop x "
+                                   "N(N-1) ORDERED pair interactions (SURVEY.md §8(d)) / launch time" +
+                                   ("; the symmetric pass delivers them by evaluating each unordered pair once (r, r^2, the cube and "
+                                    "the rsqrt are shared; both accelerations accumulated), 18 packed/transcendental issue slots + "
+                                    "rotation per TWO interactions instead of 16 per one" if "sym" in sim.variant else ""),
                            "integrate_kernel_avg_ms": i_ms}
         if i_ms > 0:
             # algorithmic 96 B per body; "moved" adds the jsplit partials K2 sums.
             # At this size the state is cache-resident: the HBM figure of K2 is tools/k2_hbm.py (N >= 4M)
-            js = _jsplit(sim.variant)
-            moved = 96.0 if js == 1 else 96.0 + 16.0 * js
+            moved = _k2_bytes_per_body(sim.variant)
             out["roofline"]["integrate_kernel_GBps"] = 96.0 * plan.count / (i_ms * 1e-3) / 1e9
             out["roofline"]["integrate_kernel_GBps_moved"] = moved * plan.count / (i_ms * 1e-3) / 1e9
             out["roofline"]["integrate_bytes_moved_over_algorithmic"] = moved / 96.0

@@ -71,6 +71,9 @@ typedef enum nb_precision { NB_F32 = 0, NB_F64 = 1 } nb_precision;
                                   part / partition mode) instead of write-through (sc1) stores + a relaxed ticket: the
                                   conservative fallback, 2-8 us per step slower; bit-identical results */
 
+#define NB_FLAG_NO_SYM 64u     /* tuning/A-B: never pick the symmetric force pass (K = 7: each unordered pair once, both
+                                  accelerations), i.e. keep the ordered-pair kernels of ABI 2 at every size */
+
 /* nb_array: selector for nb_device_ptr */
 typedef enum nb_array { NB_BODIES = 0, NB_VEL = 1, NB_ACCEL = 2 } nb_array;
 
@@ -114,6 +117,11 @@ typedef struct nb_config {
                                from a pair-transposed copy of the positions (II = 01, LL = 01;
                                X = waves per workgroup splitting j: 4, 8, or 6 for 16); jsplit > 1
                                splits j over workgroups too (reduced in the same launch).
+                               K = 7: the symmetric force pass (whole-system f32 handles): every unordered pair is
+                               evaluated once and both accelerations accumulated; II = resident bodies per lane (08
+                               or 16), LL = 01, X = 3 / 1: wave-granular form with 1 / 2 traveling bodies per lane
+                               (jsplit = waves per SIMD), X = 4: workgroup form (II = 08; jsplit = segments per
+                               super-block).  E.g. 716013.
                                See nb_variant_name().                              */
     uint32_t jsplit;        /* number of j-partitions (grid.y)                  */
     uint32_t flags;         /* NB_FLAG_*                                        */

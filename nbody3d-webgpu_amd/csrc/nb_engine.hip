@@ -142,14 +142,12 @@ const void* kernel_of(bool f64, const Shape& sh)
         case kDirect:
             if (f64 || sh.ipl != 2 || sh.ls != 64) return nullptr;
             return sh.x == 1 ? (const void*)&nb::nb_step_direct<16> : sh.x == 2 ? (const void*)&nb::nb_step_direct<32> : nullptr;
-        case kSym:       // ipl = residents per lane (8 or 16), x = waves per workgroup
+        case kSym:       // ipl = residents per lane (8 or 16); x = 1 / 3: wave-granular form with 2 / 1 travelers per lane,
+                         // x = 4: workgroup form (4 waves, 8 residents per lane)
             if (f64 || sh.ls != 1) return nullptr;
-            if (sh.ipl == 8)
-                return sh.x == 1 ? (const void*)&nb::nb_force_sym<1, 4, 2> : sh.x == 2 ? (const void*)&nb::nb_force_sym<2, 4, 2>
-                       : sh.x == 4 ? (const void*)&nb::nb_force_sym<4, 4, 2> : sh.x == 8 ? (const void*)&nb::nb_force_sym<8, 4, 2> : nullptr;
-            if (sh.ipl == 16)
-                return sh.x == 1 ? (const void*)&nb::nb_force_sym<1, 8, 2> : sh.x == 2 ? (const void*)&nb::nb_force_sym<2, 8, 2>
-                       : sh.x == 4 ? (const void*)&nb::nb_force_sym<4, 8, 2> : nullptr;
+            if (sh.x == 4) return sh.ipl == 8 ? (const void*)&nb::nb_force_sym<4, 4, 2> : nullptr;
+            if (sh.ipl == 8) return sh.x == 1 ? (const void*)&nb::nb_force_symw<4, 2> : sh.x == 3 ? (const void*)&nb::nb_force_symw<4, 1> : nullptr;
+            if (sh.ipl == 16) return sh.x == 1 ? (const void*)&nb::nb_force_symw<8, 2> : sh.x == 3 ? (const void*)&nb::nb_force_symw<8, 1> : nullptr;
             return nullptr;
         case kJpk:
             if (f64 || sh.ipl != 1 || sh.ls != 1) return nullptr;
@@ -163,7 +161,7 @@ const void* kernel_of(bool f64, const Shape& sh)
 uint32_t ipb_of(const Shape& sh)
 {
     if (sh.kind == kJpk) return 64;
-    if (sh.kind == kSym) return 64u * (uint32_t)sh.ipl * (uint32_t)sh.x;
+    if (sh.kind == kSym) return 64u * (uint32_t)sh.ipl * (sh.x == 4 ? 4u : 1u);      // rows per super-block
     if (sh.kind == kPkSgpr) return (uint32_t)(nb::kBlock / sgpr_ws(sh.x)) * sh.ipl;
     return (uint32_t)(nb::kBlock / sh.ls) * sh.ipl;
 }
@@ -205,7 +203,8 @@ void name_variant(nb_sim* s, const Shape& sh)
     else if (sh.kind == kJpk)
         snprintf(buf, sizeof buf, "f32pk_fused_jpairs_ws%d_js%u", jpk_ws(sh.x), s->jsplit);
     else if (sh.kind == kSym)
-        snprintf(buf, sizeof buf, "f32pk_sym_ipl%d_ws%d_r%ut%u", sh.ipl, sh.x, s->sym_plan[2], s->sym_layers - s->sym_plan[2]);
+        snprintf(buf, sizeof buf, s->symw ? "f32pk_symw_ipl%d_j%d_w%u_r%ut%u" : "f32pk_sym_ipl%d_ws%d_q%u_r%ut%u", sh.ipl, s->symw ? (sh.x == 3 ? 1 : 2) : sh.x,
+                 s->sym_plan[2], s->sym_plan[8] - s->sym_plan[7], s->sym_layers - (s->sym_plan[8] - s->sym_plan[7]));     // words 7, 8: r_layer0, t_layer0 in both plans
     else
         snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.kind == kPkLds ? "pk" : "",
                  nb::kTile * (sh.kind == kPkLds ? sh.x : 1), sh.ipl, sh.ls, s->jsplit);
@@ -249,6 +248,36 @@ const ModelKnobs& model_knobs()
         return m;
     }();
     return k;
+}
+
+// The symmetric pass, wave-granular form (nb_force_symw<NG, 1>): predicted step time for n bodies with 2*NG residents per lane
+// and k waves per SIMD.  A chunk-sweep is 64 rotation steps of NG * (16 packed + 2 transcendental) + 10 DPP issue slots; the
+// loop runs at 93.5 % of that (N = 65,536 and 262,144, both forms: profiles/r03/sym_variants_scan_wave_granular.txt).  L
+// chunk-sweeps are cut into W = k * SIMDs equal ranges; one wave per SIMD leaves ~1 % on the table (k = 1: 82.5 %, k = 2: 83.3 %
+// at N = 262,144) but halves the rounding loss of ceil(L / W) at mid sizes (N = 40,002: 270 us with k = 1, 283 us with k = 2).
+struct SymChoice { int ipl; uint32_t k; double t; };
+SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary)
+{
+    SymChoice best{0, 0, 1e300};
+    for (int ipl : {8, 16}) {
+        const uint32_t NG = (uint32_t)ipl / 2, S = 64u * (uint32_t)ipl, cps = S / 64u;
+        const uint32_t nsb = ceil_div(n, S);
+        if (nsb < 4) continue;
+        const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
+        const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (uint64_t)(H + 1) * cps;
+        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo;
+        const double t_chunk = 64.0 * (80.0 * NG + 40.0) / 0.935 / clock;
+        for (uint32_t k = 1; k <= 4; ++k) {
+            const uint64_t W = (uint64_t)4 * n_cu * k;
+            if (W > L) break;
+            const double per_wave = (double)((L + W - 1) / W);
+            const double segs = per_wave / (double)total_lo + 1.0;             // super-blocks a wave's range touches
+            const double layers = (double)(H + 1) + (double)total_hi / ((double)L / (double)W) + 1.0;     // traveler + resident layers K2 reads per body
+            const double t = per_wave * k * t_chunk / (k == 1 ? 0.99 : 1.0) + segs * k * 1.5e-6 + boundary + layers * n * 12.0 / 2.0e12;
+            if (t < best.t) best = {ipl, k, t};
+        }
+    }
+    return best;
 }
 
 void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
@@ -296,7 +325,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
     }
 
     Shape sh{s->f64 ? kScalar : kPkLds, 2, 1, 1};
-    uint32_t js = cfg.jsplit;
+    uint32_t js = cfg.jsplit, sym_k = 0;
     const uint32_t variant = cfg.force_variant;
     bool pinned = false;
     if (variant != 0) {
@@ -306,7 +335,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
             if ((want.kind == kFused || want.kind == kDirect) && !may_fuse && !s->f64) want = {kPkLds, want.ipl, want.ls, 1};   // same loop, two kernels
             if (want.kind == kDirect && n > 1024u * (uint32_t)want.x) want = {kFused, 2, 64, 4};
             if (want.kind == kJpk && !may_fuse) want = {kPkSgpr, 4, 1, 4};      // whole-system f32 handles only
-            if (want.kind == kSym && (!whole || s->f64 || cfg.ext_bodies || !kernel_of(false, want) || n < 4u * ipb_of(want))) want = {kPkSgpr, 8, 1, 4};   // likewise; >= 4 super-blocks
+            if (want.kind == kSym && (!whole || s->f64 || cfg.ext_bodies || !kernel_of(false, want) || n <= ipb_of(want))) want = {kPkSgpr, 8, 1, 4};   // likewise; >= 2 super-blocks
             if (kernel_of(s->f64, want)) { sh = want; pinned = true; }
         }
     }
@@ -427,6 +456,12 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
             if (!pick || c.q < pick->q || (c.q == pick->q && c.t < pick->t)) pick = &c;
         }
         if (pick) { if (!pinned) sh = pick->sh; js = pick->q; }
+        // the symmetric pass (whole-system f32 handles; every unordered pair once): from N ~ 14,000 up it beats every
+        // ordered-pair shape above (N = 16,384: 61.7 vs 65.7 us, 40,002: 270 vs 357 us, 262,144: 10.5 vs 14.6 ms)
+        if (!pinned && whole && !s->f64 && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
+            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary);
+            if (sc2.ipl && sc2.t < (pick ? pick->t : best_t)) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; }
+        }
     }
     if (js < 1) {   // pinned shape outside the model's candidate list: fill ~4096 workgroups
         js = ceil_div((uint32_t)n_cu * 16, ceil_div(sc, ipb_of(sh)));
@@ -435,12 +470,50 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
         if (js < 1) js = 1;
     }
     if (sh.kind == kFused || sh.kind == kDirect) js = 1;
+    if (sh.kind == kSym && sh.x != 4) {
+        // wave-granular form: super-block = one wave's residents; the chunk lists of all super-blocks laid end to end are cut
+        // into W equal ranges, W = cfg.jsplit (default 1) waves per SIMD of the chip.
+        const uint32_t S = ipb_of(sh), J = sh.x == 3 ? 1u : 2u, cps = S / (64u * J);
+        const uint32_t nsb = ceil_div(n, S), H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
+        nb::SymWPlan pl;
+        pl.np = nsb * S; pl.nsb = nsb;
+        pl.total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps; pl.total_lo = (H + 1) * cps;
+        pl.n_hi = n_hi; pl.H = H;
+        pl.L = n_hi * pl.total_hi + (nsb - n_hi) * pl.total_lo;
+        uint32_t W = 4u * (uint32_t)n_cu * (sym_k ? sym_k : cfg.jsplit ? cfg.jsplit : 1u);
+        if (W > pl.L) W = (pl.L + 3u) & ~3u;
+        pl.W = W;
+        auto start_of = [&](uint32_t w) { return (uint32_t)(((uint64_t)w * pl.L) / pl.W); };
+        auto wave_of = [&](uint32_t p) {
+            uint32_t w = (uint32_t)(((uint64_t)p * pl.W) / pl.L);
+            while (w + 1 < pl.W && start_of(w + 1) <= p) ++w;
+            while (w > 0 && start_of(w) > p) --w;
+            return w;
+        };
+        s->sym_tab_host.assign(2 * (size_t)nsb, 0);
+        uint32_t max_r = 1;
+        for (uint32_t g = 0; g < nsb; ++g) {
+            const uint32_t total = g < n_hi ? pl.total_hi : pl.total_lo;
+            const uint32_t off = g <= n_hi ? g * pl.total_hi : n_hi * pl.total_hi + (g - n_hi) * pl.total_lo;
+            const uint32_t first = wave_of(off), last = wave_of(off + total - 1);
+            s->sym_tab_host[2 * g] = first; s->sym_tab_host[2 * g + 1] = last - first + 1;
+            if (last - first + 1 > max_r) max_r = last - first + 1;
+        }
+        pl.r_layer0 = 0; pl.t_layer0 = max_r;
+        static_assert(sizeof(pl) <= sizeof(s->sym_plan), "nb_sim::sym_plan holds a SymWPlan");
+        memcpy(s->sym_plan, &pl, sizeof pl);
+        s->sym = true; s->symw = true; s->sym_np = pl.np; s->sym_layers = max_r + H + (n_hi ? 1u : 0u);
+        s->ipl = sh.ipl; s->ls = 1; s->packed = true; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
+        s->ws = sh.x; s->tl = 1;
+        s->jsplit = max_r; s->j_per_split = ceil_div(pl.L, pl.W) * 64u * J; s->swap_acc = false; s->own_split0 = 0; s->own_splits = 0;
+        name_variant(s, sh);
+        return;
+    }
     if (sh.kind == kSym) {
-        // super-blocks of S rows on a ring; workgroup (g, q) sweeps segment q of Q of g's chunk list (the H or H+1
-        // super-blocks ahead on the ring, then g itself in resident-only mode).  cfg.jsplit, if given, is Q.
-        // One wave per SIMD already issues this loop at ~90 % of its rate (profiles/r03/symsweep_*.txt: 256 workgroups of 4
-        // waves run as fast per pair as 1,024), so what matters is that every SIMD gets the same number of equal
-        // waves: time ~ ceil(nsb * Q * WS / SIMDs) * ceil(chunks / Q) chunk-sweeps; Q minimises that (ties: fewest layers).
+        // workgroup form: super-blocks of S rows on a ring; workgroup (g, q) sweeps segment q of Q of g's chunk list (the H or
+        // H+1 super-blocks ahead on the ring, then g itself in resident-only mode).  cfg.jsplit, if given, is Q.
+        // One wave per SIMD already issues this loop at ~90 % of its rate (profiles/r03/symsweep_*.txt), so what matters is
+        // that every CU gets the same number of equal workgroups: time ~ ceil(nsb * Q / CUs) * ceil(chunks / Q) sweeps.
         const uint32_t S = ipb_of(sh), cps = S / 128u;
         const uint32_t nsb = ceil_div(n, S), H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
         const uint32_t total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (H + 1) * cps;     // + the resident-only chunks of g itself
@@ -448,9 +521,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
         if (q == 0) {
             double best = 1e300;
             for (uint32_t c = 1; c <= total_hi && c <= 512; ++c) {
-                // rounds of waves over the chip's SIMDs (a workgroup's WS waves sit on different SIMDs) x chunks per workgroup,
-                // + ~15 % of a sweep per workgroup (residents in, sums out)
-                const double t = (double)ceil_div(nsb * c * (uint32_t)sh.x, 4u * (uint32_t)n_cu) * (ceil_div(total_hi, c) + 0.15);
+                const double t = (double)ceil_div(nsb * c, (uint32_t)n_cu) * (ceil_div(total_hi, c) + 0.15);   // + ~15 % of a sweep per workgroup
                 if (t < best * 0.999) { best = t; q = c; }
             }
         }
@@ -459,7 +530,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
         nb::SymPlan pl;
         pl.np = nsb * S; pl.nsb = nsb; pl.q = q; pl.total_hi = total_hi; pl.total_lo = total_lo;
         pl.n_hi = n_hi; pl.H = H; pl.r_layer0 = 0; pl.t_layer0 = q;
-        static_assert(sizeof(pl) == sizeof(s->sym_plan), "nb_sim::sym_plan mirrors nb::SymPlan");
+        static_assert(sizeof(pl) <= sizeof(s->sym_plan), "nb_sim::sym_plan holds a SymPlan");
         memcpy(s->sym_plan, &pl, sizeof pl);
         s->sym = true; s->sym_np = pl.np; s->sym_layers = q + H + (n_hi ? 1u : 0u);
         s->ipl = sh.ipl; s->ls = 1; s->packed = true; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
@@ -554,6 +625,18 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
 {
     using V4 = typename nb::vec4<T>::type;
     const Shape sh = shape_of(s);
+    if (s->symw) {
+        nb::SymWPlan pl;
+        memcpy(&pl, s->sym_plan, sizeof pl);
+        const float4* b = (const float4*)jstream(s, s->cur);
+        nb::SymRow* p = (nb::SymRow*)s->partial;
+        const uint32_t* tab = s->sym_tab;
+        float e2 = (float)s->eps2;
+        uint32_t n = s->n;
+        void* args[] = {&b, &p, &tab, &pl, &n, &e2};
+        launch_kernel(kernel_of(false, sh), dim3(ceil_div(pl.W, 4u)), dim3(256), args, s->stream, t0, t1);
+        return;
+    }
     if (s->sym) {
         nb::SymPlan pl;
         memcpy(&pl, s->sym_plan, sizeof pl);
@@ -636,6 +719,20 @@ void launch_integrate(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullpt
     T dt = (T)s->dt, G = (T)s->G;
     // the j-stream rows of the new positions; a handle whose rows are exchanged rebuilds the whole copy after the gather instead
     V4* gout = gm_active(s) && !(s->xfn || s->rccl) ? (V4*)s->gm[s->cur] : nullptr;
+    if (s->symw) {
+        if constexpr (std::is_same<T, float>::value) {
+            nb::SymWPlan pl;
+            memcpy(&pl, s->sym_plan, sizeof pl);
+            float4 *bb = (float4*)b, *vv = (float4*)v, *aa = (float4*)s->acc, *gg = (float4*)gout;
+            const nb::SymRow* pp = (const nb::SymRow*)s->partial;
+            const uint32_t* tab = s->sym_tab;
+            uint32_t n = s->n, S = ipb_of(shape_of(s));
+            float fdt = (float)s->dt, fG = (float)s->G;
+            void* args[] = {&bb, &vv, &aa, &pp, &tab, &n, &pl, &S, &fdt, &gg, &fG};
+            launch_kernel((const void*)&nb::nb_integrate_symw<8>, dim3(ceil_div(n * 8u, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
+        }
+        return;
+    }
     if (s->sym) {
         if constexpr (std::is_same<T, float>::value) {
             nb::SymPlan pl;
@@ -840,8 +937,15 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     }
     NB_HIPC(hipMalloc(&s->vel, row * s->sc));
     NB_HIPC(hipMalloc(&s->acc, row * s->sc));
-    if (s->sym) NB_HIPC(hipMalloc(&s->partial, (size_t)12 * s->sym_np * s->sym_layers));   // (x, y, z) rows
-    else if (!s->fused) NB_HIPC(hipMalloc(&s->partial, row * s->sc * s->jsplit));
+    if (s->sym) {
+        NB_HIPC(hipMalloc(&s->partial, (size_t)12 * s->sym_np * s->sym_layers));       // layers of 12-byte (x, y, z) rows
+        if (s->symw) {
+            NB_HIPC(hipMalloc((void**)&s->sym_tab, sizeof(uint32_t) * s->sym_tab_host.size()));
+            NB_HIPC(hipMemcpy(s->sym_tab, s->sym_tab_host.data(), sizeof(uint32_t) * s->sym_tab_host.size(), hipMemcpyHostToDevice));
+        }
+    } else if (!s->fused) {
+        NB_HIPC(hipMalloc(&s->partial, row * s->sc * s->jsplit));
+    }
     if (s->jpk) {
         // pairs: whole 4-pair units (128 B) plus one spare the loop's last request may touch; everything past the
         // system stays zero (zero-mass bodies at the origin).  Partials: 64 rows per (split, i-block).
@@ -889,6 +993,7 @@ void nb_destroy(nb_sim* s)
     for (auto& p : s->gm) if (p) (void)hipFree(p);
     if (s->jpartial) (void)hipFree(s->jpartial);
     if (s->tickets) (void)hipFree(s->tickets);
+    if (s->sym_tab) (void)hipFree(s->sym_tab);
     if (s->diag) (void)hipFree(s->diag);
     if (s->zero_row) (void)hipFree(s->zero_row);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);

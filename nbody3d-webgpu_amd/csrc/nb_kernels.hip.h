@@ -1192,6 +1192,183 @@ void nb_force_sym(const float4* __restrict__ bodies, SymRow* __restrict__ partia
     }
 }
 
+// The same pass with the WAVE as the unit of work (no LDS, no barrier): a super-block is one wave's 128*NG residents, and
+// the chunk lists of all super-blocks, laid end to end (L chunk-sweeps), are cut into W contiguous ranges of floor/ceil(L/W)
+// sweeps -- one per wave, W a multiple of the chip's SIMD count -- so every SIMD gets the same work to within ONE sweep at
+// any N (the workgroup form above needs nsb * Q to land on a multiple of the CU count).  A wave whose range crosses into the
+// next super-block stores its resident sums, reloads its residents and goes on; its resident sums of super-block g go to
+// layer r_layer0 + (w - first wave of g) (table `gtab`: first wave and wave count per super-block, built by the host).
+struct SymWPlan {
+    uint32_t np, nsb, W;
+    uint32_t total_hi, total_lo, n_hi, H;
+    uint32_t r_layer0, t_layer0;
+    uint32_t L;                 // n_hi * total_hi + (nsb - n_hi) * total_lo
+};
+
+template <int NG, int J>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : 4)))
+void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ partial, const uint32_t* __restrict__ gtab, const SymWPlan pl,
+                   const uint32_t n, const float eps2)
+{
+    constexpr uint32_t S = 128u * NG;          // rows per super-block = one wave's residents
+    constexpr uint32_t CH = 64u * J;           // travelers per chunk
+    constexpr uint32_t CPS = S / CH;           // chunks per super-block
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));     // the four waves of a workgroup are independent
+    if (w >= pl.W) return;
+    uint32_t p = (uint32_t)(((uint64_t)w * pl.L) / pl.W);
+    const uint32_t pend = (uint32_t)(((uint64_t)(w + 1) * pl.L) / pl.W);
+    const nb_f2 e2 = nb_f2{eps2, eps2};
+    const uint32_t first_lo = pl.n_hi * pl.total_hi;
+
+    while (p < pend) {
+        // which super-block's list p lies in, and where
+        uint32_t g, k, total;
+        if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
+        else { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
+        const uint32_t ring = total - CPS;                           // symmetric chunks of g; CPS resident-only chunks follow
+        uint32_t kend = k + (pend - p);
+        if (kend > total) kend = total;
+        p += kend - k;
+
+        nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
+        {
+            const float4* rb = bodies + (size_t)g * S + lane;
+#pragma unroll
+            for (int c = 0; c < NG; ++c) {
+                const float4 b0 = ld4(rb + (2 * c) * 64), b1 = ld4(rb + (2 * c + 1) * 64);
+                xi[c] = nb_f2{b0.x, b1.x}; yi[c] = nb_f2{b0.y, b1.y}; zi[c] = nb_f2{b0.z, b1.z}; mi[c] = nb_f2{b0.w, b1.w};
+                ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
+            }
+        }
+        for (; k < kend; ++k) {
+            const bool sym = k < ring;
+            const uint32_t d = k / CPS;                              // ring distance - 1 (symmetric chunks)
+            uint32_t tb = g + 1 + d;
+            if (tb >= pl.nsb) tb -= pl.nsb;
+            const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
+            if (tstart >= n) continue;   // a chunk of padding rows only (zero mass): exerts nothing, and nobody reads its sums
+            float tx[J], ty[J], tz[J], tm[J];
+            nb_f2 bx[J], by[J], bz[J];
+#pragma unroll
+            for (int u = 0; u < J; ++u) {
+                const float4 t = ld4(bodies + tstart + u * 64 + lane);
+                tx[u] = t.x; ty[u] = t.y; tz[u] = t.z; tm[u] = t.w;
+                bx[u] = nb_f2{0, 0}; by[u] = nb_f2{0, 0}; bz[u] = nb_f2{0, 0};
+            }
+            for (int st = 0; st < 64; ++st) {
+#pragma unroll
+                for (int u = 0; u < J; ++u) {
+                    const nb_f2 px = nb_f2{tx[u], tx[u]}, py = nb_f2{ty[u], ty[u]}, pz = nb_f2{tz[u], tz[u]}, pm = nb_f2{tm[u], tm[u]};
+#pragma unroll
+                    for (int c0g = 0; c0g < NG; c0g += 4) {          // stage-major over groups of four
+                        nb_f2 dx[4], dy[4], dz[4], d2[4], r[4], si[4], sj[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dx[c] = px - xi[c0g + c];                                   // :233
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dy[c] = py - yi[c0g + c];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) dz[c] = pz - zi[c0g + c];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) r[c] = d2[c] * d2[c];                                       // :235
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) sj[c] = mi[c0g + c] * r[c];       // (G m_i) inv: traveler side
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) bx[u] = __builtin_elementwise_fma(-sj[c], dx[c], bx[u]);   // x_i - x_t = -(x_t - x_i), exactly
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) by[u] = __builtin_elementwise_fma(-sj[c], dy[c], by[u]);
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) bz[u] = __builtin_elementwise_fma(-sj[c], dz[c], bz[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < J; ++u) {                        // the travelers and their sums move on by one lane
+                    tx[u] = wave_rot1(tx[u]); ty[u] = wave_rot1(ty[u]); tz[u] = wave_rot1(tz[u]); tm[u] = wave_rot1(tm[u]);
+                    bx[u] = nb_f2{wave_rot1(bx[u].x), wave_rot1(bx[u].y)};
+                    by[u] = nb_f2{wave_rot1(by[u].x), wave_rot1(by[u].y)};
+                    bz[u] = nb_f2{wave_rot1(bz[u].x), wave_rot1(bz[u].y)};
+                }
+            }
+            if (sym) {
+                SymRow* out = partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart + lane;
+#pragma unroll
+                for (int u = 0; u < J; ++u) out[u * 64] = SymRow{bx[u].x + bx[u].y, by[u].x + by[u].y, bz[u].x + bz[u].y};
+            }
+        }
+        // resident sums of this wave's part of g's list
+        SymRow* out = partial + (size_t)(pl.r_layer0 + (w - gtab[2 * g])) * pl.np + (size_t)g * S + lane;
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+            out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
+            out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
+        }
+    }
+}
+
+// K2 for the wave-granular form: resident layers gtab[2g+1] (waves that worked on g's list), then the traveler layers.
+template <int R>
+__global__ __launch_bounds__(kBlock) void nb_integrate_symw(float4* __restrict__ bodies, float4* __restrict__ vel, float4* __restrict__ acc,
+                                                           const SymRow* __restrict__ partial, const uint32_t* __restrict__ gtab, uint32_t n,
+                                                           const SymWPlan pl, uint32_t S, float dt, float4* __restrict__ gout, float G)
+{
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t il = gid / R, r = gid % R;
+    const bool valid = il < n;
+    float sx = 0, sy = 0, sz = 0;
+    if (valid) {
+        const uint32_t b = il / S;
+        const uint32_t nr = gtab[2 * b + 1];
+        const uint32_t nt = pl.H + ((pl.n_hi && b >= pl.n_hi) ? 1u : 0u);
+        const uint32_t total = nr + nt;
+        auto row = [&](uint32_t e) { return partial + (size_t)(e < nr ? pl.r_layer0 + e : pl.t_layer0 + (e - nr)) * pl.np + il; };
+        uint32_t e = r;
+        for (; e + 3 * R < total; e += 4 * R) {
+            const SymRow p0 = *row(e), p1 = *row(e + R), p2 = *row(e + 2 * R), p3 = *row(e + 3 * R);
+            sx += p0.x; sy += p0.y; sz += p0.z;
+            sx += p1.x; sy += p1.y; sz += p1.z;
+            sx += p2.x; sy += p2.y; sz += p2.z;
+            sx += p3.x; sy += p3.y; sz += p3.z;
+        }
+        for (; e < total; e += R) {
+            const SymRow p0 = *row(e);
+            sx += p0.x; sy += p0.y; sz += p0.z;
+        }
+    }
+    if constexpr (R > 1) {
+#pragma unroll
+        for (int m = 1; m < R; m <<= 1) {
+            sx += __shfl_xor(sx, m, 64);
+            sy += __shfl_xor(sy, m, 64);
+            sz += __shfl_xor(sz, m, 64);
+        }
+    }
+    if (!valid || r != 0) return;
+    float4 nx, nv, na;
+    leapfrog<float>(ld4(bodies + il), ld4(vel + il), ld4(acc + il), sx, sy, sz, dt, nx, nv, na);
+    vel[il] = nv;                                                       // :281
+    bodies[il] = nx;                                                    // :283
+    acc[il] = na;                                                       // :290
+    if (gout) gout[il] = float4{nx.x, nx.y, nx.z, G * nx.w};
+}
+
 // K2 for the symmetric pass: a body's acceleration is the sum of its resident layers (one per segment of its
 // super-block's chunk list) and its traveler layers (one per ring distance), in ascending layer order.
 template <int R>

@@ -452,7 +452,7 @@ def test_energy_drift_reported_and_small(manifest):
     assert drift < 5 * m["energy_drift"]["f64"] + 1e-6
 
 
-@pytest.mark.parametrize("n,variant", [(65536, 0), (65536, 28), (262144, 0), (262144, 208011), (1048576, 0)])
+@pytest.mark.parametrize("n,variant", [(65536, 0), (65536, 28), (65536, -1), (262144, 0), (262144, 208011), (262144, -1), (1048576, 0)])
 def test_full_size_properties(n, variant):
     """BASELINE.json configs 2, 3 and 4 (N=1,048,576) at full size, through size-independent
     properties (the oracle would take minutes): a sampled i-slice against the
@@ -460,13 +460,19 @@ def test_full_size_properties(n, variant):
     1/8 shard handle equal the full handle's rows).  variant 28 / 208011 pin config 2's
     "LDS tile=256" kernel (the default shape at these sizes streams j through SGPRs)."""
     b, v = (ic.uniform_cube(n, seed=2) if n == 65536 else ic.plummer(n, seed=1))
-    with Simulation(n, force_variant=variant) as sim:
+    from nbody3d_amd import capi
+    # variant 0: the default shape (the symmetric pass at these sizes); -1: the default among the ordered-pair kernels
+    with Simulation(n, force_variant=max(variant, 0), flags=capi.NB_FLAG_NO_SYM if variant < 0 else 0) as sim:
         sim.init(b, v)
         sim.simulate(1, 1e-3, 1.0)
         bb, vv, aa = sim.read()
         name = sim.variant
-    if variant:
+    if variant > 0:
         assert "pk_lds256" in name, name
+    elif variant < 0:
+        assert "sgpr" in name, name
+    else:
+        assert "symw" in name, name
     rows = np.random.default_rng(0).choice(n, 96, replace=False)
     rows.sort()
     b64 = b.astype(np.float64)

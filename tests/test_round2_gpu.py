@@ -346,14 +346,20 @@ def test_integrate_pass_measures_the_integrator_alone():
 
 # ---- the automatic launch shape ----------------------------------------------------------------
 
-@pytest.mark.parametrize("n,family", [(512, "fused_regs"), (1024, "fused_regs"), (2002, "fused_lds"), (4096, "fused_lds"),
-                                      (6000, "fused_lds"), (8192, "fused"), (10000, "fused_jpairs"), (12000, "fused_jpairs"), (13000, "sgpr"), (16384, "sgpr"), (20000, "sgpr"), (32768, "sgpr"),
-                                      (40002, "sgpr"), (65536, "sgpr"), (131072, "sgpr"), (262144, "sgpr_ipl8_ws4"),
-                                      (500010, "sgpr"), (1048576, "sgpr")])
-def test_default_launch_shape_family_by_size(n, family):
-    """choose_shape's pick per system size, as measured best in profiles/r02/size_scan_final_4k_65k.txt: a refit of one
-    model constant once moved N = 12,000 .. 32,768 onto a shape 1-6 % slower without any test noticing."""
+@pytest.mark.parametrize("n,family,classic", [(512, "fused_regs", None), (1024, "fused_regs", None), (2002, "fused_lds", None), (4096, "fused_lds", None),
+                                              (6000, "fused_lds", None), (8192, "fused", None), (10000, "fused_jpairs", None), (12000, "fused_jpairs", None),
+                                              (16384, "symw", "sgpr"), (20000, "symw", "sgpr"), (32768, "symw_ipl16", "sgpr"),
+                                              (40002, "symw_ipl16", "sgpr"), (65536, "symw_ipl16", "sgpr"), (131072, "symw_ipl16", "sgpr"),
+                                              (262144, "symw_ipl16", "sgpr_ipl8_ws4"), (500010, "symw_ipl16", "sgpr"), (1048576, "symw_ipl16", "sgpr")])
+def test_default_launch_shape_family_by_size(n, family, classic):
+    """choose_shape's pick per system size, as measured best (profiles/r02/size_scan_final_4k_65k.txt below N ~ 14,000,
+    profiles/r03/sym_variants_scan_wave_granular*.txt above): from there the symmetric pass; with NB_FLAG_NO_SYM the
+    ordered-pair families of round 2.  (A refit of one model constant once moved N = 12,000 .. 32,768 onto a shape 1-6 %
+    slower without any test noticing.)"""
     with Simulation(n) as s:
         assert family in s.variant, (n, s.variant)
-    with Simulation(n, shard=(0, (n // 2 + 255) // 256 * 256 if n > 512 else n)) as s:      # a rank's shard never fuses
-        assert "fused" not in s.variant, (n, s.variant)
+    if classic:
+        with Simulation(n, flags=capi.NB_FLAG_NO_SYM) as s:
+            assert classic in s.variant and "sym" not in s.variant, (n, s.variant)
+    with Simulation(n, shard=(0, (n // 2 + 255) // 256 * 256 if n > 512 else n)) as s:      # a rank's shard never fuses, nor pairs up symmetrically
+        assert "fused" not in s.variant and "sym" not in s.variant, (n, s.variant)

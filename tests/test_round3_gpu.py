@@ -53,8 +53,9 @@ def galaxy40002():
 
 # default shape; config 2's LDS tile=256 kernel; the SGPR kernel with 8 bodies per lane; the j-packed step with a split;
 # the fused LDS-tile step; the scalar template
-GALAXY_VARIANTS = [(0, 0, None), (28, 0, "pk_lds256"), (308014, 0, "sgpr_ipl8"), (304014, 21, "sgpr_ipl4"),
-                   (601018, 4, "jpairs"), (404324, 0, "fused_lds"), (2, 4, "f32_lds256")]
+GALAXY_VARIANTS = [(0, 0, "symw"), (28, 0, "pk_lds256"), (308014, 0, "sgpr_ipl8"), (304014, 21, "sgpr_ipl4"),
+                   (601018, 4, "jpairs"), (404324, 0, "fused_lds"), (2, 4, "f32_lds256"),
+                   (716013, 2, "symw_ipl16_j1"), (708011, 1, "symw_ipl8_j2"), (708014, 0, "sym_ipl8_ws4")]     # the symmetric pass: default above, pinned forms here
 
 
 @pytest.mark.parametrize("variant,jsplit,family", GALAXY_VARIANTS)
@@ -92,10 +93,11 @@ def test_reference_default_workload_full_size(galaxy40002, variant, jsplit, fami
 
 
 def test_reference_default_workload_step_forms_agree(galaxy40002):
-    """At the reference's G = 1e-4 the default (two-kernel SGPR) step, the j-packed fused step and the LDS-tile kernel
-    differ by summation order only: with every kernel multiplying (G*m_j)*inv per pair they agree as tightly as at G = 1."""
+    """At the reference's G = 1e-4 the two-kernel SGPR step, the j-packed fused step, the LDS-tile kernel and the default
+    (symmetric pass) differ by summation order only: with every kernel multiplying (G*m_j)*inv per pair they agree as tightly
+    as at G = 1."""
     g = galaxy40002
-    outs = [run(g["b"], g["v"], 10, g["dt"], g["G"], force_variant=fv, jsplit=js) for fv, js in ((0, 0), (601018, 4), (28, 0))]
+    outs = [run(g["b"], g["v"], 10, g["dt"], g["G"], force_variant=fv, jsplit=js) for fv, js in ((304014, 21), (601018, 4), (28, 0), (0, 0))]
     for o in outs[1:]:
         assert rel_pos_err(o[0], outs[0][0], 1.0) < 2e-6, (o[3], outs[0][3])
         rel = np.abs(o[2][:, :3] - outs[0][2][:, :3]).max(1) / np.maximum(np.abs(outs[0][2][:, :3]).max(1), 1e-3)
@@ -318,6 +320,9 @@ def test_overlapped_exchange_with_model_chosen_splits_and_virtual_shards(n, g, v
 
 def test_shape_info_of_a_whole_system_handle():
     with Simulation(262144) as s:
+        info = s.shape_info()
+        assert info["jsplit"] >= 1 and info["own_splits"] == 0 and "symw" in s.variant
+    with Simulation(262144, flags=capi.NB_FLAG_NO_SYM) as s:
         info = s.shape_info()
         assert info["jsplit"] >= 1 and info["own_splits"] == 0 and "_js%d" % info["jsplit"] in s.variant
         assert info["j_per_split"] * info["jsplit"] >= 262144

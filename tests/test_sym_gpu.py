@@ -1,0 +1,167 @@
+"""GPU tests of the symmetric force pass (force_variant 7 II 01 X: nb_force_symw / nb_force_sym + their integrate kernels),
+through the C ABI.
+
+The pass evaluates every UNORDERED pair once and accumulates both accelerations (Newton's third law): r = x_j - x_i, r^2, the
+cube and the reciprocal square root are shared, the per-pair products (G m_j) inv r and (G m_i) inv (-r) are the reference's
+(nbody3d.js:233-236).  Checked here: the sums against the fp64 oracle at every kind of size (one super-block pair, ragged N,
+padding rows, odd and even super-block counts, the workgroup form), the golden trajectories, exact momentum conservation
+of the pair sums, determinism (graph replay, restarts, repeated runs), G != 1, and that the default shape picks it.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden32, load_golden64, rel_pos_err
+from oracle import oracle
+from nbody3d_amd import Simulation, capi, ic
+
+pytestmark = pytest.mark.gpu
+
+TOL_ACC, TOL_TIGHT = 2e-5, 2e-5
+
+# (variant, jsplit): wave-granular form with 8 / 16 residents per lane and 1 / 2 travelers per lane, 1-3 waves per SIMD;
+# the workgroup form with its automatic and two pinned segment counts
+SYM_VARIANTS = [(708013, 0), (708013, 2), (708011, 1), (708011, 3), (716013, 0), (716013, 2), (716011, 1), (708014, 0), (708014, 5), (708014, 13)]
+
+
+def run(b, v, steps, dt=1e-3, G=1.0, **kw):
+    with Simulation(b.shape[0], **kw) as sim:
+        sim.init(b, v)
+        sim.simulate(steps, dt, G)
+        return sim.read() + (sim.variant,)
+
+
+@pytest.mark.parametrize("variant,jsplit", SYM_VARIANTS)
+@pytest.mark.parametrize("n", [1025, 2049, 4096, 5000, 8192, 12289, 20001])
+def test_single_step_matches_the_fp64_oracle(variant, jsplit, n):
+    """Sizes that make 2 .. 40 super-blocks, odd and even counts (the even ones have an antipodal partner that only half the
+    super-blocks sweep), N a multiple of the super-block and not (zero-mass padding rows; chunks of padding only are skipped)."""
+    b, v = (ic.plummer(n, seed=81) if n % 2 == 0 else ic.uniform_cube(n, seed=81))
+    bb, vv, aa, name = run(b, v, 1, force_variant=variant, jsplit=jsplit)
+    rows_per_sb = 64 * (variant // 1000 % 100) * (4 if variant % 10 == 4 else 1)
+    if n <= rows_per_sb:
+        assert "sym" not in name, name          # one super-block: nothing to pair up, the ordered-pair kernel runs
+        return
+    assert "sym" in name, name
+    ref = oracle.accel_f64(b, 1.0)
+    assert np.abs(aa[:, :3] - ref[:, :3]).max() < TOL_ACC * np.abs(ref[:, :3]).max(), name
+    assert not aa[:, 3].any() and np.array_equal(bb[:, 3], b[:, 3])
+    b2, v2, _ = oracle.run_f32(b, v, None, 1e-3, 1.0, 1)
+    assert rel_pos_err(bb, b2, 1.0) < 1e-6, name
+
+
+@pytest.mark.parametrize("name,steps", [("plummer1024", 100), ("cube1000", 20), ("disk771", 50), ("galaxy_ref", 30)])
+@pytest.mark.parametrize("variant,jsplit", [(708013, 0), (708011, 2)])
+def test_golden_trajectories(manifest, name, steps, variant, jsplit):
+    """BASELINE config 1 and the ragged / harsh-mass-ratio / G = 1e-4 fixtures (two super-blocks of 512 rows)."""
+    m = manifest[name]
+    b0, v0 = load_golden32(name + "_bodies0"), load_golden32(name + "_vel0")
+    bb, vv, aa, vname = run(b0, v0, steps, dt=m["dt"], G=m["G"], force_variant=variant, jsplit=jsplit)
+    assert "symw" in vname, vname
+    assert rel_pos_err(bb, load_golden64("%s_s%d_bodies" % (name, steps)), m["r_scale"]) < TOL_TIGHT, vname
+    assert rel_pos_err(bb, load_golden32("%s_s%d_bodies" % (name, steps)), m["r_scale"]) < TOL_TIGHT, vname
+    a32 = load_golden32("%s_s%d_accel" % (name, steps))
+    assert np.abs(aa[:, :3] - a32[:, :3]).max() < 1e-4 * np.abs(a32[:, :3]).max()
+
+
+@pytest.mark.parametrize("n,variant", [(16384, 0), (40002, 0), (70001, 716013), (30000, 708014)])
+def test_pair_sums_conserve_momentum_to_rounding(n, variant):
+    """Both accelerations of a pair come from the SAME inv * r: sum m_i a_i is zero up to the rounding of the additions
+    (1e-8 of sum |m_i a_i| here; the ordered-pair kernels, with an independent rsq per direction, sit at 1e-6)."""
+    b, v = ic.plummer(n, seed=82)
+    _, _, aa, name = run(b, v, 1, force_variant=variant)
+    assert "sym" in name, name
+    f = b[:, 3:4].astype(np.float64) * aa[:, :3]
+    assert np.all(np.abs(f.sum(0)) < 2e-8 * np.abs(f).sum(0)), (name, np.abs(f.sum(0)) / np.abs(f).sum(0))
+    _, _, ao, oname = run(b, v, 1, flags=capi.NB_FLAG_NO_SYM)
+    assert "sym" not in oname, oname
+    assert np.abs(aa[:, :3] - ao[:, :3]).max() < 5e-6 * np.abs(ao[:, :3]).max(), (name, oname)
+
+
+@pytest.mark.parametrize("variant,jsplit,n", [(0, 0, 20000), (716013, 2, 9000), (708011, 1, 3000), (708014, 0, 7000)])
+def test_deterministic_across_runs_graphs_restores_and_G(variant, jsplit, n):
+    """No float atomics anywhere: a repeated run, graph replay against single steps, a restore mid-run and a G change
+    (the (x, y, z, G*m) j-stream copy of the padded array) give the same bits."""
+    b, v = ic.plummer(n, seed=83)
+    kw = dict(force_variant=variant, jsplit=jsplit)
+    with Simulation(n, **kw) as a, Simulation(n, **kw) as c:
+        assert "sym" in a.variant, a.variant
+        a.init(b, v)
+        c.init(b, v)
+        for G, k in ((1.0, 19), (0.25, 33), (1.0, 2)):
+            a.simulate(k, 1e-3, G)
+            for _ in range(k):
+                c.step(1e-3, G)
+        for x, y in zip(a.read(), c.read()):
+            assert x.tobytes() == y.tobytes(), a.variant
+        state = a.read()
+        a.simulate(7)
+        a.restore(*state)
+        a.simulate(18)
+        c.simulate(18)
+        got, want = a.read(), c.read()
+        a.request_frame()
+        fb, fs, step = a.frame(wait=True)
+        assert fb.tobytes() == got[0].tobytes()
+        ke, pe, mom = a.diagnostics()
+        name = a.variant
+    for x, y in zip(got, want):
+        assert x.tobytes() == y.tobytes(), name
+    rke, rpe, _ = oracle.energy(got[0], got[1], 1.0)
+    assert abs(ke - rke) < 1e-9 * abs(rke) and abs(pe - rpe) < 1e-6 * abs(rpe)
+    again = run(b, v, 19, **kw)
+    with Simulation(n, **kw) as d:
+        d.init(b, v)
+        d.simulate(19, 1e-3, 1.0)
+        first = d.read()
+    for x, y in zip(again[:3], first):
+        assert x.tobytes() == y.tobytes(), name
+
+
+def test_mid_size_trajectory_against_fp64_oracle():
+    n, steps = 8192, 20
+    b, v = ic.plummer(n, seed=23)
+    bb, vv, aa, name = run(b, v, steps, force_variant=708013)
+    assert "symw" in name, name
+    rb, rv, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, steps)
+    assert rel_pos_err(bb, rb, 1.0) < TOL_TIGHT, name
+    assert np.abs(aa[:, :3] - ra[:, :3]).max() < TOL_ACC * np.abs(ra[:, :3]).max(), name
+
+
+def test_edge_cases_zero_mass_coincident_far_and_custom_eps2():
+    """Bodies that coincide (r = 0: both directions exactly 0, like the self term a body meets in its own super-block),
+    zero-mass tracers, a second cluster so far that r^6 overflows binary32 (rsq(inf) = 0: exactly nothing, no NaN), eps2."""
+    n = 2048
+    b = np.zeros((n, 4), np.float32)
+    b[:700, 3] = 1.0                                        # 700 massive bodies at the origin
+    b[700:1400, 0] = np.linspace(1, 2, 700)                 # massless tracers
+    b[1400:, :3] = np.random.default_rng(1).random((n - 1400, 3)) + 1e7
+    b[1400:, 3] = 1.0
+    v = np.zeros((n, 4), np.float32)
+    bb, vv, aa, name = run(b, v, 1, force_variant=708013)
+    assert "symw" in name and np.isfinite(aa).all() and np.isfinite(bb).all()
+    assert np.all(aa[:700] == 0)
+    ref = oracle.accel_f64(b, 1.0)
+    assert np.allclose(aa[700:1400, :3], ref[700:1400, :3], rtol=2e-5, atol=1e-7)
+    own = oracle.accel_f32(b[1400:].copy(), 1.0)
+    assert np.abs(aa[1400:, :3] - own[:, :3]).max() < TOL_ACC * np.abs(own[:, :3]).max()
+    p, q = ic.plummer(3000, seed=84)
+    for eps2 in (1e-6, 2.5e-3):
+        _, _, a2, nm = run(p, q, 1, force_variant=716013, eps2=eps2)
+        r2 = oracle.accel_f64(p, 1.0, eps2=eps2)
+        assert np.abs(a2[:, :3] - r2[:, :3]).max() < TOL_ACC * np.abs(r2[:, :3]).max(), (nm, eps2)
+    bb, vv, aa, _ = run(p, q, 3, dt=1e-2, G=0.0, force_variant=708013)
+    assert np.all(aa == 0) and vv.tobytes() == q.tobytes()
+
+
+def test_handles_that_cannot_use_the_symmetric_pass_fall_back():
+    n = 16384
+    with Simulation(n, force_variant=716013, shard=(0, 8192)) as s:       # a rank's shard: the other ranks own half of every pair
+        assert "sym" not in s.variant, s.variant
+    with Simulation(n, shard=(0, 8192)) as s:
+        assert "sym" not in s.variant, s.variant
+    with Simulation(n, precision="f64", force_variant=716013) as s:
+        assert s.variant.startswith("f64"), s.variant
+    with Simulation(n, flags=capi.NB_FLAG_NO_SYM) as s:
+        assert "sgpr" in s.variant, s.variant
+    with Simulation(n) as s:
+        assert "symw" in s.variant, s.variant
