@@ -252,9 +252,14 @@ const ModelKnobs& model_knobs()
 
 // The symmetric pass, wave-granular form (nb_force_symw<NG, 1>): predicted step time for n bodies with 2*NG residents per lane
 // and k waves per SIMD.  A chunk-sweep is 64 rotation steps of NG * (16 packed + 2 transcendental) + 10 DPP issue slots; the
-// loop runs at 93.5 % of that (N = 65,536 and 262,144, both forms: profiles/r03/sym_variants_scan_wave_granular.txt).  L
-// chunk-sweeps are cut into W = k * SIMDs equal ranges; one wave per SIMD leaves ~1 % on the table (k = 1: 82.5 %, k = 2: 83.3 %
-// at N = 262,144) but halves the rounding loss of ceil(L / W) at mid sizes (N = 40,002: 270 us with k = 1, 283 us with k = 2).
+// loop runs at 93.5 % of that.  The L chunk-sweeps are cut into W = k * SIMDs equal ranges:
+//   k = 1: ceil(L / SIMDs) sweeps per SIMD, 1.9 % slower per sweep (nothing hides a chunk's traveler loads);
+//   k = 2: the two ranges of a SIMD rarely both round up: L / SIMDs + 0.5 sweeps on average, 1 % over the bare rate;
+//   + 3.5 us of kernel fixed cost, 1.5 us per super-block a range touches, the K1 -> K2 boundary and K2's layer traffic
+//   (12 B per layer and body at ~5 TB/s: the layers are Infinity-Cache resident).  16 residents per lane run ~1.5 % closer to
+//   their issue count than 8 (half the rotations per pair).
+// Fitted on profiles/r03/sym_variants_scan_wave_granular*.txt (N = 12,000 .. 262,144, both resident counts: within 2 %);
+// k = 3 measured behind k = 2 (N = 131,072: 2,682 vs 2,615 us).
 struct SymChoice { int ipl; uint32_t k; double t; };
 SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary)
 {
@@ -266,14 +271,14 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary)
         const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
         const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (uint64_t)(H + 1) * cps;
         const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo;
-        const double t_chunk = 64.0 * (80.0 * NG + 40.0) / 0.935 / clock;
-        for (uint32_t k = 1; k <= 4; ++k) {
-            const uint64_t W = (uint64_t)4 * n_cu * k;
-            if (W > L) break;
-            const double per_wave = (double)((L + W - 1) / W);
-            const double segs = per_wave / (double)total_lo + 1.0;             // super-blocks a wave's range touches
-            const double layers = (double)(H + 1) + (double)total_hi / ((double)L / (double)W) + 1.0;     // traveler + resident layers K2 reads per body
-            const double t = per_wave * k * t_chunk / (k == 1 ? 0.99 : 1.0) + segs * k * 1.5e-6 + boundary + layers * n * 12.0 / 2.0e12;
+        const double t_chunk = 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.95 : 0.935) / clock;
+        const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
+        if (per_simd < 1.0) continue;
+        for (uint32_t k = 1; k <= 2; ++k) {
+            const double sweeps = k == 1 ? std::ceil(per_simd) * 1.019 : (per_simd + 0.5) * 1.01;
+            const double segs = per_simd / k / (double)total_lo + 1.0;             // super-blocks a wave's range touches
+            const double layers = (double)(H + 1) + (double)total_hi * k / per_simd + 1.0;     // traveler + resident layers K2 reads per body
+            const double t = sweeps * t_chunk + 3.5e-6 + segs * 1.5e-6 + boundary + layers * n * 12.0 / 5.0e12;
             if (t < best.t) best = {ipl, k, t};
         }
     }
@@ -460,7 +465,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
         // ordered-pair shape above (N = 16,384: 61.7 vs 65.7 us, 40,002: 270 vs 357 us, 262,144: 10.5 vs 14.6 ms)
         if (!pinned && whole && !s->f64 && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
             const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary);
-            if (sc2.ipl && sc2.t < (pick ? pick->t : best_t)) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; }
+            if (sc2.ipl && sc2.t < 0.98 * (pick ? pick->t : best_t)) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; }     // a clear win only: both estimates are good to ~3 %
         }
     }
     if (js < 1) {   // pinned shape outside the model's candidate list: fill ~4096 workgroups
