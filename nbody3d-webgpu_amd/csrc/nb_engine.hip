@@ -144,7 +144,8 @@ const void* kernel_of(bool f64, const Shape& sh)
             return sh.x == 1 ? (const void*)&nb::nb_step_direct<16> : sh.x == 2 ? (const void*)&nb::nb_step_direct<32> : nullptr;
         case kSym:       // ipl = residents per lane (8 or 16); x = 1 / 3: wave-granular form with 2 / 1 travelers per lane,
                          // x = 4: workgroup form (4 waves, 8 residents per lane)
-            if (f64 || sh.ls != 1) return nullptr;
+            if (sh.ls != 1) return nullptr;
+            if (f64) return sh.ipl == 8 && sh.x == 3 ? (const void*)&nb::nb_force_symw64<8> : nullptr;      // 8 residents, 1 traveler per lane
             if (sh.x == 4) return sh.ipl == 8 ? (const void*)&nb::nb_force_sym<4, 4, 2> : nullptr;
             if (sh.ipl == 8) return sh.x == 1 ? (const void*)&nb::nb_force_symw<4, 2> : sh.x == 3 ? (const void*)&nb::nb_force_symw<4, 1> : nullptr;
             if (sh.ipl == 16) return sh.x == 1 ? (const void*)&nb::nb_force_symw<8, 2> : sh.x == 3 ? (const void*)&nb::nb_force_symw<8, 1> : nullptr;
@@ -203,7 +204,7 @@ void name_variant(nb_sim* s, const Shape& sh)
     else if (sh.kind == kJpk)
         snprintf(buf, sizeof buf, "f32pk_fused_jpairs_ws%d_js%u", jpk_ws(sh.x), s->jsplit);
     else if (sh.kind == kSym)
-        snprintf(buf, sizeof buf, s->symw ? "f32pk_symw_ipl%d_j%d_w%u_r%ut%u" : "f32pk_sym_ipl%d_ws%d_q%u_r%ut%u", sh.ipl, s->symw ? (sh.x == 3 ? 1 : 2) : sh.x,
+        snprintf(buf, sizeof buf, s->f64 ? "f64_symw_ipl%d_j%d_w%u_r%ut%u" : s->symw ? "f32pk_symw_ipl%d_j%d_w%u_r%ut%u" : "f32pk_sym_ipl%d_ws%d_q%u_r%ut%u", sh.ipl, s->symw ? (sh.x == 3 ? 1 : 2) : sh.x,
                  s->sym_plan[2], s->sym_plan[8] - s->sym_plan[7], s->sym_layers - (s->sym_plan[8] - s->sym_plan[7]));     // words 7, 8: r_layer0, t_layer0 in both plans
     else
         snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.kind == kPkLds ? "pk" : "",
@@ -261,24 +262,26 @@ const ModelKnobs& model_knobs()
 // Fitted on profiles/r03/sym_variants_scan_wave_granular*.txt (N = 12,000 .. 262,144, both resident counts: within 2 %);
 // k = 3 measured behind k = 2 (N = 131,072: 2,682 vs 2,615 us).
 struct SymChoice { int ipl; uint32_t k; double t; };
-SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary)
+SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64)
 {
     SymChoice best{0, 0, 1e300};
     for (int ipl : {8, 16}) {
+        if (f64 && ipl != 8) continue;              // nb_force_symw64<8>: 8 residents per lane, 19 DP instructions + v_rsq_f64 per pair
         const uint32_t NG = (uint32_t)ipl / 2, S = 64u * (uint32_t)ipl, cps = S / 64u;
         const uint32_t nsb = ceil_div(n, S);
         if (nsb < 4) continue;
         const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
         const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (uint64_t)(H + 1) * cps;
         const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo;
-        const double t_chunk = 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.95 : 0.935) / clock;
+        // f64: 92 issue cycles per resident and step + 14 DPP; the loop runs at 96 % of that (N = 262,144: 23.7 ms, profiles/r03/sym_f64_first.txt)
+        const double t_chunk = f64 ? 64.0 * (92.0 * ipl + 56.0) / 0.96 / clock : 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.95 : 0.935) / clock;
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
         if (per_simd < 1.0) continue;
         for (uint32_t k = 1; k <= 2; ++k) {
             const double sweeps = k == 1 ? std::ceil(per_simd) * 1.019 : (per_simd + 0.5) * 1.01;
             const double segs = per_simd / k / (double)total_lo + 1.0;             // super-blocks a wave's range touches
             const double layers = (double)(H + 1) + (double)total_hi * k / per_simd + 1.0;     // traveler + resident layers K2 reads per body
-            const double t = sweeps * t_chunk + 3.5e-6 + segs * 1.5e-6 + boundary + layers * n * 12.0 / 5.0e12;
+            const double t = sweeps * t_chunk + 3.5e-6 + segs * 1.5e-6 + boundary + layers * n * (f64 ? 24.0 : 12.0) / 5.0e12;
             if (t < best.t) best = {ipl, k, t};
         }
     }
@@ -336,11 +339,12 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
     if (variant != 0) {
         Shape want;
         if (decode_variant(variant, &want)) {
-            if (s->f64 && want.kind != kScalar) want = {kScalar, want.ipl > 4 ? 4 : want.ipl, 1, 1};
+            if (s->f64 && want.kind != kScalar && want.kind != kSym) want = {kScalar, want.ipl > 4 ? 4 : want.ipl, 1, 1};
             if ((want.kind == kFused || want.kind == kDirect) && !may_fuse && !s->f64) want = {kPkLds, want.ipl, want.ls, 1};   // same loop, two kernels
             if (want.kind == kDirect && n > 1024u * (uint32_t)want.x) want = {kFused, 2, 64, 4};
             if (want.kind == kJpk && !may_fuse) want = {kPkSgpr, 4, 1, 4};      // whole-system f32 handles only
-            if (want.kind == kSym && (!whole || s->f64 || cfg.ext_bodies || !kernel_of(false, want) || n <= ipb_of(want))) want = {kPkSgpr, 8, 1, 4};   // likewise; >= 2 super-blocks
+            if (want.kind == kSym && (!whole || cfg.ext_bodies || !kernel_of(s->f64, want) || n <= ipb_of(want)))       // likewise; >= 2 super-blocks
+                want = s->f64 ? Shape{kScalar, 4, 1, 1} : Shape{kPkSgpr, 8, 1, 4};
             if (kernel_of(s->f64, want)) { sh = want; pinned = true; }
         }
     }
@@ -463,8 +467,8 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
         if (pick) { if (!pinned) sh = pick->sh; js = pick->q; }
         // the symmetric pass (whole-system f32 handles; every unordered pair once): from N ~ 14,000 up it beats every
         // ordered-pair shape above (N = 16,384: 61.7 vs 65.7 us, 40,002: 270 vs 357 us, 262,144: 10.5 vs 14.6 ms)
-        if (!pinned && whole && !s->f64 && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
-            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary);
+        if (!pinned && whole && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
+            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, s->f64);
             if (sc2.ipl && sc2.t < 0.98 * (pick ? pick->t : best_t)) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; }     // a clear win only: both estimates are good to ~3 %
         }
     }
@@ -508,7 +512,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
         static_assert(sizeof(pl) <= sizeof(s->sym_plan), "nb_sim::sym_plan holds a SymWPlan");
         memcpy(s->sym_plan, &pl, sizeof pl);
         s->sym = true; s->symw = true; s->sym_np = pl.np; s->sym_layers = max_r + H + (n_hi ? 1u : 0u);
-        s->ipl = sh.ipl; s->ls = 1; s->packed = true; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
+        s->ipl = sh.ipl; s->ls = 1; s->packed = !s->f64; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
         s->ws = sh.x; s->tl = 1;
         s->jsplit = max_r; s->j_per_split = ceil_div(pl.L, pl.W) * 64u * J; s->swap_acc = false; s->own_split0 = 0; s->own_splits = 0;
         name_variant(s, sh);
@@ -633,13 +637,19 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
     if (s->symw) {
         nb::SymWPlan pl;
         memcpy(&pl, s->sym_plan, sizeof pl);
-        const float4* b = (const float4*)jstream(s, s->cur);
-        nb::SymRow* p = (nb::SymRow*)s->partial;
+        const void* b = jstream(s, s->cur);                // f32: rows (x, y, z, G*m); f64: (x, y, z, m) and G
+        void* p = s->partial;
         const uint32_t* tab = s->sym_tab;
-        float e2 = (float)s->eps2;
         uint32_t n = s->n;
-        void* args[] = {&b, &p, &tab, &pl, &n, &e2};
-        launch_kernel(kernel_of(false, sh), dim3(ceil_div(pl.W, 4u)), dim3(256), args, s->stream, t0, t1);
+        if (s->f64) {
+            double G = s->G, e2 = s->eps2;
+            void* args[] = {&b, &p, &tab, &pl, &n, &G, &e2};
+            launch_kernel(kernel_of(true, sh), dim3(ceil_div(pl.W, 4u)), dim3(256), args, s->stream, t0, t1);
+        } else {
+            float e2 = (float)s->eps2;
+            void* args[] = {&b, &p, &tab, &pl, &n, &e2};
+            launch_kernel(kernel_of(false, sh), dim3(ceil_div(pl.W, 4u)), dim3(256), args, s->stream, t0, t1);
+        }
         return;
     }
     if (s->sym) {
@@ -725,17 +735,14 @@ void launch_integrate(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullpt
     // the j-stream rows of the new positions; a handle whose rows are exchanged rebuilds the whole copy after the gather instead
     V4* gout = gm_active(s) && !(s->xfn || s->rccl) ? (V4*)s->gm[s->cur] : nullptr;
     if (s->symw) {
-        if constexpr (std::is_same<T, float>::value) {
-            nb::SymWPlan pl;
-            memcpy(&pl, s->sym_plan, sizeof pl);
-            float4 *bb = (float4*)b, *vv = (float4*)v, *aa = (float4*)s->acc, *gg = (float4*)gout;
-            const nb::SymRow* pp = (const nb::SymRow*)s->partial;
-            const uint32_t* tab = s->sym_tab;
-            uint32_t n = s->n, S = ipb_of(shape_of(s));
-            float fdt = (float)s->dt, fG = (float)s->G;
-            void* args[] = {&bb, &vv, &aa, &pp, &tab, &n, &pl, &S, &fdt, &gg, &fG};
-            launch_kernel((const void*)&nb::nb_integrate_symw<8>, dim3(ceil_div(n * 8u, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
-        }
+        nb::SymWPlan pl;
+        memcpy(&pl, s->sym_plan, sizeof pl);
+        V4* aa = (V4*)s->acc;
+        const nb::SymRowT<T>* pp = (const nb::SymRowT<T>*)s->partial;
+        const uint32_t* tab = s->sym_tab;
+        uint32_t n = s->n, S = ipb_of(shape_of(s));
+        void* args[] = {&b, &v, &aa, &pp, &tab, &n, &pl, &S, &dt, &gout, &G};
+        launch_kernel((const void*)&nb::nb_integrate_symw<T, 8>, dim3(ceil_div(n * 8u, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
         return;
     }
     if (s->sym) {
@@ -943,7 +950,7 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     NB_HIPC(hipMalloc(&s->vel, row * s->sc));
     NB_HIPC(hipMalloc(&s->acc, row * s->sc));
     if (s->sym) {
-        NB_HIPC(hipMalloc(&s->partial, (size_t)12 * s->sym_np * s->sym_layers));       // layers of 12-byte (x, y, z) rows
+        NB_HIPC(hipMalloc(&s->partial, (size_t)3 * s->esz * s->sym_np * s->sym_layers));       // layers of (x, y, z) rows: 12 bytes (24 in f64)
         if (s->symw) {
             NB_HIPC(hipMalloc((void**)&s->sym_tab, sizeof(uint32_t) * s->sym_tab_host.size()));
             NB_HIPC(hipMemcpy(s->sym_tab, s->sym_tab_host.data(), sizeof(uint32_t) * s->sym_tab_host.size(), hipMemcpyHostToDevice));
@@ -1223,7 +1230,7 @@ int nb_integrate_pass(nb_sim* s, uint32_t reps, double* avg_ms)
     const double dt = s->dt > 0 ? s->dt : 1e-3;
     const double keep = s->dt;
     s->dt = dt;
-    if (s->steps_done == 0) NB_HIP(s, hipMemsetAsync(s->partial, 0, s->sym ? (size_t)12 * s->sym_np * s->sym_layers : 4 * s->esz * s->sc * s->jsplit, s->stream));
+    if (s->steps_done == 0) NB_HIP(s, hipMemsetAsync(s->partial, 0, s->sym ? (size_t)3 * s->esz * s->sym_np * s->sym_layers : 4 * s->esz * s->sc * s->jsplit, s->stream));
     hipEvent_t e0, e1;
     NB_HIP(s, hipEventCreate(&e0));
     NB_HIP(s, hipEventCreate(&e1));

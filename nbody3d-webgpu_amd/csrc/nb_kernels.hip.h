@@ -1036,7 +1036,8 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
 //     nb_integrate_sym adds a body's layers in ascending order: deterministic, no float atomics.  A partial row is
 //     12 bytes (x, y, z: one global_store_dwordx3 per lane): the layers are the pass's memory traffic.
 // Rows [n, np) of `bodies` are zero-mass bodies at the origin (np = nsb * S).
-struct SymRow { float x, y, z; };   // 12-byte partial row (an ext_vector_type(3) would be padded to 16)
+template <typename T> struct SymRowT { T x, y, z; };   // a partial row: 12 bytes in f32 (an ext_vector_type(3) would be padded to 16), 24 in f64
+using SymRow = SymRowT<float>;
 struct SymPlan {
     uint32_t np, nsb;          // padded rows, super-blocks
     uint32_t q;                // segments per super-block's chunk list (workgroups per super-block)
@@ -1323,16 +1324,106 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
     }
 }
 
-// K2 for the wave-granular form: resident layers gtab[2g+1] (waves that worked on g's list), then the traveler layers.
-template <int R>
-__global__ __launch_bounds__(kBlock) void nb_integrate_symw(float4* __restrict__ bodies, float4* __restrict__ vel, float4* __restrict__ acc,
-                                                           const SymRow* __restrict__ partial, const uint32_t* __restrict__ gtab, uint32_t n,
-                                                           const SymWPlan pl, uint32_t S, float dt, float4* __restrict__ gout, float G)
+// The fp64 form (BASELINE config 5): non-packed, IPL residents per lane, one traveler per lane.  Per unordered pair: 3 adds,
+// 3 fma (r^2 + eps2), v_rsq_f64 + first-order correction as in pair(double...) -- y = rsq(d2), e = 1 - d2 y^2,
+// u = y^3 (1 + 3e/2) -- then (G m_t) u and (G m_i) u and six fma: 19 DP instructions + the seed for TWO interactions where
+// nb_force<double,...> spends 15 + the seed on one; 14 v_mov_b32_dpp per traveler and step rotate the seven doubles.
+__device__ __forceinline__ double wave_rot1(double v)
 {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    const unsigned rlo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xF, 0xF, false);
+    const unsigned rhi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)rhi << 32) | rlo));
+}
+
+template <int IPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __restrict__ partial, const uint32_t* __restrict__ gtab,
+                     const SymWPlan pl, const uint32_t n, const double G, const double eps2)
+{
+    constexpr uint32_t S = 64u * IPL, CH = 64u, CPS = S / CH;
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (w >= pl.W) return;
+    uint32_t p = (uint32_t)(((uint64_t)w * pl.L) / pl.W);
+    const uint32_t pend = (uint32_t)(((uint64_t)(w + 1) * pl.L) / pl.W);
+    const uint32_t first_lo = pl.n_hi * pl.total_hi;
+    while (p < pend) {
+        uint32_t g, k, total;
+        if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
+        else { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
+        const uint32_t ring = total - CPS;
+        uint32_t kend = k + (pend - p);
+        if (kend > total) kend = total;
+        p += kend - k;
+        double xi[IPL], yi[IPL], zi[IPL], mi[IPL], ax[IPL], ay[IPL], az[IPL];
+#pragma unroll
+        for (int c = 0; c < IPL; ++c) {
+            const double4 b = ld4(bodies + (size_t)g * S + c * 64 + lane);
+            xi[c] = b.x; yi[c] = b.y; zi[c] = b.z; mi[c] = b.w * G;
+            ax[c] = 0; ay[c] = 0; az[c] = 0;
+        }
+        for (; k < kend; ++k) {
+            const bool sym = k < ring;
+            const uint32_t d = k / CPS;
+            uint32_t tb = g + 1 + d;
+            if (tb >= pl.nsb) tb -= pl.nsb;
+            const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
+            if (tstart >= n) continue;
+            const double4 t = ld4(bodies + tstart + lane);
+            double tx = t.x, ty = t.y, tz = t.z, tm = t.w * G, bx = 0, by = 0, bz = 0;
+            for (int st = 0; st < 64; ++st) {
+#pragma unroll
+                for (int c0g = 0; c0g < IPL; c0g += 4) {             // stage-major over four residents
+                    double dx[4], dy[4], dz[4], d2[4], y[4], u[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dx[c] = tx - xi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dy[c] = ty - yi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dz[c] = tz - zi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) d2[c] = nb_fma(dz[c], dz[c], nb_fma(dy[c], dy[c], nb_fma(dx[c], dx[c], eps2)));
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) y[c] = __builtin_amdgcn_rsq(d2[c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double y2 = y[c] * y[c];
+                        const double e = nb_fma(-d2[c], y2, 1.0);
+                        const double t3 = y[c] * y2;
+                        u[c] = nb_fma(t3 * e, 1.5, t3);
+                    }
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const double si = tm * u[c], sj = mi[c0g + c] * u[c];
+                        ax[c0g + c] = nb_fma(si, dx[c], ax[c0g + c]); ay[c0g + c] = nb_fma(si, dy[c], ay[c0g + c]); az[c0g + c] = nb_fma(si, dz[c], az[c0g + c]);
+                        bx = nb_fma(-sj, dx[c], bx); by = nb_fma(-sj, dy[c], by); bz = nb_fma(-sj, dz[c], bz);
+                    }
+                }
+                tx = wave_rot1(tx); ty = wave_rot1(ty); tz = wave_rot1(tz); tm = wave_rot1(tm);
+                bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz);
+            }
+            if (sym) partial[(size_t)(pl.t_layer0 + d) * pl.np + tstart + lane] = SymRowT<double>{bx, by, bz};
+        }
+        SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + (w - gtab[2 * g])) * pl.np + (size_t)g * S + lane;
+#pragma unroll
+        for (int c = 0; c < IPL; ++c) out[c * 64] = SymRowT<double>{ax[c], ay[c], az[c]};
+    }
+}
+
+// K2 for the wave-granular form: resident layers gtab[2g+1] (waves that worked on g's list), then the traveler layers.
+template <typename T, int R>
+__global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::type* __restrict__ bodies, typename vec4<T>::type* __restrict__ vel,
+                                                           typename vec4<T>::type* __restrict__ acc, const SymRowT<T>* __restrict__ partial,
+                                                           const uint32_t* __restrict__ gtab, uint32_t n, const SymWPlan pl, uint32_t S, T dt,
+                                                           typename vec4<T>::type* __restrict__ gout, T G)
+{
+    using V4 = typename vec4<T>::type;
     const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t il = gid / R, r = gid % R;
     const bool valid = il < n;
-    float sx = 0, sy = 0, sz = 0;
+    T sx = 0, sy = 0, sz = 0;
     if (valid) {
         const uint32_t b = il / S;
         const uint32_t nr = gtab[2 * b + 1];
@@ -1341,14 +1432,14 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(float4* __restrict__
         auto row = [&](uint32_t e) { return partial + (size_t)(e < nr ? pl.r_layer0 + e : pl.t_layer0 + (e - nr)) * pl.np + il; };
         uint32_t e = r;
         for (; e + 3 * R < total; e += 4 * R) {
-            const SymRow p0 = *row(e), p1 = *row(e + R), p2 = *row(e + 2 * R), p3 = *row(e + 3 * R);
+            const SymRowT<T> p0 = *row(e), p1 = *row(e + R), p2 = *row(e + 2 * R), p3 = *row(e + 3 * R);
             sx += p0.x; sy += p0.y; sz += p0.z;
             sx += p1.x; sy += p1.y; sz += p1.z;
             sx += p2.x; sy += p2.y; sz += p2.z;
             sx += p3.x; sy += p3.y; sz += p3.z;
         }
         for (; e < total; e += R) {
-            const SymRow p0 = *row(e);
+            const SymRowT<T> p0 = *row(e);
             sx += p0.x; sy += p0.y; sz += p0.z;
         }
     }
@@ -1361,12 +1452,12 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(float4* __restrict__
         }
     }
     if (!valid || r != 0) return;
-    float4 nx, nv, na;
-    leapfrog<float>(ld4(bodies + il), ld4(vel + il), ld4(acc + il), sx, sy, sz, dt, nx, nv, na);
+    V4 nx, nv, na;
+    leapfrog<T>(ld4(bodies + il), ld4(vel + il), ld4(acc + il), sx, sy, sz, dt, nx, nv, na);
     vel[il] = nv;                                                       // :281
     bodies[il] = nx;                                                    // :283
     acc[il] = na;                                                       // :290
-    if (gout) gout[il] = float4{nx.x, nx.y, nx.z, G * nx.w};
+    if (gout) gout[il] = V4{nx.x, nx.y, nx.z, G * nx.w};
 }
 
 // K2 for the symmetric pass: a body's acceleration is the sum of its resident layers (one per segment of its

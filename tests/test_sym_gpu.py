@@ -165,3 +165,47 @@ def test_handles_that_cannot_use_the_symmetric_pass_fall_back():
         assert "sgpr" in s.variant, s.variant
     with Simulation(n) as s:
         assert "symw" in s.variant, s.variant
+
+
+# ---- fp64 (BASELINE config 5) ---------------------------------------------------------------------
+
+@pytest.mark.parametrize("n,jsplit", [(1025, 0), (2049, 1), (5000, 2), (8192, 0), (12289, 1), (20001, 2)])
+def test_f64_single_step_matches_the_fp64_oracle(n, jsplit):
+    """nb_force_symw64: 1e-12 against the fp64 oracle (the per-pair arithmetic is nb_force<double,...>'s -- v_rsq_f64 seed +
+    first-order correction -- evaluated once per unordered pair), momentum of the pair sums at 1e-15."""
+    b, v = ic.plummer(n, seed=85) if n % 2 == 0 else ic.uniform_cube(n, seed=85)
+    b, v = b.astype(np.float64), v.astype(np.float64)
+    bb, vv, aa, name = run(b, v, 1, precision="f64", force_variant=708013, jsplit=jsplit)
+    assert name.startswith("f64_symw"), name
+    ref = oracle.accel_f64(b, 1.0)
+    assert np.abs(aa[:, :3] - ref[:, :3]).max() < 1e-12 * np.abs(ref[:, :3]).max(), name
+    rb, rv, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 1)
+    assert rel_pos_err(bb, rb, 1.0) < 1e-12, name
+    f = b[:, 3:4] * aa[:, :3]
+    assert np.all(np.abs(f.sum(0)) < 1e-14 * np.abs(f).sum(0)), name
+
+
+@pytest.mark.parametrize("name,steps", [("plummer1024", 100), ("galaxy_ref", 30), ("disk771", 50)])
+def test_f64_golden_trajectories(manifest, name, steps):
+    m = manifest[name]
+    b0 = load_golden32(name + "_bodies0").astype(np.float64)
+    v0 = load_golden32(name + "_vel0").astype(np.float64)
+    bb, vv, aa, vname = run(b0, v0, steps, dt=m["dt"], G=m["G"], precision="f64", force_variant=708013, jsplit=1)
+    assert vname.startswith("f64_symw"), vname
+    assert rel_pos_err(bb, load_golden64("%s_s%d_bodies" % (name, steps)), m["r_scale"]) < 1e-12, vname
+
+
+def test_f64_default_shape_and_determinism():
+    n = 20000
+    b, v = ic.plummer(n, seed=86)
+    b, v = b.astype(np.float64), v.astype(np.float64)
+    x = run(b, v, 21, precision="f64")
+    y = run(b, v, 21, precision="f64")
+    assert x[3].startswith("f64_symw"), x[3]
+    for p, q in zip(x[:3], y[:3]):
+        assert p.tobytes() == q.tobytes()
+    z = run(b, v, 21, precision="f64", flags=capi.NB_FLAG_NO_SYM)
+    assert z[3].startswith("f64_lds"), z[3]
+    assert rel_pos_err(x[0], z[0], 1.0) < 1e-12
+    with Simulation(4096, precision="f64") as s:
+        assert s.variant.startswith("f64_lds"), s.variant          # small systems keep the ordered-pair kernel
