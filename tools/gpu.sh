@@ -19,7 +19,7 @@ while [ $# -gt 0 ]; do
            step size_scan 900 python tools/size_scan.py "${args[@]}"; cat gpurun_out/size_scan.txt ;;
     shapes) args=(); while [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; do args+=("$1"); shift; done
            step shape_scan 1000 python tools/shape_scan.py "${args[@]}"; grep -c . gpurun_out/shape_scan.txt ;;
-    prof)  bash tools/gpu_prof.sh ;;
+    prof)  tag=$1; shift; pargs=(); while [ $# -gt 0 ] && [[ $1 == --* ]]; do pargs+=("$1" "$2"); shift 2; done; bash tools/gpu_prof.sh "$tag" "${pargs[@]}" ;;
     py)    script=$1; shift; step "$(basename "$script" .py)" 900 python "$script"; tail -40 "gpurun_out/$(basename "$script" .py).txt" ;;
     *) echo "unknown leg $leg"; exit 2 ;;
   esac
