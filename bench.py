@@ -361,7 +361,8 @@ def main():
         local_rank = 0          # every rank shares device 0 (1-GPU development box)
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1 or args.force_dist:
+    dist_wanted = world > 1 or args.force_dist
+    if dist_wanted:
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:      # --force-dist without a launcher: a free port, not a fixed one
             with socket.socket() as sk:
@@ -377,7 +378,10 @@ def main():
     G, dt = 1.0, 1e-3
     bodies, vel = (ic.plummer(n, seed=1) if args.workload == "plummer" else ic.uniform_cube(n, seed=2))
     np_dtype = np.float64 if args.precision == "f64" else np.float32
-    plan = ShardPlan(n, world, rank)
+    # native exchange, f32: rows in whole super-blocks of 1,024, so that the ranks can take the rank form of the symmetric force
+    # pass (NB_FLAG_SYM_SHARD: each unordered pair evaluated by ONE rank, partial accelerations reduce-scattered by the engine)
+    sym_shard = dist_wanted and args.exchange == "native" and args.precision == "f32" and not args.variant and not (args.flags & capi.NB_FLAG_NO_SYM)
+    plan = ShardPlan(n, world, rank, align=1024 if sym_shard else 256)
     bodies_p, vel_p = plan.pad(bodies.astype(np_dtype)), plan.pad(vel.astype(np_dtype))
 
     overlap = args.overlap or os.environ.get("NB_OVERLAP") == "1"
@@ -401,7 +405,8 @@ def main():
             why = None
             try:
                 my_uid = capi.rccl_unique_id()          # loads librccl on EVERY rank (rank 0's id is the one used)
-                sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count), **kw)
+                sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count),
+                                 **dict(kw, flags=kw["flags"] | (capi.NB_FLAG_SYM_SHARD if sym_shard else 0)))
                 if plan.padded_n != world * plan.count or plan.begin != rank * plan.count:
                     raise RuntimeError("partition is not nranks equal row blocks")
             except Exception as e:
@@ -422,12 +427,13 @@ def main():
             if why is None:
                 nr, rk, ver = sim.rccl_info()
                 shp = sim.shape_info()
-                exchange = {"kind": "rccl-native in-place ncclAllGather on the engine stream" +
-                                    (" (overlapped: own-row force work first)" if overlap else ""),
+                exchange = {"kind": ("rccl-native: in-place ncclReduceScatter of the partial accelerations (rank form of the symmetric pass) + "
+                                     if "symwrank" in sim.variant else "rccl-native ") + "in-place ncclAllGather of the positions on the engine stream" +
+                                    (" (overlapped: own-row force work first)" if overlap and "symwrank" not in sim.variant else ""),
                             "rccl_nranks": nr, "rccl_rank": rk, "rccl_version": ver,
                             "overlap_requested": bool(overlap),
                             # the overlapped form only hides the gather when some j-partitions lie inside the rank's own rows
-                            "overlap_engaged": bool(overlap and shp["own_splits"] > 0),
+                            "overlap_engaged": bool(overlap and shp["own_splits"] > 0 and "symwrank" not in sim.variant),
                             "own_splits": shp["own_splits"], "jsplit": shp["jsplit"]}
             else:                      # keep the run alive on torch's collective -- every rank together -- and say so
                 if sim is not None:

@@ -74,6 +74,14 @@ typedef enum nb_precision { NB_F32 = 0, NB_F64 = 1 } nb_precision;
 #define NB_FLAG_NO_SYM 64u     /* tuning/A-B: never pick the symmetric force pass (K = 7: each unordered pair once, both
                                   accelerations), i.e. keep the ordered-pair kernels of ABI 2 at every size */
 
+#define NB_FLAG_SYM_SHARD 128u  /* a SHARD handle (shard_count != 0) may take the rank form of the symmetric force pass: the rank
+                                  sweeps the pair lists of its own rows only -- every unordered pair of the system is evaluated
+                                  by exactly one rank -- and the ranks reduce-scatter their partial accelerations before the
+                                  integrate kernel.  The reduce-scatter is the engine's own (nb_rccl_attach: in-place
+                                  ncclReduceScatter; nb_multi sets this flag itself): nb_step fails with NB_ERR_STATE on such a
+                                  handle until a communicator is attached.  Needs shard rows that are whole super-blocks
+                                  (shard_begin, shard_count and n multiples of 1,024, or of 512); ignored otherwise */
+
 /* nb_array: selector for nb_device_ptr */
 typedef enum nb_array { NB_BODIES = 0, NB_VEL = 1, NB_ACCEL = 2 } nb_array;
 

@@ -39,6 +39,7 @@ struct RcclApi {
     decltype(&ncclCommCount) CommCount = nullptr;
     decltype(&ncclCommUserRank) CommUserRank = nullptr;
     decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclReduceScatter) ReduceScatter = nullptr;
     decltype(&ncclGroupStart) GroupStart = nullptr;
     decltype(&ncclGroupEnd) GroupEnd = nullptr;
     decltype(&ncclGetErrorString) GetErrorString = nullptr;
@@ -80,7 +81,7 @@ void load_rccl_once()
     if (!a.field) { a.error = std::string("missing symbol ") + name + " in " + a.path; a.lib = nullptr; return; }
     NB_SYM(GetUniqueId, "ncclGetUniqueId") NB_SYM(CommInitRank, "ncclCommInitRank") NB_SYM(CommInitAll, "ncclCommInitAll")
     NB_SYM(CommDestroy, "ncclCommDestroy") NB_SYM(CommCount, "ncclCommCount") NB_SYM(CommUserRank, "ncclCommUserRank")
-    NB_SYM(AllGather, "ncclAllGather") NB_SYM(GroupStart, "ncclGroupStart") NB_SYM(GroupEnd, "ncclGroupEnd")
+    NB_SYM(AllGather, "ncclAllGather") NB_SYM(ReduceScatter, "ncclReduceScatter") NB_SYM(GroupStart, "ncclGroupStart") NB_SYM(GroupEnd, "ncclGroupEnd")
     NB_SYM(GetErrorString, "ncclGetErrorString") NB_SYM(GetVersion, "ncclGetVersion")
 #undef NB_SYM
     (void)a.GetVersion(&a.version);
@@ -135,6 +136,21 @@ int rccl_exchange_begin(nb_sim* s)
         const hipError_t e = hipEventRecord(c->ev_done, c->stream);
         if (e != hipSuccess) return fail(s, NB_ERR_HIP, std::string("rccl_exchange_begin: ") + hipGetErrorString(e));
     }
+    return NB_OK;
+}
+
+// Rank form of the symmetric pass: sym_A holds this rank's sums for every row of the system; in place, rank r receives the
+// sum over all ranks of rows [r * rows, (r + 1) * rows) at that position of its own array (recv = send + rank * count, the
+// in-place form RCCL documents for ncclReduceScatter).  On the engine stream: ordered after nb_sym_reduce, before the integrate kernel.
+int rccl_reduce_scatter_A(nb_sim* s)
+{
+    nb_rccl* c = s->rccl;
+    const RcclApi* api = rccl_api(nullptr);
+    if (!c || !api) return fail(s, NB_ERR_COMM, "rccl_reduce_scatter_A: no communicator");
+    float* A = (float*)s->sym_A;
+    const size_t count = (size_t)4 * s->sc;
+    const ncclResult_t r = api->ReduceScatter(A, A + (size_t)4 * s->sb, count, ncclFloat, ncclSum, c->comm, s->stream);
+    if (r != ncclSuccess) return fail(s, NB_ERR_COMM, std::string("ncclReduceScatter: ") + api->GetErrorString(r));
     return NB_OK;
 }
 
@@ -244,6 +260,12 @@ struct nb_multi {
     std::vector<nb_sim*> shard;
     std::vector<hipEvent_t> ev_k2, ev_copied;   // per shard: "own rows written", "all foreign rows received"
     bool copied_pending = false;
+    // rank form of the symmetric force pass (f32, rows in whole super-blocks): each shard sweeps the pair lists of its own rows,
+    // then the shards reduce-scatter their partial accelerations (peer copies into `stage` + a fixed-order sum, or ncclReduceScatter)
+    bool sym = false;
+    std::vector<hipEvent_t> ev_a, ev_rs;        // per shard: "sym_A complete", "this shard has copied what it needs of the others' sym_A"
+    std::vector<void*> stage;                   // per shard: g x rows float4
+    bool rs_pending = false;
     int mode = NB_MULTI_PEER;
     std::vector<ncclComm_t> comms;               // NB_MULTI_RCCL: one per shard (ncclCommInitAll)
     std::vector<char> pad_b, pad_v, pad_a;       // host staging for the zero-mass padding rows
@@ -293,7 +315,10 @@ int nb_multi_create(const nb_config* cfg_in, uint32_t n_shards, const int32_t* d
     m->n = cfg.n; m->g = n_shards;
     m->esz = cfg.precision == NB_F64 ? 8 : 4;
     uint32_t rows = ceil_div(cfg.n, n_shards);
-    rows = ceil_div(rows, (uint32_t)nb::kTile) * nb::kTile;     // 256-aligned blocks (reference tile, nbody3d.js:4)
+    // the rank form of the symmetric pass wants rows in whole super-blocks of 1,024 (f32, >= 2 shards, systems worth it)
+    const bool want_sym = cfg.precision != NB_F64 && n_shards >= 2 && rows >= 2048 && !(cfg.flags & NB_FLAG_NO_SYM) && cfg.force_variant == 0;
+    const uint32_t align = want_sym ? 1024u : (uint32_t)nb::kTile;
+    rows = ceil_div(rows, align) * align;                       // 256-aligned blocks (reference tile, nbody3d.js:4) at least
     m->rows = rows; m->padded_n = rows * n_shards;
     for (uint32_t k = 0; k < n_shards; ++k) {
         nb_config c = cfg;
@@ -302,6 +327,7 @@ int nb_multi_create(const nb_config* cfg_in, uint32_t n_shards, const int32_t* d
         c.shard_begin = k * rows; c.shard_count = rows;
         c.device = devices ? devices[k] : (int32_t)(k % (uint32_t)count);
         if (n_shards == 1) c.flags |= NB_FLAG_NO_FUSE;   // keep the shard code path (and its exchange) even for g = 1
+        if (want_sym) c.flags |= NB_FLAG_SYM_SHARD;
         nb_sim* s = nullptr;
         int rc = nb_create(&c, &s);
         if (rc != NB_OK) { std::string e = nbi::create_error(); nb_multi_destroy(m); return mfail(nullptr, rc, "nb_multi_create: shard " + std::to_string(k) + ": " + e); }
@@ -320,12 +346,18 @@ int nb_multi_create(const nb_config* cfg_in, uint32_t n_shards, const int32_t* d
             }
         }
     m->ev_k2.resize(n_shards); m->ev_copied.resize(n_shards);
+    m->sym = want_sym;
+    for (nb_sim* s : m->shard) if (!s->sym_rank) m->sym = false;
+    m->ev_a.assign(n_shards, nullptr); m->ev_rs.assign(n_shards, nullptr); m->stage.assign(n_shards, nullptr);
     for (uint32_t k = 0; k < n_shards; ++k) {
         if (hipSetDevice(m->shard[k]->device) != hipSuccess ||
             hipEventCreateWithFlags(&m->ev_k2[k], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&m->ev_copied[k], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&m->ev_copied[k], hipEventDisableTiming) != hipSuccess ||
+            (m->sym && (hipEventCreateWithFlags(&m->ev_a[k], hipEventDisableTiming) != hipSuccess ||
+                        hipEventCreateWithFlags(&m->ev_rs[k], hipEventDisableTiming) != hipSuccess ||
+                        hipMalloc(&m->stage[k], (size_t)16 * rows * n_shards) != hipSuccess))) {
             nb_multi_destroy(m);
-            return mfail(nullptr, NB_ERR_HIP, "nb_multi_create: event creation failed");
+            return mfail(nullptr, NB_ERR_HIP, "nb_multi_create: event / staging creation failed");
         }
     }
     *out = m;
@@ -344,6 +376,9 @@ void nb_multi_destroy(nb_multi* m)
         if (k < m->shard.size()) (void)hipSetDevice(m->shard[k]->device);
         if (m->ev_k2[k]) (void)hipEventDestroy(m->ev_k2[k]);
         if (m->ev_copied[k]) (void)hipEventDestroy(m->ev_copied[k]);
+        if (k < m->ev_a.size() && m->ev_a[k]) (void)hipEventDestroy(m->ev_a[k]);
+        if (k < m->ev_rs.size() && m->ev_rs[k]) (void)hipEventDestroy(m->ev_rs[k]);
+        if (k < m->stage.size() && m->stage[k]) (void)hipFree(m->stage[k]);
     }
     for (nb_sim* s : m->shard) nb_destroy(s);
     delete m;
@@ -365,7 +400,7 @@ int nb_multi_set_collective(nb_multi* m, int mode)
     if (mode != NB_MULTI_PEER && mode != NB_MULTI_RCCL) return mfail(m, NB_ERR_INVALID, "nb_multi_set_collective: unknown mode");
     if (int rc = nb_multi_sync(m)) return rc;
     if (mode == m->mode) return NB_OK;
-    if (mode == NB_MULTI_PEER) { drop_comms(m); m->mode = mode; m->copied_pending = false; return NB_OK; }
+    if (mode == NB_MULTI_PEER) { drop_comms(m); m->mode = mode; m->copied_pending = false; m->rs_pending = false; return NB_OK; }
     // one communicator per shard, one shard per device (RCCL refuses two ranks on one GPU)
     std::vector<int> devs;
     for (nb_sim* s : m->shard) {
@@ -381,6 +416,7 @@ int nb_multi_set_collective(nb_multi* m, int mode)
     if (r != ncclSuccess) { m->comms.clear(); return mfail(m, NB_ERR_COMM, std::string("ncclCommInitAll: ") + api->GetErrorString(r)); }
     m->mode = mode;
     m->copied_pending = false;
+    m->rs_pending = false;
     return NB_OK;
 }
 
@@ -404,6 +440,7 @@ int nb_multi_upload(nb_multi* m, const void* bodies, const void* vel, const void
     if (!bodies || !vel) return mfail(m, NB_ERR_INVALID, "nb_multi_upload: bodies and vel are required");
     if (int rc = nb_multi_sync(m)) return rc;
     m->copied_pending = false;
+    m->rs_pending = false;
     const size_t row = 4 * m->esz, real = row * m->n, padded = row * m->padded_n;
     const void *b = bodies, *v = vel, *a = accel;
     if (m->padded_n != m->n) {     // zero-mass rows at the origin, zero velocity
@@ -434,9 +471,10 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
     }
     const RcclApi* api = m->mode == NB_MULTI_RCCL ? rccl_api(nullptr) : nullptr;
     if (m->mode == NB_MULTI_RCCL && !api) return mfail(m, NB_ERR_COMM, "nb_multi_step: RCCL is not loaded");
+    if (m->sym && !m->shard[0]->uploaded) return mfail(m, NB_ERR_STATE, "nb_multi_step: nb_multi_upload has not been called");
     for (uint32_t k = 0; k < nsteps; ++k) {
         // force + integrate on every shard (asynchronous on the shard's own stream)
-        for (uint32_t d = 0; d < g; ++d) {
+        for (uint32_t d = 0; d < g && !m->sym; ++d) {
             nb_sim* s = m->shard[d];
             NB_MHIP(m, hipSetDevice(s->device));
             if (m->copied_pending)      // nobody may still be reading the rows this shard is about to overwrite
@@ -445,6 +483,62 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
             int rc = nb_step(s, 1);
             if (rc != NB_OK) return mfail(m, rc, s->err);
             if (m->mode == NB_MULTI_PEER) NB_MHIP(m, hipEventRecord(m->ev_k2[d], s->stream));
+        }
+        if (m->sym) {
+            // rank form of the symmetric pass.  (a) every shard: force pass over the pair lists of its own rows, then its sums
+            // for every row of the system (sym_A)
+            for (uint32_t d = 0; d < g; ++d) {
+                nb_sim* s = m->shard[d];
+                NB_MHIP(m, hipSetDevice(s->device));
+                if (m->rs_pending)       // the other shards may still be copying out of this shard's sym_A (previous step)
+                    for (uint32_t e = 0; e < g; ++e)
+                        if (e != d) NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_rs[e], 0));
+                // (the positions this pass reads were completed on this stream by the previous step's gather)
+                int rc = nbi::sym_rank_phase_a(s);
+                if (rc != NB_OK) return mfail(m, rc, s->err);
+                if (m->mode == NB_MULTI_PEER) NB_MHIP(m, hipEventRecord(m->ev_a[d], s->stream));
+            }
+            // (b) reduce-scatter: shard e ends up with the sum over all shards of the rows it owns
+            if (m->mode == NB_MULTI_RCCL) {
+                ncclResult_t r = api->GroupStart();
+                for (uint32_t d = 0; d < g && r == ncclSuccess; ++d) {
+                    nb_sim* s = m->shard[d];
+                    float* A = (float*)s->sym_A;
+                    r = api->ReduceScatter(A, A + (size_t)4 * m->rows * d, (size_t)4 * m->rows, ncclFloat, ncclSum, m->comms[d], s->stream);
+                }
+                const ncclResult_t r2 = api->GroupEnd();
+                if (r == ncclSuccess) r = r2;
+                if (r != ncclSuccess) return mfail(m, NB_ERR_COMM, std::string("nb_multi_step: ncclReduceScatter: ") + api->GetErrorString(r));
+            } else {
+                for (uint32_t e = 0; e < g; ++e) {
+                    nb_sim* dst = m->shard[e];
+                    NB_MHIP(m, hipSetDevice(dst->device));
+                    for (uint32_t d = 0; d < g; ++d) {
+                        nb_sim* src = m->shard[d];
+                        if (d != e) NB_MHIP(m, hipStreamWaitEvent(dst->stream, m->ev_a[d], 0));
+                        NB_MHIP(m, hipMemcpyAsync((char*)m->stage[e] + (size_t)16 * m->rows * d, (const char*)src->sym_A + (size_t)16 * m->rows * e,
+                                                  (size_t)16 * m->rows, hipMemcpyDeviceToDevice, dst->stream));
+                    }
+                    NB_MHIP(m, hipEventRecord(m->ev_rs[e], dst->stream));
+                    const float4* st = (const float4*)m->stage[e];
+                    float4* out = (float4*)dst->sym_A + (size_t)m->rows * e;
+                    uint32_t rows = m->rows, shards = g;
+                    void* args[] = {&st, &out, &rows, &shards};
+                    NB_MHIP(m, hipLaunchKernel((const void*)&nb::nb_sym_sum_shards<0>, dim3((rows + nb::kBlock - 1) / nb::kBlock), dim3(nb::kBlock), args, 0, dst->stream));
+                }
+                m->rs_pending = true;
+            }
+            // (c) integrate every shard's own rows
+            for (uint32_t d = 0; d < g; ++d) {
+                nb_sim* s = m->shard[d];
+                NB_MHIP(m, hipSetDevice(s->device));
+                if (m->copied_pending)      // nobody may still be reading the rows this shard is about to overwrite
+                    for (uint32_t e = 0; e < g; ++e)
+                        if (e != d) NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_copied[e], 0));
+                int rc = nbi::sym_rank_phase_b(s);
+                if (rc != NB_OK) return mfail(m, rc, s->err);
+                if (m->mode == NB_MULTI_PEER) NB_MHIP(m, hipEventRecord(m->ev_k2[d], s->stream));
+            }
         }
         if (m->mode == NB_MULTI_RCCL) {
             // ncclGroupStart / per-device in-place ncclAllGather / ncclGroupEnd.

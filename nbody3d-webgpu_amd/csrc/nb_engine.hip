@@ -204,7 +204,7 @@ void name_variant(nb_sim* s, const Shape& sh)
     else if (sh.kind == kJpk)
         snprintf(buf, sizeof buf, "f32pk_fused_jpairs_ws%d_js%u", jpk_ws(sh.x), s->jsplit);
     else if (sh.kind == kSym)
-        snprintf(buf, sizeof buf, s->f64 ? "f64_symw_ipl%d_j%d_w%u_r%ut%u" : s->symw ? "f32pk_symw_ipl%d_j%d_w%u_r%ut%u" : "f32pk_sym_ipl%d_ws%d_q%u_r%ut%u", sh.ipl, s->symw ? (sh.x == 3 ? 1 : 2) : sh.x,
+        snprintf(buf, sizeof buf, s->f64 ? "f64_symw_ipl%d_j%d_w%u_r%ut%u" : s->sym_rank ? "f32pk_symwrank_ipl%d_j%d_w%u_r%ut%u" : s->symw ? "f32pk_symw_ipl%d_j%d_w%u_r%ut%u" : "f32pk_sym_ipl%d_ws%d_q%u_r%ut%u", sh.ipl, s->symw ? (sh.x == 3 ? 1 : 2) : sh.x,
                  s->sym_plan[2], s->sym_plan[8] - s->sym_plan[7], s->sym_layers - (s->sym_plan[8] - s->sym_plan[7]));     // words 7, 8: r_layer0, t_layer0 in both plans
     else
         snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.kind == kPkLds ? "pk" : "",
@@ -334,8 +334,15 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
 
     Shape sh{s->f64 ? kScalar : kPkLds, 2, 1, 1};
     uint32_t js = cfg.jsplit, sym_k = 0;
-    const uint32_t variant = cfg.force_variant;
+    // NB_FLAG_SYM_SHARD: a rank's shard whose cross-rank reduction the engine's native exchange provides takes the RANK form of the
+    // symmetric pass when its rows are whole super-blocks (1,024 rows, or 512); otherwise the flag is ignored
+    int rank_ipl = 0;
+    if ((cfg.flags & NB_FLAG_SYM_SHARD) && !(cfg.flags & NB_FLAG_NO_SYM) && !s->f64 && !cfg.ext_bodies && cfg.shard_count != 0)
+        for (uint32_t S : {1024u, 512u})
+            if (!rank_ipl && s->sb % S == 0 && sc % S == 0 && n % S == 0 && n / S >= 2) rank_ipl = (int)(S / 64u);
+    const uint32_t variant = rank_ipl ? 0u : cfg.force_variant;
     bool pinned = false;
+    if (rank_ipl) { sh = {kSym, rank_ipl, 1, 3}; pinned = true; if (js == 0) js = 0xffffffffu; }     // js: placeholder, set with the plan below
     if (variant != 0) {
         Shape want;
         if (decode_variant(variant, &want)) {
@@ -348,7 +355,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
             if (kernel_of(s->f64, want)) { sh = want; pinned = true; }
         }
     }
-    if (!pinned || js == 0) {
+    if (!rank_ipl && (!pinned || js == 0)) {
         struct Scored { Shape sh; uint32_t q; double t; };
         std::vector<Scored> scored;
         double best_t = 1e300;
@@ -488,12 +495,17 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
         pl.np = nsb * S; pl.nsb = nsb;
         pl.total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps; pl.total_lo = (H + 1) * cps;
         pl.n_hi = n_hi; pl.H = H;
-        pl.L = n_hi * pl.total_hi + (nsb - n_hi) * pl.total_lo;
-        uint32_t W = 4u * (uint32_t)n_cu * (sym_k ? sym_k : cfg.jsplit ? cfg.jsplit : 1u);
+        auto offset_of = [&](uint32_t g) { return g <= n_hi ? g * pl.total_hi : n_hi * pl.total_hi + (g - n_hi) * pl.total_lo; };
+        // a whole system sweeps every super-block's list; a rank (rank_ipl) only those of its own rows
+        const uint32_t g0 = rank_ipl ? s->sb / S : 0u, g1 = rank_ipl ? (s->sb + sc) / S : nsb;
+        pl.p0 = offset_of(g0);
+        pl.L = offset_of(g1) - pl.p0;
+        const uint32_t kw = sym_k ? sym_k : (cfg.jsplit ? cfg.jsplit : (rank_ipl && pl.L >= 16u * (uint32_t)n_cu ? 2u : 1u));
+        uint32_t W = 4u * (uint32_t)n_cu * kw;
         if (W > pl.L) W = (pl.L + 3u) & ~3u;
         pl.W = W;
         auto start_of = [&](uint32_t w) { return (uint32_t)(((uint64_t)w * pl.L) / pl.W); };
-        auto wave_of = [&](uint32_t p) {
+        auto wave_of = [&](uint32_t p) {              // p: position inside this handle's range
             uint32_t w = (uint32_t)(((uint64_t)p * pl.W) / pl.L);
             while (w + 1 < pl.W && start_of(w + 1) <= p) ++w;
             while (w > 0 && start_of(w) > p) --w;
@@ -501,13 +513,14 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
         };
         s->sym_tab_host.assign(2 * (size_t)nsb, 0);
         uint32_t max_r = 1;
-        for (uint32_t g = 0; g < nsb; ++g) {
+        for (uint32_t g = g0; g < g1; ++g) {
             const uint32_t total = g < n_hi ? pl.total_hi : pl.total_lo;
-            const uint32_t off = g <= n_hi ? g * pl.total_hi : n_hi * pl.total_hi + (g - n_hi) * pl.total_lo;
+            const uint32_t off = offset_of(g) - pl.p0;
             const uint32_t first = wave_of(off), last = wave_of(off + total - 1);
             s->sym_tab_host[2 * g] = first; s->sym_tab_host[2 * g + 1] = last - first + 1;
             if (last - first + 1 > max_r) max_r = last - first + 1;
         }
+        s->sym_rank = rank_ipl != 0; s->sym_g0 = g0; s->sym_g1 = g1;
         pl.r_layer0 = 0; pl.t_layer0 = max_r;
         static_assert(sizeof(pl) <= sizeof(s->sym_plan), "nb_sim::sym_plan holds a SymWPlan");
         memcpy(s->sym_plan, &pl, sizeof pl);
@@ -868,6 +881,43 @@ void free_frames(nb_sim* s)
 
 }  // namespace
 
+namespace nbi {
+
+// Rank form of the symmetric pass, first half of a step: the force pass over the chunk lists of the handle's own super-blocks,
+// then this rank's sums for every row of the system into sym_A.
+int sym_rank_phase_a(nb_sim* s)
+{
+    if (!s->sym_rank) return fail(s, NB_ERR_STATE, "sym_rank_phase_a: not a rank-form handle");
+    if (int rc = ensure_gm(s)) return rc;
+    launch_force<float>(s);
+    nb::SymWPlan pl;
+    memcpy(&pl, s->sym_plan, sizeof pl);
+    const nb::SymRow* p = (const nb::SymRow*)s->partial;
+    const uint32_t* tab = s->sym_tab;
+    float4* A = (float4*)s->sym_A;
+    uint32_t S = ipb_of(shape_of(s)), g0 = s->sym_g0, g1 = s->sym_g1;
+    void* args[] = {&p, &tab, &A, &pl, &S, &g0, &g1};
+    NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_sym_reduce<0>, dim3(ceil_div(pl.np, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
+    return NB_OK;
+}
+
+// Second half: the plain integrate kernel on the handle's rows of the (reduce-scattered) sym_A.
+int sym_rank_phase_b(nb_sim* s)
+{
+    float4 *b = (float4*)s->bodies[s->cur], *v = (float4*)s->vel, *a = (float4*)s->acc;
+    const float4* p = (const float4*)s->sym_A + s->sb;
+    uint32_t sb = s->sb, sc = s->sc, js = 1;
+    float dt = (float)s->dt, G = (float)s->G;
+    float4* gout = nullptr;                          // the (x, y, z, G*m) copy is rebuilt whole after the position all-gather
+    void* args[] = {&b, &v, &a, &p, &sb, &sc, &js, &dt, &gout, &G};
+    NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_integrate<float, 1>, dim3(ceil_div(sc, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
+    ++s->steps_done;
+    s->gm_ok = false;
+    return NB_OK;
+}
+
+}  // namespace nbi
+
 extern "C" {
 
 uint32_t nb_abi_version(void) { return NB_ABI_VERSION; }
@@ -951,6 +1001,7 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     NB_HIPC(hipMalloc(&s->acc, row * s->sc));
     if (s->sym) {
         NB_HIPC(hipMalloc(&s->partial, (size_t)3 * s->esz * s->sym_np * s->sym_layers));       // layers of (x, y, z) rows: 12 bytes (24 in f64)
+        if (s->sym_rank) NB_HIPC(hipMalloc(&s->sym_A, (size_t)16 * s->sym_np));
         if (s->symw) {
             NB_HIPC(hipMalloc((void**)&s->sym_tab, sizeof(uint32_t) * s->sym_tab_host.size()));
             NB_HIPC(hipMemcpy(s->sym_tab, s->sym_tab_host.data(), sizeof(uint32_t) * s->sym_tab_host.size(), hipMemcpyHostToDevice));
@@ -1006,6 +1057,7 @@ void nb_destroy(nb_sim* s)
     if (s->jpartial) (void)hipFree(s->jpartial);
     if (s->tickets) (void)hipFree(s->tickets);
     if (s->sym_tab) (void)hipFree(s->sym_tab);
+    if (s->sym_A) (void)hipFree(s->sym_A);
     if (s->diag) (void)hipFree(s->diag);
     if (s->zero_row) (void)hipFree(s->zero_row);
     if (s->own_stream && s->stream) (void)hipStreamDestroy(s->stream);
@@ -1077,6 +1129,27 @@ int nb_step(nb_sim* s, uint32_t nsteps)
             // which every multi-GPU configuration of BASELINE.json uses)
             if (int rc = finish_gather(s)) return rc;
             if (int rc = ensure_gm(s)) return rc;
+        }
+        if (s->sym_rank) {
+            // rank form of the symmetric pass: force pass -> this rank's sums for every row -> reduce-scatter across the ranks
+            // -> integrate own rows -> all-gather of the new positions
+            if (!s->rccl) return fail(s, NB_ERR_STATE, "nb_step: an NB_FLAG_SYM_SHARD handle needs nb_rccl_attach (or nb_multi) for its reduce-scatter");
+            if (int rc = finish_gather(s)) return rc;
+            nb_events evr;
+            const bool recr = s->timing && get_events(s, &evr) == 0;
+            if (recr) NB_HIP(s, hipEventRecord(evr.e[0], s->stream));
+            if (int rc = nbi::sym_rank_phase_a(s)) return rc;
+            if (recr) NB_HIP(s, hipEventRecord(evr.e[1], s->stream));
+            if (int rc = nbi::rccl_reduce_scatter_A(s)) return rc;
+            if (recr) NB_HIP(s, hipEventRecord(evr.e[6], s->stream));
+            if (int rc = nbi::sym_rank_phase_b(s)) return rc;
+            if (recr) NB_HIP(s, hipEventRecord(evr.e[2], s->stream));
+            NB_HIP(s, hipGetLastError());
+            if (int rc = nbi::rccl_exchange_begin(s)) return rc;
+            if (nbi::rccl_overlapped(s)) { s->gather_pending = true; if (int rc2 = finish_gather(s)) return rc2; }
+            else if (recr) { NB_HIP(s, hipEventRecord(evr.e[5], s->stream)); evr.xchg = true; }
+            if (recr) s->pending.push_back(evr);
+            continue;
         }
         nb_events ev;
         const bool rec = s->timing && get_events(s, &ev) == 0;

@@ -87,10 +87,16 @@ struct nb_sim {
     // bodies / gm are allocated with sym_np >= n rows (zero-mass padding); `partial` holds sym_layers x sym_np rows.
     bool sym = false;
     uint32_t sym_np = 0, sym_layers = 0;
-    uint32_t sym_plan[10] = {0};   // nb::SymPlan / nb::SymWPlan, kept as plain words here (nb_comm.hip does not see the kernels' types)
+    uint32_t sym_plan[11] = {0};   // nb::SymPlan / nb::SymWPlan, kept as plain words here (nb_comm.hip does not see the kernels' types)
     bool symw = false;             // wave-granular form (nb_force_symw): sym_plan holds a SymWPlan, sym_tab the per-super-block table
     uint32_t* sym_tab = nullptr;   // device: {first wave, wave count} per super-block
     std::vector<uint32_t> sym_tab_host;
+    // rank form (NB_FLAG_SYM_SHARD: a shard handle whose cross-rank reduction the engine's native exchange provides): the
+    // handle's own rows are the resident super-blocks [sym_g0, sym_g1); sym_A[np] = this rank's sums for EVERY row, reduce-
+    // scattered across the ranks before the integrate kernel reads the rank's own rows of it
+    bool sym_rank = false;
+    uint32_t sym_g0 = 0, sym_g1 = 0;
+    void* sym_A = nullptr;
     std::string variant, err;
     nb_exchange_fn xfn = nullptr;
     nb_exchange_wait_fn xwait = nullptr;   // non-null: two-phase (overlapped) exchange
@@ -130,6 +136,11 @@ const std::string& create_error();
 // begin: enqueue the in-place all-gather of this rank's rows (on the engine stream, or on the
 // communicator's own stream when overlapped); wait: make the engine stream wait for it.
 int rccl_exchange_begin(nb_sim* s);
+// rank form of the symmetric pass: in-place ncclReduceScatter of sym_A on the engine stream (this rank's rows receive the sum)
+int rccl_reduce_scatter_A(nb_sim* s);
+// the two halves of a rank-form step, for nb_multi (which runs its own reduce-scatter between them)
+int sym_rank_phase_a(nb_sim* s);     // force pass + nb_sym_reduce
+int sym_rank_phase_b(nb_sim* s);     // integrate kernel on the handle's rows of sym_A
 int rccl_exchange_wait(nb_sim* s);
 bool rccl_overlapped(const nb_sim* s);
 void rccl_release(nb_sim* s);

@@ -1203,7 +1203,9 @@ struct SymWPlan {
     uint32_t np, nsb, W;
     uint32_t total_hi, total_lo, n_hi, H;
     uint32_t r_layer0, t_layer0;
-    uint32_t L;                 // n_hi * total_hi + (nsb - n_hi) * total_lo
+    uint32_t L;                 // chunk-sweeps of this handle: n_hi * total_hi + (nsb - n_hi) * total_lo for a whole system
+    uint32_t p0;                // where this handle's range starts in the global list (0 for a whole system; a RANK that owns
+                                // the resident super-blocks [g0, g1) works on the lists of those super-blocks only)
 };
 
 template <int NG, int J>
@@ -1217,8 +1219,8 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));     // the four waves of a workgroup are independent
     if (w >= pl.W) return;
-    uint32_t p = (uint32_t)(((uint64_t)w * pl.L) / pl.W);
-    const uint32_t pend = (uint32_t)(((uint64_t)(w + 1) * pl.L) / pl.W);
+    uint32_t p = pl.p0 + (uint32_t)(((uint64_t)w * pl.L) / pl.W);
+    const uint32_t pend = pl.p0 + (uint32_t)(((uint64_t)(w + 1) * pl.L) / pl.W);
     const nb_f2 e2 = nb_f2{eps2, eps2};
     const uint32_t first_lo = pl.n_hi * pl.total_hi;
 
@@ -1346,8 +1348,8 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (w >= pl.W) return;
-    uint32_t p = (uint32_t)(((uint64_t)w * pl.L) / pl.W);
-    const uint32_t pend = (uint32_t)(((uint64_t)(w + 1) * pl.L) / pl.W);
+    uint32_t p = pl.p0 + (uint32_t)(((uint64_t)w * pl.L) / pl.W);
+    const uint32_t pend = pl.p0 + (uint32_t)(((uint64_t)(w + 1) * pl.L) / pl.W);
     const uint32_t first_lo = pl.n_hi * pl.total_hi;
     while (p < pend) {
         uint32_t g, k, total;
@@ -1410,6 +1412,46 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
 #pragma unroll
         for (int c = 0; c < IPL; ++c) out[c * 64] = SymRowT<double>{ax[c], ay[c], az[c]};
     }
+}
+
+// The RANK form of the pass (multi-GPU: rank r keeps the super-blocks [g0, g1) of its own rows resident and sweeps THEIR chunk
+// lists, so every unordered pair of the system is evaluated by exactly one rank): the traveler sums a rank produces belong
+// to bodies of other ranks as well.  This kernel adds up, for EVERY row of the system, what this rank has for it -- its
+// resident layers (own rows only) and the traveler layers written by the rank's own super-blocks, in the order
+// nb_integrate_symw uses -- into one array A[np]; the ranks then reduce-scatter A (ncclReduceScatter, or peer copies + a
+// fixed-order sum in the single-process handle) and the plain integrate kernel reads the rank's rows of the result.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRow* __restrict__ partial, const uint32_t* __restrict__ gtab, float4* __restrict__ A,
+                                                       const SymWPlan pl, uint32_t S, uint32_t g0, uint32_t g1)
+{
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= pl.np) return;
+    const uint32_t b = j / S;
+    float sx = 0, sy = 0, sz = 0;
+    if (b >= g0 && b < g1) {
+        const uint32_t nr = gtab[2 * b + 1];
+        for (uint32_t e = 0; e < nr; ++e) { const SymRow r = partial[(size_t)(pl.r_layer0 + e) * pl.np + j]; sx += r.x; sy += r.y; sz += r.z; }
+    }
+    for (uint32_t d = 0; d <= pl.H; ++d) {                       // ascending ring distance, as nb_integrate_symw
+        uint32_t g = b + pl.nsb - 1 - d;
+        if (g >= pl.nsb) g -= pl.nsb;
+        if (g < g0 || g >= g1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
+        const SymRow r = partial[(size_t)(pl.t_layer0 + d) * pl.np + j];
+        sx += r.x; sy += r.y; sz += r.z;
+    }
+    A[j] = float4{sx, sy, sz, 0};
+}
+
+// The single-process multi-device handle's reduce-scatter by peer copies: stage[d] holds shard d's A rows for THIS shard's
+// row block (shard d = own: its own A); summed in ascending shard order -- deterministic.
+template <int UNUSED = 0>
+__global__ __launch_bounds__(kBlock) void nb_sym_sum_shards(const float4* __restrict__ stage, float4* __restrict__ out, uint32_t rows, uint32_t shards)
+{
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= rows) return;
+    float sx = 0, sy = 0, sz = 0;
+    for (uint32_t d = 0; d < shards; ++d) { const float4 r = ld4(stage + (size_t)d * rows + i); sx += r.x; sy += r.y; sz += r.z; }
+    out[i] = float4{sx, sy, sz, 0};
 }
 
 // K2 for the wave-granular form: resident layers gtab[2g+1] (waves that worked on g's list), then the traveler layers.

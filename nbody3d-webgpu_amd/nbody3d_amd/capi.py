@@ -25,6 +25,7 @@ NB_FLAG_NO_FUSE = 8
 NB_FLAG_POISON = 16
 NB_FLAG_JPK_FENCED = 32
 NB_FLAG_NO_SYM = 64
+NB_FLAG_SYM_SHARD = 128
 NB_RCCL_ID_BYTES = 128
 NB_RCCL_OVERLAP = 1
 NB_MULTI_PEER, NB_MULTI_RCCL = 0, 1

@@ -209,3 +209,112 @@ def test_f64_default_shape_and_determinism():
     assert rel_pos_err(x[0], z[0], 1.0) < 1e-12
     with Simulation(4096, precision="f64") as s:
         assert s.variant.startswith("f64_lds"), s.variant          # small systems keep the ordered-pair kernel
+
+
+# ---- the rank form (multi-GPU): every unordered pair evaluated by ONE rank, partial accelerations reduce-scattered ------------
+
+def test_rank_form_with_one_rank_equals_the_whole_system_form():
+    """NB_FLAG_SYM_SHARD on a shard handle that owns every row, native RCCL attached (one rank: the in-place
+    ncclReduceScatter and ncclAllGather really run): force pass -> nb_sym_reduce -> reduce-scatter -> plain integrate kernel.
+    Same pair sums in the same layers as the whole-system form; only the order in which a body's layers are added differs
+    (eight lanes per body there, one here): agreement to rounding, at G = 1 and at the reference's G = 1e-4; deterministic."""
+    n, steps = 16384, 6
+    b, v = ic.plummer(n, seed=87)
+    for G in (1.0, 1e-4):
+        with Simulation(n, force_variant=716013, jsplit=1) as one:
+            one.init(b, v)
+            one.simulate(steps, 1e-3, G)
+            ref = one.read()
+        with Simulation(n, shard=(0, n), jsplit=1, flags=capi.NB_FLAG_SYM_SHARD) as sim:
+            assert "symwrank_ipl16" in sim.variant, sim.variant
+            sim.init(b, v)
+            with pytest.raises(Exception) as e:
+                sim.simulate(1, 1e-3, G)                     # no communicator yet: nobody would do the reduce-scatter
+            assert "NB_ERR_STATE" in str(e.value)
+            sim.rccl_attach(capi.rccl_unique_id(), 1, 0)
+            sim.enable_timing(True)
+            sim.simulate(steps, 1e-3, G)
+            f_ms, i_ms, x_ms, launches = sim.step_times()
+            got = sim.read()
+            assert launches == steps and f_ms > 0 and i_ms > 0 and x_ms > 0
+        assert rel_pos_err(got[0], ref[0], 1.0) < 1e-6, G
+        assert np.abs(got[2][:, :3] - ref[2][:, :3]).max() < 2e-6 * np.abs(ref[2][:, :3]).max(), G
+        rb, _, ra = oracle.run_f64(b, v, None, 1e-3, G, steps)
+        assert rel_pos_err(got[0], rb, 1.0) < TOL_TIGHT and np.abs(got[2][:, :3] - ra[:, :3]).max() < TOL_ACC * np.abs(ra[:, :3]).max(), G
+        with Simulation(n, shard=(0, n), jsplit=1, flags=capi.NB_FLAG_SYM_SHARD) as again:
+            again.init(b, v)
+            again.rccl_attach(capi.rccl_unique_id(), 1, 0)
+            again.simulate(steps, 1e-3, G)
+            for x, y in zip(again.read(), got):
+                assert x.tobytes() == y.tobytes(), G
+
+
+def test_rank_form_is_not_taken_when_the_rows_are_not_whole_super_blocks_or_without_the_flag():
+    n = 16384
+    with Simulation(n, shard=(256, 8192), flags=capi.NB_FLAG_SYM_SHARD) as s:       # begin not on a 512-row boundary
+        assert "sym" not in s.variant, s.variant
+    with Simulation(n, shard=(0, 8192)) as s:
+        assert "sym" not in s.variant, s.variant
+    with Simulation(n, shard=(8192, 8192), flags=capi.NB_FLAG_SYM_SHARD | capi.NB_FLAG_NO_SYM) as s:
+        assert "sym" not in s.variant, s.variant
+    with Simulation(n, shard=(8192, 8192), precision="f64", flags=capi.NB_FLAG_SYM_SHARD) as s:
+        assert s.variant.startswith("f64_lds"), s.variant
+    with Simulation(n, shard=(8192, 8192), flags=capi.NB_FLAG_SYM_SHARD) as s:
+        assert "symwrank" in s.variant, s.variant
+    with Simulation(n + 512, shard=(8192, 8704), flags=capi.NB_FLAG_SYM_SHARD) as s:  # 512-row super-blocks
+        assert "symwrank_ipl8" in s.variant, s.variant
+
+
+@pytest.mark.parametrize("n,g", [(16384, 2), (16384, 4), (40002, 4), (65536, 8), (20000, 3)])
+def test_multi_handle_takes_the_rank_form_and_matches_oracle_and_single_handle(n, g):
+    """nb_multi with g shards on ONE GPU (virtual shards: the partition, event and copy logic of a g-GPU node): each shard
+    sweeps the pair lists of its own rows, the shards reduce-scatter their partial accelerations by peer copies + a fixed-order
+    sum, integrate, and all-gather the positions.  Against the fp64 oracle, against the single-handle symmetric pass (summation
+    order only), momentum of the pair sums, and bit-reproducible from run to run."""
+    from nbody3d_amd import MultiSimulation
+    steps = 5
+    b, v = ic.plummer(n, seed=88) if n % 2 == 0 else ic.uniform_cube(n, seed=88)
+    runs = []
+    for _ in range(2):
+        with MultiSimulation(n, g) as ms:
+            assert "symwrank" in ms.variant, ms.variant
+            ms.init(b, v)
+            ms.simulate(1, 1e-3, 1.0)
+            first = ms.read()
+            ms.simulate(steps - 1)
+            runs.append(ms.read())
+            name = ms.variant
+    for x, y in zip(runs[0], runs[1]):
+        assert x.tobytes() == y.tobytes(), name
+    ref = oracle.accel_f64(b, 1.0)
+    assert np.abs(first[2][:, :3] - ref[:, :3]).max() < TOL_ACC * np.abs(ref[:, :3]).max(), name
+    f = b[:, 3:4].astype(np.float64) * first[2][:, :3]
+    assert np.all(np.abs(f.sum(0)) < 5e-8 * np.abs(f).sum(0)), name
+    with Simulation(n) as one:
+        one.init(b, v)
+        one.simulate(steps, 1e-3, 1.0)
+        want = one.read()
+    assert rel_pos_err(runs[0][0], want[0], 1.0) < 2e-6, name
+    assert np.array_equal(runs[0][0][:, 3], b[:, 3])
+
+
+def test_multi_handle_rank_form_at_G_not_one_and_mid_run_restore():
+    from nbody3d_amd import MultiSimulation
+    n, g = 16384, 4
+    b, v = ic.plummer(n, seed=89)
+    with MultiSimulation(n, g) as ms, Simulation(n) as one:
+        assert "symwrank" in ms.variant
+        for s in (ms, one):
+            s.init(b, v)
+            s.simulate(4, 1e-3, 0.05)
+        state = ms.read()
+        assert rel_pos_err(state[0], one.read()[0], 1.0) < 2e-6
+        ms.simulate(3)
+        after = ms.read()
+        ms.restore(*state)
+        ms.simulate(3)
+        for x, y in zip(ms.read(), after):
+            assert x.tobytes() == y.tobytes()
+        ke, pe, mom = ms.diagnostics()
+    rke, rpe, _ = oracle.energy(after[0], after[1], 0.05)
+    assert abs(ke - rke) < 1e-9 * abs(rke) and abs(pe - rpe) < 1e-6 * abs(rpe)
