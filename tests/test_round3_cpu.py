@@ -40,3 +40,62 @@ def test_release_library_reads_no_model_knobs_from_the_environment():
         subprocess.check_call(["make", "-C", CSRC, "-s", "tuning"])
     blob = open(tun, "rb").read()
     assert b"NB_MODEL_BOUNDARY" in blob and b"NB_TEST_FAIL_FRAME_SLOT" in blob
+
+
+def _sym_plan(nsb, cps):
+    H = (nsb - 1) // 2
+    n_hi = 0 if nsb & 1 else nsb // 2
+    total_hi, total_lo = (H + 1 + (1 if n_hi else 0)) * cps, (H + 1) * cps
+    off = lambda g: g * total_hi if g <= n_hi else n_hi * total_hi + (g - n_hi) * total_lo      # noqa: E731
+    return H, n_hi, total_hi, total_lo, off
+
+
+@pytest.mark.parametrize("nsb,ranks,waves", [(2, 1, 4), (3, 1, 5), (8, 2, 7), (9, 3, 16), (16, 4, 12), (40, 8, 64), (41, 1, 100), (64, 8, 33)])
+def test_symmetric_pass_partition_covers_every_pair_of_super_blocks_exactly_once(nsb, ranks, waves):
+    """The index arithmetic of nb_force_symw / choose_shape (csrc/nb_kernels.hip.h, nb_engine.hip), restated: super-blocks on a
+    ring; super-block g sweeps the chunks of the H = (nsb-1)/2 super-blocks after it (and of the antipodal one when nsb is even
+    and g < nsb/2), then its own in resident-only mode.  Rank r owns the super-blocks [r*nsb/ranks, (r+1)*nsb/ranks) and its
+    waves cut THEIR lists, laid end to end, into floor/ceil-equal ranges.  Every unordered pair of different super-blocks must be
+    swept by exactly one (rank, wave), every super-block's own block exactly once, every chunk exactly once."""
+    cps = 4
+    H, n_hi, total_hi, total_lo, off = _sym_plan(nsb, cps)
+    if nsb % ranks:
+        pytest.skip("ranks own whole super-blocks")
+    seen_pairs, seen_diag, seen_chunks = {}, {}, set()
+    for r in range(ranks):
+        g0, g1 = r * nsb // ranks, (r + 1) * nsb // ranks
+        p0, L = off(g0), off(g1) - off(g0)
+        W = min(waves, L)
+        for w in range(W):
+            p, pend = p0 + w * L // W, p0 + (w + 1) * L // W
+            while p < pend:
+                first_lo = n_hi * total_hi
+                if p < first_lo:
+                    g, total = p // total_hi, total_hi
+                    k = p - g * total_hi
+                else:
+                    g = n_hi + (p - first_lo) // total_lo
+                    total = total_lo
+                    k = (p - first_lo) - (g - n_hi) * total_lo
+                assert g0 <= g < g1                                  # a rank never touches another rank's lists
+                ring = total - cps
+                kend = min(k + (pend - p), total)
+                for kk in range(k, kend):
+                    if kk < ring:
+                        d = kk // cps
+                        tb = (g + 1 + d) % nsb
+                        assert d <= H and tb != g
+                        seen_pairs[(frozenset((g, tb)), kk % cps)] = seen_pairs.get((frozenset((g, tb)), kk % cps), 0) + 1
+                    else:
+                        seen_diag[(g, kk - ring)] = seen_diag.get((g, kk - ring), 0) + 1
+                    assert (g, kk) not in seen_chunks
+                    seen_chunks.add((g, kk))
+                p += kend - k
+    # every unordered pair {a, b}, a != b: all cps traveler chunks of one of the two, swept by the OTHER one, exactly once
+    for a in range(nsb):
+        for b in range(a + 1, nsb):
+            for c in range(cps):
+                assert seen_pairs.get((frozenset((a, b)), c), 0) == 1, (a, b, c)
+    assert len(seen_pairs) == nsb * (nsb - 1) // 2 * cps
+    assert all(v == 1 for v in seen_diag.values()) and len(seen_diag) == nsb * cps
+    assert len(seen_chunks) == n_hi * total_hi + (nsb - n_hi) * total_lo
