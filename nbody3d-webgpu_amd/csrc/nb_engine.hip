@@ -235,6 +235,7 @@ struct ModelKnobs {
                                // worst regret 8.5 -> 4.8 %, mean 1.6 -> 1.0 % over 14 sizes; fused shapes now to N = 12,000)
     double sustained = 0.958;  // share of hipDeviceProp_t::clockRate the chip holds under this kernel's load
                                // (2.24-2.29 of 2.4 GHz measured, profiles/r02/rocprof_f32_default: GRBM_GUI_ACTIVE)
+    double jpk_lo = 7000, jpk_hi = 12500;   // sizes at which the j-packed step is scored at all (see choose_shape)
 };
 const ModelKnobs& model_knobs()
 {
@@ -245,6 +246,7 @@ const ModelKnobs& model_knobs()
         m.tile_latency = knob("NB_MODEL_TILE_LATENCY", m.tile_latency); m.prologue = knob("NB_MODEL_PROLOGUE", m.prologue);
         m.hand_over = knob("NB_MODEL_HANDOVER", m.hand_over); m.lanes_scale = knob("NB_MODEL_LANES_SCALE", m.lanes_scale);
         m.boundary = knob("NB_MODEL_BOUNDARY", m.boundary); m.sustained = knob("NB_MODEL_SUSTAINED", m.sustained);
+        m.jpk_lo = knob("NB_MODEL_JPK_LO", m.jpk_lo); m.jpk_hi = knob("NB_MODEL_JPK_HI", m.jpk_hi);
 #endif
         return m;
     }();
@@ -255,13 +257,24 @@ const ModelKnobs& model_knobs()
 // and k waves per SIMD.  A chunk-sweep is 64 rotation steps of NG * (16 packed + 2 transcendental) + 10 DPP issue slots; the
 // loop runs at 93.5 % of that.  The L chunk-sweeps are cut into W = k * SIMDs equal ranges:
 //   k = 1: ceil(L / SIMDs) sweeps per SIMD, 1.9 % slower per sweep (nothing hides a chunk's traveler loads);
-//   k = 2: the two ranges of a SIMD rarely both round up: L / SIMDs + 0.5 sweeps on average, 1 % over the bare rate;
+//   k = 2: a wave gets floor or ceil(L / 2 SIMDs) sweeps; with a share p of ceil-waves a SIMD's two waves both round up
+//          about min(1, 2p) of the time somewhere on the chip: 2 floor + 2 min(1, 2p) sweeps, 1 % over the bare rate
+//          (N = 40,002: 13.64 predicted, 13.66 measured; 32,768: 8.5 / 8.9; 65,536: 33 / 32.7; 14,000: 4 / 4.1);
 //   + 3.5 us of kernel fixed cost, 1.5 us per super-block a range touches, the K1 -> K2 boundary and K2's layer traffic
 //   (12 B per layer and body at ~5 TB/s: the layers are Infinity-Cache resident).  16 residents per lane run ~1.5 % closer to
 //   their issue count than 8 (half the rotations per pair).
 // Fitted on profiles/r03/sym_variants_scan_wave_granular*.txt (N = 12,000 .. 262,144, both resident counts: within 2 %);
 // k = 3 measured behind k = 2 (N = 131,072: 2,682 vs 2,615 us).
 struct SymChoice { int ipl; uint32_t k; double t; };
+// Bytes of partial-sum layers a symmetric handle allocates: one traveler layer per ring distance, i.e. ~ 3 * esz * N^2 / (2 S)
+// (N = 1,048,576 with 1,024-row super-blocks: 6.4 GB; it grows with N^2, so very large systems fall back to the ordered-pair kernels).
+double sym_layer_bytes(uint32_t n, uint32_t S, size_t esz)
+{
+    const double nsb = std::ceil((double)n / S);
+    return (nsb / 2.0 + 8.0) * nsb * S * 3.0 * (double)esz;
+}
+constexpr double kSymLayerBudget = 16.0e9;
+
 SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64)
 {
     SymChoice best{0, 0, 1e300};
@@ -270,6 +283,7 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         const uint32_t NG = (uint32_t)ipl / 2, S = 64u * (uint32_t)ipl, cps = S / 64u;
         const uint32_t nsb = ceil_div(n, S);
         if (nsb < 4) continue;
+        if (sym_layer_bytes(n, S, f64 ? 8 : 4) > kSymLayerBudget) continue;
         const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
         const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (uint64_t)(H + 1) * cps;
         const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo;
@@ -278,7 +292,8 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
         if (per_simd < 1.0) continue;
         for (uint32_t k = 1; k <= 2; ++k) {
-            const double sweeps = k == 1 ? std::ceil(per_simd) * 1.019 : (per_simd + 0.5) * 1.01;
+            const double pw = per_simd / 2.0, fl = std::floor(pw);
+            const double sweeps = k == 1 ? std::ceil(per_simd) * 1.019 : (2.0 * fl + 2.0 * std::min(1.0, 2.0 * (pw - fl))) * 1.01;
             const double segs = per_simd / k / (double)total_lo + 1.0;             // super-blocks a wave's range touches
             const double layers = (double)(H + 1) + (double)total_hi * k / per_simd + 1.0;     // traveler + resident layers K2 reads per body
             const double t = sweeps * t_chunk + 3.5e-6 + segs * 1.5e-6 + boundary + layers * n * (f64 ? 24.0 : 12.0) / 5.0e12;
@@ -339,7 +354,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
     int rank_ipl = 0;
     if ((cfg.flags & NB_FLAG_SYM_SHARD) && !(cfg.flags & NB_FLAG_NO_SYM) && !s->f64 && !cfg.ext_bodies && cfg.shard_count != 0)
         for (uint32_t S : {1024u, 512u})
-            if (!rank_ipl && s->sb % S == 0 && sc % S == 0 && n % S == 0 && n / S >= 2) rank_ipl = (int)(S / 64u);
+            if (!rank_ipl && s->sb % S == 0 && sc % S == 0 && n % S == 0 && n / S >= 2 && sym_layer_bytes(n, S, 4) <= kSymLayerBudget) rank_ipl = (int)(S / 64u);
     const uint32_t variant = rank_ipl ? 0u : cfg.force_variant;
     bool pinned = false;
     if (rank_ipl) { sh = {kSym, rank_ipl, 1, 3}; pinned = true; if (js == 0) js = 0xffffffffu; }     // js: placeholder, set with the plan below
@@ -350,7 +365,8 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
             if ((want.kind == kFused || want.kind == kDirect) && !may_fuse && !s->f64) want = {kPkLds, want.ipl, want.ls, 1};   // same loop, two kernels
             if (want.kind == kDirect && n > 1024u * (uint32_t)want.x) want = {kFused, 2, 64, 4};
             if (want.kind == kJpk && !may_fuse) want = {kPkSgpr, 4, 1, 4};      // whole-system f32 handles only
-            if (want.kind == kSym && (!whole || cfg.ext_bodies || !kernel_of(s->f64, want) || n <= ipb_of(want)))       // likewise; >= 2 super-blocks
+            if (want.kind == kSym && (!whole || cfg.ext_bodies || !kernel_of(s->f64, want) || n <= ipb_of(want) ||       // likewise; >= 2 super-blocks,
+                                      sym_layer_bytes(n, ipb_of(want), s->esz) > 4.0 * kSymLayerBudget))                  // and layers that fit (pinned: 64 GB)
                 want = s->f64 ? Shape{kScalar, 4, 1, 1} : Shape{kPkSgpr, 8, 1, 4};
             if (kernel_of(s->f64, want)) { sh = want; pinned = true; }
         }
@@ -426,12 +442,16 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
         // waves, the j-pairs split over ws waves x q workgroups.  One scalar request (4 pairs, 256 issue cycles)
         // is in flight per wave and returns after ~1,100 cycles, so a SIMD needs > 4 resident waves to stay
         // busy.  Since its partial rows go out write-through (no release fence per workgroup) its split forms are the
-        // fastest step from N ~ 8,000 to ~ 18,000 (through the engine: 8,192 19.9 vs 20.4 us, 10,000 28.7 vs 31.7,
+        // fastest ORDERED-PAIR step from N ~ 8,000 to ~ 18,000 (through the engine: 8,192 19.9 vs 20.4 us, 10,000 28.7 vs 31.7,
         // 12,000 39.1 vs 41.2, 14,000 50.8 vs 51.4, 16,384 64.5 vs 65.3; level at 20,000 and behind above and below:
         // profiles/r02/shape_scan_jpk_sc1.txt).  The automatic choice offers it from 7,000 to 12,500, where it wins by 5-10 %
         // whatever split count this model lands on; from 13,000 to 20,000 the margin is 1-2 % with the best split and the
         // model's split choice is off by more than that (size_scan_jpk_auto.txt), so the SGPR step stays there.
-        if (may_fuse && (pinned ? sh.kind == kJpk : (!(cfg.flags & NB_FLAG_LDS_ONLY) && n >= 7000 && n <= 12500))) {
+        // The two bounds are model constants (ModelKnobs::jpk_lo / jpk_hi).  Scored at every size instead (profiles/r03/
+        // size_scan_2k_15k_jpk_no_window.txt) this cost model picks it at 5,000 / 6,000 (1-4 % behind the LDS-tile step) and at
+        // 13,000 (5 % behind the symmetric pass), and wins 8 % at 14,000: its estimate is good to ~5 %, the window is where it
+        // wins by more than that.
+        if (may_fuse && (pinned ? sh.kind == kJpk : (!(cfg.flags & NB_FLAG_LDS_ONLY) && n >= (uint32_t)mk.jpk_lo && n <= (uint32_t)mk.jpk_hi))) {
             const uint32_t units = ((ceil_div(ceil_div(n, 2u), 4u) + 1u) & ~1u);
             for (int x : {4, 8, 6}) {
                 const Shape jsh{kJpk, 1, 1, x};

@@ -345,7 +345,8 @@ class Simulation:
     def frame(self, wait=True):
         """Newest finished frame: (bodies f32 (n,4), speed f32 (n,), step index) -- views of the
         engine's pinned host memory, valid until the fourth request_frame() after the one that
-        produced them; None when wait=False and nothing has landed yet."""
+        produced them AND no longer than the handle itself (close() frees the memory: copy what
+        must outlive it); None when wait=False and nothing has landed yet."""
         pb, ps, st = C.POINTER(C.c_float)(), C.POINTER(C.c_float)(), C.c_uint64()
         rc = self._L.nb_frame_acquire(self._h, 1 if wait else 0, C.byref(pb), C.byref(ps), C.byref(st))
         if rc == NB_NOT_READY:

@@ -165,6 +165,8 @@ def test_handles_that_cannot_use_the_symmetric_pass_fall_back():
         assert "sgpr" in s.variant, s.variant
     with Simulation(n) as s:
         assert "symw" in s.variant, s.variant
+    with Simulation(2500000) as s:       # the traveler layers grow with N^2 (here 37 GB): past the 16 GB budget the ordered-pair kernel runs
+        assert "sgpr" in s.variant, s.variant
 
 
 # ---- fp64 (BASELINE config 5) ---------------------------------------------------------------------
