@@ -191,3 +191,49 @@ def test_no_packed_multiply_reads_a_reciprocal_square_root_issued_right_before_i
                 assert not (prev_op is not None and prev_op.startswith("v_rsq_f32") and (prev_dst & srcs)), (m.group(1), code)
             prev_op, prev_dst = op, vregs(rest.split(",")[0])
     assert kernels >= 20 and asm_muls >= 4 * kernels, (kernels, asm_muls)
+
+
+def test_symmetric_pass_rotation_loop_is_the_pair_arithmetic_and_the_rotation_only():
+    """The 64-step rotation loop of the symmetric force pass must carry exactly: per packed group of residents 16 packed
+    instructions + 2 v_rsq_f32 (f64: 19 double-precision instructions + v_rsq_f64 per resident), 10 (f64: 14) v_mov_b32_dpp
+    wave_ror:1 per traveler and step -- and nothing else: no scratch access (a second loop in the same kernel once made the
+    register allocator spill INTO this loop), no v_mov_b32 copies, no LDS traffic.  The measured issue rate (4.41 cycles per VALU
+    instruction, VALU instructions = 1.0015 x the pair arithmetic: profiles/r03/rocprof_f32_default) is this count."""
+    if shutil.which("/opt/rocm/bin/hipcc") is None and shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    if not os.path.exists(ASM):
+        subprocess.check_call(["make", "-C", CSRC, "-s", "asm"])
+    text = open(ASM).read()
+
+    def innermost_loops(body):
+        lines = [l.split(";")[0].strip() for l in body.splitlines()]
+        lines = [l for l in lines if l and (not l.startswith(".") or l.startswith(".LBB"))]
+        labels = {l[:-1]: i for i, l in enumerate(lines) if l.endswith(":")}
+        loops = []
+        for i, l in enumerate(lines):
+            m = re.match(r"s_cbranch_\w+\s+(\S+)", l)
+            if m and m.group(1) in labels and labels[m.group(1)] < i:
+                loops.append(lines[labels[m.group(1)]:i + 1])
+        rot = sorted((lp for lp in loops if any(o.startswith("v_mov_b32_dpp") for o in lp)), key=len)
+        return rot[:1]          # the rotation loop itself: the shortest loop that rotates
+
+    seen = 0
+    # (mangled prefix, residents' packed groups NG or residents IPL, travelers J, f64)
+    for pat, ng, j, f64 in ((r"_ZN2nb13nb_force_symwILi4ELi1EEE", 4, 1, False), (r"_ZN2nb13nb_force_symwILi4ELi2EEE", 4, 2, False),
+                            (r"_ZN2nb13nb_force_symwILi8ELi1EEE", 8, 1, False), (r"_ZN2nb12nb_force_symILi4ELi4ELi2EEE", 4, 2, False),
+                            (r"_ZN2nb15nb_force_symw64ILi8EEE", 8, 1, True)):
+        m = re.search(r"^(%s\w*):.*?$(.*?)^\.Lfunc_end" % pat, text, re.S | re.M)      # to the end of the function: an s_endpgm may sit mid-body
+        assert m, pat
+        loops = innermost_loops(m.group(2))
+        assert len(loops) == 1, (pat, len(loops))
+        ops = [l.split()[0] for l in loops[0] if not l.endswith(":")]
+        valu = [o for o in ops if o.startswith("v_")]
+        assert not any(o.startswith("scratch_") or o.startswith("ds_") or o.startswith("global_") or o.startswith("buffer_") for o in ops), pat
+        assert ops.count("v_mov_b32_dpp") == (14 if f64 else 10) * j, (pat, ops.count("v_mov_b32_dpp"))
+        if f64:
+            assert ops.count("v_rsq_f64_e32") == ng and len(valu) == ng * 20 + 14, (pat, len(valu))
+        else:
+            assert ops.count("v_rsq_f32_e32") == 2 * ng * j and sum(o.startswith("v_pk_") for o in valu) == 16 * ng * j, pat
+            assert len(valu) == (18 * ng + 10) * j, (pat, len(valu))
+        seen += 1
+    assert seen == 5
