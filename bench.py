@@ -381,9 +381,9 @@ def main():
     G, dt = 1.0, 1e-3
     bodies, vel = (ic.plummer(n, seed=1) if args.workload == "plummer" else ic.uniform_cube(n, seed=2))
     np_dtype = np.float64 if args.precision == "f64" else np.float32
-    # native exchange, f32: rows in whole super-blocks of 1,024, so that the ranks can take the rank form of the symmetric force
+    # native exchange: rows in whole super-blocks of 1,024 (f64: 512), so that the ranks can take the rank form of the symmetric force
     # pass (NB_FLAG_SYM_SHARD: each unordered pair evaluated by ONE rank, partial accelerations reduce-scattered by the engine)
-    sym_shard = dist_wanted and args.exchange == "native" and args.precision == "f32" and not args.variant and not (args.flags & capi.NB_FLAG_NO_SYM)
+    sym_shard = dist_wanted and args.exchange == "native" and not args.variant and not (args.flags & capi.NB_FLAG_NO_SYM)
     plan = ShardPlan(n, world, rank, align=1024 if sym_shard else 256)
     bodies_p, vel_p = plan.pad(bodies.astype(np_dtype)), plan.pad(vel.astype(np_dtype))
 

@@ -147,9 +147,9 @@ int rccl_reduce_scatter_A(nb_sim* s)
     nb_rccl* c = s->rccl;
     const RcclApi* api = rccl_api(nullptr);
     if (!c || !api) return fail(s, NB_ERR_COMM, "rccl_reduce_scatter_A: no communicator");
-    float* A = (float*)s->sym_A;
+    char* A = (char*)s->sym_A;
     const size_t count = (size_t)4 * s->sc;
-    const ncclResult_t r = api->ReduceScatter(A, A + (size_t)4 * s->sb, count, ncclFloat, ncclSum, c->comm, s->stream);
+    const ncclResult_t r = api->ReduceScatter(A, A + 4 * s->esz * s->sb, count, s->f64 ? ncclDouble : ncclFloat, ncclSum, c->comm, s->stream);
     if (r != ncclSuccess) return fail(s, NB_ERR_COMM, std::string("ncclReduceScatter: ") + api->GetErrorString(r));
     return NB_OK;
 }
@@ -316,8 +316,8 @@ int nb_multi_create(const nb_config* cfg_in, uint32_t n_shards, const int32_t* d
     m->esz = cfg.precision == NB_F64 ? 8 : 4;
     uint32_t rows = ceil_div(cfg.n, n_shards);
     // the rank form of the symmetric pass wants rows in whole super-blocks of 1,024 (f32, >= 2 shards, systems worth it)
-    const bool want_sym = cfg.precision != NB_F64 && n_shards >= 2 && rows >= 2048 && !(cfg.flags & NB_FLAG_NO_SYM) && cfg.force_variant == 0;
-    const uint32_t align = want_sym ? 1024u : (uint32_t)nb::kTile;
+    const bool want_sym = n_shards >= 2 && rows >= 2048 && !(cfg.flags & NB_FLAG_NO_SYM) && cfg.force_variant == 0;
+    const uint32_t align = want_sym ? (cfg.precision == NB_F64 ? 512u : 1024u) : (uint32_t)nb::kTile;      // whole super-blocks
     rows = ceil_div(rows, align) * align;                       // 256-aligned blocks (reference tile, nbody3d.js:4) at least
     m->rows = rows; m->padded_n = rows * n_shards;
     for (uint32_t k = 0; k < n_shards; ++k) {
@@ -355,7 +355,7 @@ int nb_multi_create(const nb_config* cfg_in, uint32_t n_shards, const int32_t* d
             hipEventCreateWithFlags(&m->ev_copied[k], hipEventDisableTiming) != hipSuccess ||
             (m->sym && (hipEventCreateWithFlags(&m->ev_a[k], hipEventDisableTiming) != hipSuccess ||
                         hipEventCreateWithFlags(&m->ev_rs[k], hipEventDisableTiming) != hipSuccess ||
-                        hipMalloc(&m->stage[k], (size_t)16 * rows * n_shards) != hipSuccess))) {
+                        hipMalloc(&m->stage[k], 4 * m->esz * rows * n_shards) != hipSuccess))) {
             nb_multi_destroy(m);
             return mfail(nullptr, NB_ERR_HIP, "nb_multi_create: event / staging creation failed");
         }
@@ -503,8 +503,8 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
                 ncclResult_t r = api->GroupStart();
                 for (uint32_t d = 0; d < g && r == ncclSuccess; ++d) {
                     nb_sim* s = m->shard[d];
-                    float* A = (float*)s->sym_A;
-                    r = api->ReduceScatter(A, A + (size_t)4 * m->rows * d, (size_t)4 * m->rows, ncclFloat, ncclSum, m->comms[d], s->stream);
+                    char* A = (char*)s->sym_A;
+                    r = api->ReduceScatter(A, A + blk * d, (size_t)4 * m->rows, m->esz == 8 ? ncclDouble : ncclFloat, ncclSum, m->comms[d], s->stream);
                 }
                 const ncclResult_t r2 = api->GroupEnd();
                 if (r == ncclSuccess) r = r2;
@@ -516,15 +516,15 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
                     for (uint32_t d = 0; d < g; ++d) {
                         nb_sim* src = m->shard[d];
                         if (d != e) NB_MHIP(m, hipStreamWaitEvent(dst->stream, m->ev_a[d], 0));
-                        NB_MHIP(m, hipMemcpyAsync((char*)m->stage[e] + (size_t)16 * m->rows * d, (const char*)src->sym_A + (size_t)16 * m->rows * e,
-                                                  (size_t)16 * m->rows, hipMemcpyDeviceToDevice, dst->stream));
+                        NB_MHIP(m, hipMemcpyAsync((char*)m->stage[e] + blk * d, (const char*)src->sym_A + blk * e, blk, hipMemcpyDeviceToDevice, dst->stream));
                     }
                     NB_MHIP(m, hipEventRecord(m->ev_rs[e], dst->stream));
-                    const float4* st = (const float4*)m->stage[e];
-                    float4* out = (float4*)dst->sym_A + (size_t)m->rows * e;
+                    const void* st = m->stage[e];
+                    void* out = (char*)dst->sym_A + blk * e;
                     uint32_t rows = m->rows, shards = g;
                     void* args[] = {&st, &out, &rows, &shards};
-                    NB_MHIP(m, hipLaunchKernel((const void*)&nb::nb_sym_sum_shards<0>, dim3((rows + nb::kBlock - 1) / nb::kBlock), dim3(nb::kBlock), args, 0, dst->stream));
+                    const void* fn = m->esz == 8 ? (const void*)&nb::nb_sym_sum_shards<double> : (const void*)&nb::nb_sym_sum_shards<float>;
+                    NB_MHIP(m, hipLaunchKernel(fn, dim3((rows + nb::kBlock - 1) / nb::kBlock), dim3(nb::kBlock), args, 0, dst->stream));
                 }
                 m->rs_pending = true;
             }

@@ -204,7 +204,7 @@ void name_variant(nb_sim* s, const Shape& sh)
     else if (sh.kind == kJpk)
         snprintf(buf, sizeof buf, "f32pk_fused_jpairs_ws%d_js%u", jpk_ws(sh.x), s->jsplit);
     else if (sh.kind == kSym)
-        snprintf(buf, sizeof buf, s->f64 ? "f64_symw_ipl%d_j%d_w%u_r%ut%u" : s->sym_rank ? "f32pk_symwrank_ipl%d_j%d_w%u_r%ut%u" : s->symw ? "f32pk_symw_ipl%d_j%d_w%u_r%ut%u" : "f32pk_sym_ipl%d_ws%d_q%u_r%ut%u", sh.ipl, s->symw ? (sh.x == 3 ? 1 : 2) : sh.x,
+        snprintf(buf, sizeof buf, s->f64 ? (s->sym_rank ? "f64_symwrank_ipl%d_j%d_w%u_r%ut%u" : "f64_symw_ipl%d_j%d_w%u_r%ut%u") : s->sym_rank ? "f32pk_symwrank_ipl%d_j%d_w%u_r%ut%u" : s->symw ? "f32pk_symw_ipl%d_j%d_w%u_r%ut%u" : "f32pk_sym_ipl%d_ws%d_q%u_r%ut%u", sh.ipl, s->symw ? (sh.x == 3 ? 1 : 2) : sh.x,
                  s->sym_plan[2], s->sym_plan[8] - s->sym_plan[7], s->sym_layers - (s->sym_plan[8] - s->sym_plan[7]));     // words 7, 8: r_layer0, t_layer0 in both plans
     else
         snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.kind == kPkLds ? "pk" : "",
@@ -352,9 +352,10 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
     // NB_FLAG_SYM_SHARD: a rank's shard whose cross-rank reduction the engine's native exchange provides takes the RANK form of the
     // symmetric pass when its rows are whole super-blocks (1,024 rows, or 512); otherwise the flag is ignored
     int rank_ipl = 0;
-    if ((cfg.flags & NB_FLAG_SYM_SHARD) && !(cfg.flags & NB_FLAG_NO_SYM) && !s->f64 && !cfg.ext_bodies && cfg.shard_count != 0)
+    if ((cfg.flags & NB_FLAG_SYM_SHARD) && !(cfg.flags & NB_FLAG_NO_SYM) && !cfg.ext_bodies && cfg.shard_count != 0)
         for (uint32_t S : {1024u, 512u})
-            if (!rank_ipl && s->sb % S == 0 && sc % S == 0 && n % S == 0 && n / S >= 2 && sym_layer_bytes(n, S, 4) <= kSymLayerBudget) rank_ipl = (int)(S / 64u);
+            if (!rank_ipl && !(s->f64 && S != 512u) && s->sb % S == 0 && sc % S == 0 && n % S == 0 && n / S >= 2 &&        // f64: 8 residents per lane only
+                sym_layer_bytes(n, S, s->esz) <= kSymLayerBudget) rank_ipl = (int)(S / 64u);
     const uint32_t variant = rank_ipl ? 0u : cfg.force_variant;
     bool pinned = false;
     if (rank_ipl) { sh = {kSym, rank_ipl, 1, 3}; pinned = true; if (js == 0) js = 0xffffffffu; }     // js: placeholder, set with the plan below
@@ -905,32 +906,47 @@ namespace nbi {
 
 // Rank form of the symmetric pass, first half of a step: the force pass over the chunk lists of the handle's own super-blocks,
 // then this rank's sums for every row of the system into sym_A.
+template <typename T>
+int sym_rank_phase_a_t(nb_sim* s)
+{
+    using V4 = typename nb::vec4<T>::type;
+    launch_force<T>(s);
+    nb::SymWPlan pl;
+    memcpy(&pl, s->sym_plan, sizeof pl);
+    const nb::SymRowT<T>* p = (const nb::SymRowT<T>*)s->partial;
+    const uint32_t* tab = s->sym_tab;
+    V4* A = (V4*)s->sym_A;
+    uint32_t S = ipb_of(shape_of(s)), g0 = s->sym_g0, g1 = s->sym_g1;
+    void* args[] = {&p, &tab, &A, &pl, &S, &g0, &g1};
+    NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_sym_reduce<T>, dim3(ceil_div(pl.np, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
+    return NB_OK;
+}
+
 int sym_rank_phase_a(nb_sim* s)
 {
     if (!s->sym_rank) return fail(s, NB_ERR_STATE, "sym_rank_phase_a: not a rank-form handle");
     if (int rc = ensure_gm(s)) return rc;
-    launch_force<float>(s);
-    nb::SymWPlan pl;
-    memcpy(&pl, s->sym_plan, sizeof pl);
-    const nb::SymRow* p = (const nb::SymRow*)s->partial;
-    const uint32_t* tab = s->sym_tab;
-    float4* A = (float4*)s->sym_A;
-    uint32_t S = ipb_of(shape_of(s)), g0 = s->sym_g0, g1 = s->sym_g1;
-    void* args[] = {&p, &tab, &A, &pl, &S, &g0, &g1};
-    NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_sym_reduce<0>, dim3(ceil_div(pl.np, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
+    return s->f64 ? sym_rank_phase_a_t<double>(s) : sym_rank_phase_a_t<float>(s);
+}
+
+template <typename T>
+int sym_rank_phase_b_t(nb_sim* s)
+{
+    using V4 = typename nb::vec4<T>::type;
+    V4 *b = (V4*)s->bodies[s->cur], *v = (V4*)s->vel, *a = (V4*)s->acc;
+    const V4* p = (const V4*)s->sym_A + s->sb;
+    uint32_t sb = s->sb, sc = s->sc, js = 1;
+    T dt = (T)s->dt, G = (T)s->G;
+    V4* gout = nullptr;                              // the (x, y, z, G*m) copy is rebuilt whole after the position all-gather
+    void* args[] = {&b, &v, &a, &p, &sb, &sc, &js, &dt, &gout, &G};
+    NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_integrate<T, 1>, dim3(ceil_div(sc, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
     return NB_OK;
 }
 
 // Second half: the plain integrate kernel on the handle's rows of the (reduce-scattered) sym_A.
 int sym_rank_phase_b(nb_sim* s)
 {
-    float4 *b = (float4*)s->bodies[s->cur], *v = (float4*)s->vel, *a = (float4*)s->acc;
-    const float4* p = (const float4*)s->sym_A + s->sb;
-    uint32_t sb = s->sb, sc = s->sc, js = 1;
-    float dt = (float)s->dt, G = (float)s->G;
-    float4* gout = nullptr;                          // the (x, y, z, G*m) copy is rebuilt whole after the position all-gather
-    void* args[] = {&b, &v, &a, &p, &sb, &sc, &js, &dt, &gout, &G};
-    NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_integrate<float, 1>, dim3(ceil_div(sc, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
+    if (int rc = s->f64 ? sym_rank_phase_b_t<double>(s) : sym_rank_phase_b_t<float>(s)) return rc;
     ++s->steps_done;
     s->gm_ok = false;
     return NB_OK;
@@ -1021,7 +1037,7 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     NB_HIPC(hipMalloc(&s->acc, row * s->sc));
     if (s->sym) {
         NB_HIPC(hipMalloc(&s->partial, (size_t)3 * s->esz * s->sym_np * s->sym_layers));       // layers of (x, y, z) rows: 12 bytes (24 in f64)
-        if (s->sym_rank) NB_HIPC(hipMalloc(&s->sym_A, (size_t)16 * s->sym_np));
+        if (s->sym_rank) NB_HIPC(hipMalloc(&s->sym_A, 4 * s->esz * s->sym_np));
         if (s->symw) {
             NB_HIPC(hipMalloc((void**)&s->sym_tab, sizeof(uint32_t) * s->sym_tab_host.size()));
             NB_HIPC(hipMemcpy(s->sym_tab, s->sym_tab_host.data(), sizeof(uint32_t) * s->sym_tab_host.size(), hipMemcpyHostToDevice));

@@ -1420,38 +1420,52 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
 // resident layers (own rows only) and the traveler layers written by the rank's own super-blocks, in the order
 // nb_integrate_symw uses -- into one array A[np]; the ranks then reduce-scatter A (ncclReduceScatter, or peer copies + a
 // fixed-order sum in the single-process handle) and the plain integrate kernel reads the rank's rows of the result.
-template <int UNUSED = 0>
-__global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRow* __restrict__ partial, const uint32_t* __restrict__ gtab, float4* __restrict__ A,
-                                                       const SymWPlan pl, uint32_t S, uint32_t g0, uint32_t g1)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __restrict__ partial, const uint32_t* __restrict__ gtab,
+                                                       typename vec4<T>::type* __restrict__ A, const SymWPlan pl, uint32_t S, uint32_t g0, uint32_t g1)
 {
+    using SymRow = SymRowT<T>;
+    using V4 = typename vec4<T>::type;
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= pl.np) return;
     const uint32_t b = j / S;
-    float sx = 0, sy = 0, sz = 0;
+    T sx = 0, sy = 0, sz = 0;
     if (b >= g0 && b < g1) {
         const uint32_t nr = gtab[2 * b + 1];
         for (uint32_t e = 0; e < nr; ++e) { const SymRow r = partial[(size_t)(pl.r_layer0 + e) * pl.np + j]; sx += r.x; sy += r.y; sz += r.z; }
     }
-    for (uint32_t d = 0; d <= pl.H; ++d) {                       // ascending ring distance, as nb_integrate_symw
-        uint32_t g = b + pl.nsb - 1 - d;
-        if (g >= pl.nsb) g -= pl.nsb;
-        if (g < g0 || g >= g1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
-        const SymRow r = partial[(size_t)(pl.t_layer0 + d) * pl.np + j];
-        sx += r.x; sy += r.y; sz += r.z;
+    if (g1 - g0 > pl.H) {
+        for (uint32_t d = 0; d <= pl.H; ++d) {                   // few ring distances, many own super-blocks: ascending distance
+            uint32_t g = b + pl.nsb - 1 - d;
+            if (g >= pl.nsb) g -= pl.nsb;
+            if (g < g0 || g >= g1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
+            const SymRow r = partial[(size_t)(pl.t_layer0 + d) * pl.np + j];
+            sx += r.x; sy += r.y; sz += r.z;
+        }
+    } else {
+        for (uint32_t g = g0; g < g1; ++g) {                     // a rank of many: only its own super-blocks can have written a layer of row j
+            uint32_t d = b + pl.nsb - 1 - g;
+            if (d >= pl.nsb) d -= pl.nsb;
+            if (d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
+            const SymRow r = partial[(size_t)(pl.t_layer0 + d) * pl.np + j];
+            sx += r.x; sy += r.y; sz += r.z;
+        }
     }
-    A[j] = float4{sx, sy, sz, 0};
+    A[j] = V4{sx, sy, sz, 0};
 }
 
 // The single-process multi-device handle's reduce-scatter by peer copies: stage[d] holds shard d's A rows for THIS shard's
 // row block (shard d = own: its own A); summed in ascending shard order -- deterministic.
-template <int UNUSED = 0>
-__global__ __launch_bounds__(kBlock) void nb_sym_sum_shards(const float4* __restrict__ stage, float4* __restrict__ out, uint32_t rows, uint32_t shards)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_sym_sum_shards(const typename vec4<T>::type* __restrict__ stage, typename vec4<T>::type* __restrict__ out,
+                                                           uint32_t rows, uint32_t shards)
 {
+    using V4 = typename vec4<T>::type;
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= rows) return;
-    float sx = 0, sy = 0, sz = 0;
-    for (uint32_t d = 0; d < shards; ++d) { const float4 r = ld4(stage + (size_t)d * rows + i); sx += r.x; sy += r.y; sz += r.z; }
-    out[i] = float4{sx, sy, sz, 0};
+    T sx = 0, sy = 0, sz = 0;
+    for (uint32_t d = 0; d < shards; ++d) { const V4 r = ld4(stage + (size_t)d * rows + i); sx += r.x; sy += r.y; sz += r.z; }
+    out[i] = V4{sx, sy, sz, 0};
 }
 
 // K2 for the wave-granular form: resident layers gtab[2g+1] (waves that worked on g's list), then the traveler layers.

@@ -260,6 +260,8 @@ def test_rank_form_is_not_taken_when_the_rows_are_not_whole_super_blocks_or_with
     with Simulation(n, shard=(8192, 8192), flags=capi.NB_FLAG_SYM_SHARD | capi.NB_FLAG_NO_SYM) as s:
         assert "sym" not in s.variant, s.variant
     with Simulation(n, shard=(8192, 8192), precision="f64", flags=capi.NB_FLAG_SYM_SHARD) as s:
+        assert s.variant.startswith("f64_symwrank_ipl8"), s.variant
+    with Simulation(n, shard=(8192, 8192), precision="f64") as s:
         assert s.variant.startswith("f64_lds"), s.variant
     with Simulation(n, shard=(8192, 8192), flags=capi.NB_FLAG_SYM_SHARD) as s:
         assert "symwrank" in s.variant, s.variant
@@ -320,3 +322,23 @@ def test_multi_handle_rank_form_at_G_not_one_and_mid_run_restore():
         ke, pe, mom = ms.diagnostics()
     rke, rpe, _ = oracle.energy(after[0], after[1], 0.05)
     assert abs(ke - rke) < 1e-9 * abs(rke) and abs(pe - rpe) < 1e-6 * abs(rpe)
+
+
+@pytest.mark.parametrize("n,g", [(16384, 4), (20000, 3)])
+def test_f64_multi_handle_takes_the_rank_form(n, g):
+    """The fp64 rank form (512-row super-blocks): g virtual shards against the fp64 oracle at 1e-12 and the single fp64 handle."""
+    from nbody3d_amd import MultiSimulation
+    b, v = ic.plummer(n, seed=90) if n % 2 == 0 else ic.uniform_cube(n, seed=90)
+    b, v = b.astype(np.float64), v.astype(np.float64)
+    with MultiSimulation(n, g, precision="f64") as ms:
+        assert ms.variant.startswith("f64_symwrank"), ms.variant
+        ms.init(b, v)
+        ms.simulate(4, 1e-3, 1.0)
+        got = ms.read()
+    rb, rv, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 4)
+    assert rel_pos_err(got[0], rb, 1.0) < 1e-12
+    assert np.abs(got[2][:, :3] - ra[:, :3]).max() < 1e-12 * np.abs(ra[:, :3]).max()
+    with Simulation(n, precision="f64", shard=(0, (n + 511) // 512 * 512) if False else None) as one:
+        one.init(b, v)
+        one.simulate(4, 1e-3, 1.0)
+        assert rel_pos_err(got[0], one.read()[0], 1.0) < 1e-12
