@@ -230,10 +230,14 @@ int nb_rccl_info(nb_sim *s, int *nranks, int *rank, int *rccl_version);
  * nb_multi_* wraps n_shards shard handles: shard k owns a contiguous block of
  * rows (256-aligned; the system is padded with zero-mass rows at the origin,
  * which exert and feel exactly nothing) on device devices[k].  After every
- * step each shard's new rows are copied straight into every other shard's
- * replicated bodies array (g*(g-1) device-to-device copies, ordered with HIP
- * events): on the fully connected xGMI fabric of an 8-GPU node every copy has
- * its own link, which is the all-gather the topology wants.  devices == NULL
+ * step each shard pulls the other shards' new rows straight into its
+ * replicated bodies array (one pull kernel per shard over peer-mapped memory,
+ * ordered with HIP events; g*(g-1) device-to-device copies when peer access is
+ * missing): on the fully connected xGMI fabric of an 8-GPU node every transfer
+ * has its own link, which is the all-gather the topology wants.  f32 / f64
+ * systems with >= 2,048 rows per shard divide the PAIRS instead of the rows (rank
+ * form of the symmetric force pass, see NB_FLAG_SYM_SHARD) and reduce-scatter
+ * their partial accelerations the same way before the integrate kernel.  devices == NULL
  * -> round-robin over the visible devices; several shards may share a device
  * ("virtual shards": the way the partition logic is tested on one GPU).
  * Host arrays hold the UNPADDED n rows, exactly as for a single handle. */

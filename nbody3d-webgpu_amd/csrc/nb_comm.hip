@@ -266,6 +266,12 @@ struct nb_multi {
     std::vector<hipEvent_t> ev_a, ev_rs;        // per shard: "sym_A complete", "this shard has copied what it needs of the others' sym_A"
     std::vector<void*> stage;                   // per shard: g x rows float4
     bool rs_pending = false;
+    bool pull = false;                          // peer exchanges as one pull kernel per shard (g <= 16, every pair of devices peer-accessible)
+    // "every shard has reached X" as ONE event: a hub stream (on shard 0's device) waits for the g per-shard events and records
+    // the hub event every shard then waits for -- 2 g stream waits per dependency instead of g (g - 1) (at g = 8: 64 instead of 224
+    // per step; the host thread spends ~1.7 us per call)
+    hipStream_t hub = nullptr;
+    hipEvent_t ev_hub[4] = {nullptr, nullptr, nullptr, nullptr};   // 0: sym_A complete, 1: sym_A consumed, 2: rows written, 3: rows gathered
     int mode = NB_MULTI_PEER;
     std::vector<ncclComm_t> comms;               // NB_MULTI_RCCL: one per shard (ncclCommInitAll)
     std::vector<char> pad_b, pad_v, pad_a;       // host staging for the zero-mass padding rows
@@ -345,10 +351,23 @@ int nb_multi_create(const nb_config* cfg_in, uint32_t n_shards, const int32_t* d
                 if (e != hipSuccess) (void)hipGetLastError();   // hipErrorPeerAccessAlreadyEnabled is fine
             }
         }
+    // pull kernels need every shard's memory mapped on every other shard's device
+    m->pull = n_shards <= 16;
+    for (uint32_t a = 0; a < n_shards && m->pull; ++a)
+        for (uint32_t b = 0; b < n_shards; ++b) {
+            const int da = m->shard[a]->device, db = m->shard[b]->device;
+            int can = 1;
+            if (da != db && (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can)) { m->pull = false; break; }
+        }
     m->ev_k2.resize(n_shards); m->ev_copied.resize(n_shards);
     m->sym = want_sym;
     for (nb_sim* s : m->shard) if (!s->sym_rank) m->sym = false;
     m->ev_a.assign(n_shards, nullptr); m->ev_rs.assign(n_shards, nullptr); m->stage.assign(n_shards, nullptr);
+    {
+        bool ok = hipSetDevice(m->shard[0]->device) == hipSuccess && hipStreamCreateWithFlags(&m->hub, hipStreamNonBlocking) == hipSuccess;
+        for (auto& e : m->ev_hub) ok = ok && hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        if (!ok) { nb_multi_destroy(m); return mfail(nullptr, NB_ERR_HIP, "nb_multi_create: hub stream / events"); }
+    }
     for (uint32_t k = 0; k < n_shards; ++k) {
         if (hipSetDevice(m->shard[k]->device) != hipSuccess ||
             hipEventCreateWithFlags(&m->ev_k2[k], hipEventDisableTiming) != hipSuccess ||
@@ -380,6 +399,9 @@ void nb_multi_destroy(nb_multi* m)
         if (k < m->ev_rs.size() && m->ev_rs[k]) (void)hipEventDestroy(m->ev_rs[k]);
         if (k < m->stage.size() && m->stage[k]) (void)hipFree(m->stage[k]);
     }
+    if (!m->shard.empty()) (void)hipSetDevice(m->shard[0]->device);
+    for (auto& e : m->ev_hub) if (e) (void)hipEventDestroy(e);
+    if (m->hub) { (void)hipStreamSynchronize(m->hub); (void)hipStreamDestroy(m->hub); }
     for (nb_sim* s : m->shard) nb_destroy(s);
     delete m;
 }
@@ -472,14 +494,20 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
     const RcclApi* api = m->mode == NB_MULTI_RCCL ? rccl_api(nullptr) : nullptr;
     if (m->mode == NB_MULTI_RCCL && !api) return mfail(m, NB_ERR_COMM, "nb_multi_step: RCCL is not loaded");
     if (m->sym && !m->shard[0]->uploaded) return mfail(m, NB_ERR_STATE, "nb_multi_step: nb_multi_upload has not been called");
+    // hub event `which` := all of `evs` (already recorded on the shards' streams)
+    auto join = [&](const std::vector<hipEvent_t>& evs, int which) -> hipError_t {
+        hipError_t e = hipSetDevice(m->shard[0]->device);
+        for (uint32_t d = 0; d < g && e == hipSuccess; ++d) e = hipStreamWaitEvent(m->hub, evs[d], 0);
+        if (e == hipSuccess) e = hipEventRecord(m->ev_hub[which], m->hub);
+        return e;
+    };
     for (uint32_t k = 0; k < nsteps; ++k) {
         // force + integrate on every shard (asynchronous on the shard's own stream)
         for (uint32_t d = 0; d < g && !m->sym; ++d) {
             nb_sim* s = m->shard[d];
             NB_MHIP(m, hipSetDevice(s->device));
             if (m->copied_pending)      // nobody may still be reading the rows this shard is about to overwrite
-                for (uint32_t e = 0; e < g; ++e)
-                    if (e != d) NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_copied[e], 0));
+                NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_hub[3], 0));
             int rc = nb_step(s, 1);
             if (rc != NB_OK) return mfail(m, rc, s->err);
             if (m->mode == NB_MULTI_PEER) NB_MHIP(m, hipEventRecord(m->ev_k2[d], s->stream));
@@ -490,9 +518,8 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
             for (uint32_t d = 0; d < g; ++d) {
                 nb_sim* s = m->shard[d];
                 NB_MHIP(m, hipSetDevice(s->device));
-                if (m->rs_pending)       // the other shards may still be copying out of this shard's sym_A (previous step)
-                    for (uint32_t e = 0; e < g; ++e)
-                        if (e != d) NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_rs[e], 0));
+                if (m->rs_pending)       // the other shards may still be reading this shard's sym_A (previous step)
+                    NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_hub[1], 0));
                 // (the positions this pass reads were completed on this stream by the previous step's gather)
                 int rc = nbi::sym_rank_phase_a(s);
                 if (rc != NB_OK) return mfail(m, rc, s->err);
@@ -510,12 +537,25 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
                 if (r == ncclSuccess) r = r2;
                 if (r != ncclSuccess) return mfail(m, NB_ERR_COMM, std::string("nb_multi_step: ncclReduceScatter: ") + api->GetErrorString(r));
             } else {
+                NB_MHIP(m, join(m->ev_a, 0));
                 for (uint32_t e = 0; e < g; ++e) {
                     nb_sim* dst = m->shard[e];
                     NB_MHIP(m, hipSetDevice(dst->device));
+                    NB_MHIP(m, hipStreamWaitEvent(dst->stream, m->ev_hub[0], 0));        // every shard's sym_A is complete
+                    if (m->pull) {
+                        // ONE pull kernel: reads the rows this shard owns out of every shard's sym_A, sums in shard order
+                        nb::PeerPtrs pp{};
+                        for (uint32_t d = 0; d < g; ++d) pp.p[d] = m->shard[d]->sym_A;
+                        void* out = (char*)dst->sym_A + blk * e;   // in place: the other shards read THEIR row blocks of this array, never this one
+                        uint32_t rows = m->rows, shards = g, me = e;
+                        void* args[] = {&pp, &out, &rows, &shards, &me};
+                        const void* fn = m->esz == 8 ? (const void*)&nb::nb_peer_sum<double> : (const void*)&nb::nb_peer_sum<float>;
+                        NB_MHIP(m, hipLaunchKernel(fn, dim3((rows + nb::kBlock - 1) / nb::kBlock), dim3(nb::kBlock), args, 0, dst->stream));
+                        NB_MHIP(m, hipEventRecord(m->ev_rs[e], dst->stream));
+                        continue;
+                    }
                     for (uint32_t d = 0; d < g; ++d) {
                         nb_sim* src = m->shard[d];
-                        if (d != e) NB_MHIP(m, hipStreamWaitEvent(dst->stream, m->ev_a[d], 0));
                         NB_MHIP(m, hipMemcpyAsync((char*)m->stage[e] + blk * d, (const char*)src->sym_A + blk * e, blk, hipMemcpyDeviceToDevice, dst->stream));
                     }
                     NB_MHIP(m, hipEventRecord(m->ev_rs[e], dst->stream));
@@ -526,6 +566,7 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
                     const void* fn = m->esz == 8 ? (const void*)&nb::nb_sym_sum_shards<double> : (const void*)&nb::nb_sym_sum_shards<float>;
                     NB_MHIP(m, hipLaunchKernel(fn, dim3((rows + nb::kBlock - 1) / nb::kBlock), dim3(nb::kBlock), args, 0, dst->stream));
                 }
+                NB_MHIP(m, join(m->ev_rs, 1));
                 m->rs_pending = true;
             }
             // (c) integrate every shard's own rows
@@ -533,8 +574,7 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
                 nb_sim* s = m->shard[d];
                 NB_MHIP(m, hipSetDevice(s->device));
                 if (m->copied_pending)      // nobody may still be reading the rows this shard is about to overwrite
-                    for (uint32_t e = 0; e < g; ++e)
-                        if (e != d) NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_copied[e], 0));
+                    NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_hub[3], 0));
                 int rc = nbi::sym_rank_phase_b(s);
                 if (rc != NB_OK) return mfail(m, rc, s->err);
                 if (m->mode == NB_MULTI_PEER) NB_MHIP(m, hipEventRecord(m->ev_k2[d], s->stream));
@@ -558,18 +598,31 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
             continue;
         }
         // all-gather by direct copies: shard e pulls the new rows of every other shard d
+        NB_MHIP(m, join(m->ev_k2, 2));
         for (uint32_t e = 0; e < g; ++e) {
             nb_sim* dst = m->shard[e];
             NB_MHIP(m, hipSetDevice(dst->device));
+            NB_MHIP(m, hipStreamWaitEvent(dst->stream, m->ev_hub[2], 0));        // every shard has written its new rows
+            if (m->pull) {               // one pull kernel instead of g - 1 copies
+                nb::PeerPtrs pp{};
+                for (uint32_t d = 0; d < g; ++d) pp.p[d] = m->shard[d]->bodies[m->shard[d]->cur];
+                void* out = dst->bodies[dst->cur];
+                uint32_t rows = m->rows, shards = g, me = e;
+                void* args[] = {&pp, &out, &rows, &shards, &me};
+                const void* fn = m->esz == 8 ? (const void*)&nb::nb_peer_gather<double> : (const void*)&nb::nb_peer_gather<float>;
+                NB_MHIP(m, hipLaunchKernel(fn, dim3((rows * shards + nb::kBlock - 1) / nb::kBlock), dim3(nb::kBlock), args, 0, dst->stream));
+                NB_MHIP(m, hipEventRecord(m->ev_copied[e], dst->stream));
+                continue;
+            }
             for (uint32_t d = 0; d < g; ++d) {
                 if (d == e) continue;
                 nb_sim* src = m->shard[d];
-                NB_MHIP(m, hipStreamWaitEvent(dst->stream, m->ev_k2[d], 0));
                 NB_MHIP(m, hipMemcpyAsync((char*)dst->bodies[dst->cur] + blk * d, (const char*)src->bodies[src->cur] + blk * d, blk,
                                           hipMemcpyDeviceToDevice, dst->stream));
             }
             NB_MHIP(m, hipEventRecord(m->ev_copied[e], dst->stream));
         }
+        NB_MHIP(m, join(m->ev_copied, 3));
         m->copied_pending = true;
         for (nb_sim* s : m->shard) s->gm_ok = false;         // as above
     }

@@ -1468,6 +1468,38 @@ __global__ __launch_bounds__(kBlock) void nb_sym_sum_shards(const typename vec4<
     out[i] = V4{sx, sy, sz, 0};
 }
 
+// The single-process multi-device handle's exchanges as PULL kernels (peer access: a kernel on device e reads the other
+// shards' arrays directly): one launch per shard instead of g - 1 hipMemcpyAsync -- the host thread that drives all g devices
+// issued ~120 copies per step at g = 8 (0.9-1.4 ms of host time against a 1.4 ms step, profiles/r03/multi_host_cost.txt).
+struct PeerPtrs { const void* p[16]; };
+
+// reduce-scatter: out[i] = sum over shards d (ascending: deterministic) of A_d[e * rows + i]
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_peer_sum(const PeerPtrs src, typename vec4<T>::type* __restrict__ out, uint32_t rows, uint32_t shards, uint32_t e)
+{
+    using V4 = typename vec4<T>::type;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= rows) return;
+    T sx = 0, sy = 0, sz = 0;
+    for (uint32_t d = 0; d < shards; ++d) {
+        const V4 r = ld4((const V4*)src.p[d] + (size_t)e * rows + i);
+        sx += r.x; sy += r.y; sz += r.z;
+    }
+    out[i] = V4{sx, sy, sz, 0};
+}
+
+// all-gather: dst (shard e's replicated array) takes every other shard's own row block from that shard's array
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_peer_gather(const PeerPtrs src, typename vec4<T>::type* __restrict__ dst, uint32_t rows, uint32_t shards, uint32_t e)
+{
+    using V4 = typename vec4<T>::type;
+    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= rows * shards) return;
+    const uint32_t d = idx / rows;
+    if (d == e) return;
+    dst[idx] = ld4((const V4*)src.p[d] + idx);
+}
+
 // K2 for the wave-granular form: resident layers gtab[2g+1] (waves that worked on g's list), then the traveler layers.
 template <typename T, int R>
 __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::type* __restrict__ bodies, typename vec4<T>::type* __restrict__ vel,
