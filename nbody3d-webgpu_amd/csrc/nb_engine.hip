@@ -227,8 +227,8 @@ void name_variant(nb_sim* s, const Shape& sh)
 //   there are at most 128 splits.
 struct Cand { Shape sh; double cyc_iter; };   // SIMD cycles of one wave per loop iteration (= LS j-bodies)
 
-// Constants of the launch-shape model.  A release build compiles them in; a calibration build (make TUNING=1:
-// -DNB_TUNING, used by tools/fit_model.py) reads the NB_MODEL_* environment variables ONCE per process instead.
+// Constants of the launch-shape model.  A release build compiles them in; the calibration build (`make tuning`:
+// -DNB_TUNING, libnbody3d_hip_tuning.so, used by tools/fit_model.py) reads the NB_MODEL_* environment variables instead.
 struct ModelKnobs {
     double tile_latency = 3000.0, prologue = 3000.0, hand_over = 350.0, lanes_scale = 1.0;
     double boundary = 4e-6;    // K1 -> K2 boundary + the K2 launch (refit on shape_scan_final_2k_16k.txt:
@@ -237,35 +237,22 @@ struct ModelKnobs {
                                // (2.24-2.29 of 2.4 GHz measured, profiles/r02/rocprof_f32_default: GRBM_GUI_ACTIVE)
     double jpk_lo = 7000, jpk_hi = 12500;   // sizes at which the j-packed step is scored at all (see choose_shape)
 };
-const ModelKnobs& model_knobs()
-{
-    static const ModelKnobs k = [] {
-        ModelKnobs m;
 #ifdef NB_TUNING
-        auto knob = [](const char* name, double dflt) { const char* e = getenv(name); return e && *e ? atof(e) : dflt; };
-        m.tile_latency = knob("NB_MODEL_TILE_LATENCY", m.tile_latency); m.prologue = knob("NB_MODEL_PROLOGUE", m.prologue);
-        m.hand_over = knob("NB_MODEL_HANDOVER", m.hand_over); m.lanes_scale = knob("NB_MODEL_LANES_SCALE", m.lanes_scale);
-        m.boundary = knob("NB_MODEL_BOUNDARY", m.boundary); m.sustained = knob("NB_MODEL_SUSTAINED", m.sustained);
-        m.jpk_lo = knob("NB_MODEL_JPK_LO", m.jpk_lo); m.jpk_hi = knob("NB_MODEL_JPK_HI", m.jpk_hi);
-#endif
-        return m;
-    }();
-    return k;
+// calibration build: read on every nb_create, so that one process can walk a grid of constants (tools/fit_model.py)
+ModelKnobs model_knobs()
+{
+    ModelKnobs m;
+    auto knob = [](const char* name, double dflt) { const char* e = getenv(name); return e && *e ? atof(e) : dflt; };
+    m.tile_latency = knob("NB_MODEL_TILE_LATENCY", m.tile_latency); m.prologue = knob("NB_MODEL_PROLOGUE", m.prologue);
+    m.hand_over = knob("NB_MODEL_HANDOVER", m.hand_over); m.lanes_scale = knob("NB_MODEL_LANES_SCALE", m.lanes_scale);
+    m.boundary = knob("NB_MODEL_BOUNDARY", m.boundary); m.sustained = knob("NB_MODEL_SUSTAINED", m.sustained);
+    m.jpk_lo = knob("NB_MODEL_JPK_LO", m.jpk_lo); m.jpk_hi = knob("NB_MODEL_JPK_HI", m.jpk_hi);
+    return m;
 }
+#else
+inline ModelKnobs model_knobs() { return ModelKnobs(); }       // release build: the compiled-in constants, no environment access
+#endif
 
-// The symmetric pass, wave-granular form (nb_force_symw<NG, 1>): predicted step time for n bodies with 2*NG residents per lane
-// and k waves per SIMD.  A chunk-sweep is 64 rotation steps of NG * (16 packed + 2 transcendental) + 10 DPP issue slots; the
-// loop runs at 93.5 % of that.  The L chunk-sweeps are cut into W = k * SIMDs equal ranges:
-//   k = 1: ceil(L / SIMDs) sweeps per SIMD, 1.9 % slower per sweep (nothing hides a chunk's traveler loads);
-//   k = 2: a wave gets floor or ceil(L / 2 SIMDs) sweeps; with a share p of ceil-waves a SIMD's two waves both round up
-//          about min(1, 2p) of the time somewhere on the chip: 2 floor + 2 min(1, 2p) sweeps, 1 % over the bare rate
-//          (N = 40,002: 13.64 predicted, 13.66 measured; 32,768: 8.5 / 8.9; 65,536: 33 / 32.7; 14,000: 4 / 4.1);
-//   + 3.5 us of kernel fixed cost, 1.5 us per super-block a range touches, the K1 -> K2 boundary and K2's layer traffic
-//   (12 B per layer and body at ~5 TB/s: the layers are Infinity-Cache resident).  16 residents per lane run ~1.5 % closer to
-//   their issue count than 8 (half the rotations per pair).
-// Fitted on profiles/r03/sym_variants_scan_wave_granular*.txt (N = 12,000 .. 262,144, both resident counts: within 2 %);
-// k = 3 measured behind k = 2 (N = 131,072: 2,682 vs 2,615 us).
-struct SymChoice { int ipl; uint32_t k; double t; };
 // Bytes of partial-sum layers a symmetric handle allocates: one traveler layer per ring distance, i.e. ~ 3 * esz * N^2 / (2 S)
 // (N = 1,048,576 with 1,024-row super-blocks: 6.4 GB; it grows with N^2, so very large systems fall back to the ordered-pair kernels).
 double sym_layer_bytes(uint32_t n, uint32_t S, size_t esz)
@@ -307,7 +294,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
 {
     const uint32_t sc = s->sc, n = s->n;
     const uint32_t kMaxSplit = 128, kMinSplitLen = 128;
-    const ModelKnobs& mk = model_knobs();
+    const ModelKnobs mk = model_knobs();
     const double kTileLatency = mk.tile_latency, kPrologue = mk.prologue, kClock = clock_hz * mk.sustained;
     const double kHandOver = mk.hand_over, kLanesScale = mk.lanes_scale, kBoundary = mk.boundary;
     auto split_len = [&](uint32_t js) { return ceil_div(ceil_div(n, js), 8u) * 8u; };

@@ -5,7 +5,7 @@
     python tools/fit_model.py regret gpurun_out/model_picks.json profiles/r02/shape_scan_dma_*.txt
 
 `picks` creates a default handle at every scanned size for a grid of model constants (NB_MODEL_* environment
-variables, read by nb_create) and records which launch shape the model takes.  `regret` looks every pick up
+variables, read by nb_create in the -DNB_TUNING build of the library) and records which launch shape the model takes.  `regret` looks every pick up
 in the scanned (variant -> us/step) tables and prints, per constant set, the worst and mean regret."""
 import itertools
 import json
@@ -14,6 +14,8 @@ import re
 import sys
 
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+# the release library compiles the model constants in; the calibration build (make -C nbody3d-webgpu_amd/csrc tuning) reads NB_MODEL_*
+os.environ.setdefault("NB_ENGINE_LIB", os.path.join(ROOT, "nbody3d-webgpu_amd", "csrc", "libnbody3d_hip_tuning.so"))
 SIZES = [int(x) for x in os.environ.get("NB_FIT_SIZES", "1024,2048,3000,4096,5000,6000,7000,8192,10000,12000,14000,16384,20000,32768,40002,65536").split(",")]
 GRID = {"NB_MODEL_TILE_LATENCY": [3000, 2200], "NB_MODEL_HANDOVER": [350, 250, 150, 50, 0],
         "NB_MODEL_LANES_SCALE": [1.0, 1.03, 1.06, 1.09, 1.12], "NB_MODEL_BOUNDARY": [3e-6, 4e-6, 5e-6]}
