@@ -253,6 +253,7 @@ ModelKnobs model_knobs()
 inline ModelKnobs model_knobs() { return ModelKnobs(); }       // release build: the compiled-in constants, no environment access
 #endif
 
+
 // Bytes of partial-sum layers a symmetric handle allocates: one traveler layer per ring distance, i.e. ~ 3 * esz * N^2 / (2 S)
 // (N = 1,048,576 with 1,024-row super-blocks: 6.4 GB; it grows with N^2, so very large systems fall back to the ordered-pair kernels).
 double sym_layer_bytes(uint32_t n, uint32_t S, size_t esz)
