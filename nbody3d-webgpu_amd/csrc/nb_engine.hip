@@ -254,6 +254,20 @@ inline ModelKnobs model_knobs() { return ModelKnobs(); }       // release build:
 #endif
 
 
+// The symmetric pass, wave-granular form (nb_force_symw<NG, 1>): predicted step time for n bodies with 2*NG residents per lane
+// and k waves per SIMD.  A chunk-sweep is 64 rotation steps of NG * (16 packed + 2 transcendental) + 10 DPP issue slots; the
+// loop runs at 93.5 % of that.  The L chunk-sweeps are cut into W = k * SIMDs equal ranges:
+//   k = 1: ceil(L / SIMDs) sweeps per SIMD, 1.9 % slower per sweep (nothing hides a chunk's traveler loads);
+//   k = 2: a wave gets floor or ceil(L / 2 SIMDs) sweeps; with a share p of ceil-waves a SIMD's two waves both round up
+//          about min(1, 2p) of the time somewhere on the chip: 2 floor + 2 min(1, 2p) sweeps, 1 % over the bare rate
+//          (N = 40,002: 13.64 predicted, 13.66 measured; 32,768: 8.5 / 8.9; 65,536: 33 / 32.7; 14,000: 4 / 4.1);
+//   + 3.5 us of kernel fixed cost, 1.5 us per super-block a range touches, the K1 -> K2 boundary and K2's layer traffic
+//   (12 B per layer and body at ~5 TB/s: the layers are Infinity-Cache resident).  16 residents per lane run ~1.5 % closer to
+//   their issue count than 8 (half the rotations per pair).
+// Fitted on profiles/r03/sym_variants_scan_wave_granular*.txt (N = 12,000 .. 262,144, both resident counts: within 2 %);
+// k = 3 measured behind k = 2 (N = 131,072: 2,682 vs 2,615 us).
+struct SymChoice { int ipl; uint32_t k; double t; };
+
 // Bytes of partial-sum layers a symmetric handle allocates: one traveler layer per ring distance, i.e. ~ 3 * esz * N^2 / (2 S)
 // (N = 1,048,576 with 1,024-row super-blocks: 6.4 GB; it grows with N^2, so very large systems fall back to the ordered-pair kernels).
 double sym_layer_bytes(uint32_t n, uint32_t S, size_t esz)
