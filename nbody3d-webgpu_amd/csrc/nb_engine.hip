@@ -147,6 +147,7 @@ const void* kernel_of(bool f64, const Shape& sh)
             if (sh.ls != 1) return nullptr;
             if (f64) return sh.ipl == 8 && sh.x == 3 ? (const void*)&nb::nb_force_symw64<8> : nullptr;      // 8 residents, 1 traveler per lane
             if (sh.x == 4) return sh.ipl == 8 ? (const void*)&nb::nb_force_sym<4, 4, 2> : nullptr;
+            if (sh.ipl == 4) return sh.x == 3 ? (const void*)&nb::nb_force_symw<2, 1> : nullptr;      // finer chunk-sweeps for N ~ 14k-18k
             if (sh.ipl == 8) return sh.x == 1 ? (const void*)&nb::nb_force_symw<4, 2> : sh.x == 3 ? (const void*)&nb::nb_force_symw<4, 1> : nullptr;
             if (sh.ipl == 16) return sh.x == 1 ? (const void*)&nb::nb_force_symw<8, 2> : sh.x == 3 ? (const void*)&nb::nb_force_symw<8, 1> : nullptr;
             return nullptr;
@@ -265,6 +266,7 @@ inline ModelKnobs model_knobs() { return ModelKnobs(); }       // release build:
 //   (12 B per layer and body at ~5 TB/s: the layers are Infinity-Cache resident).  16 residents per lane run ~1.5 % closer to
 //   their issue count than 8 (half the rotations per pair).
 // Fitted on profiles/r03/sym_variants_scan_wave_granular*.txt (N = 12,000 .. 262,144, both resident counts: within 2 %);
+// 4 residents per lane (half the chunk-sweep of 8: finer rounding) win from N ~ 14,000 to 18,000 (sym_4_residents_per_lane.txt);
 // k = 3 measured behind k = 2 (N = 131,072: 2,682 vs 2,615 us).
 struct SymChoice { int ipl; uint32_t k; double t; };
 
@@ -280,7 +282,7 @@ constexpr double kSymLayerBudget = 16.0e9;
 SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64)
 {
     SymChoice best{0, 0, 1e300};
-    for (int ipl : {8, 16}) {
+    for (int ipl : {4, 8, 16}) {
         if (f64 && ipl != 8) continue;              // nb_force_symw64<8>: 8 residents per lane, 19 DP instructions + v_rsq_f64 per pair
         const uint32_t NG = (uint32_t)ipl / 2, S = 64u * (uint32_t)ipl, cps = S / 64u;
         const uint32_t nsb = ceil_div(n, S);

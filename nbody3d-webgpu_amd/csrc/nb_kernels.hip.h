@@ -1209,11 +1209,12 @@ struct SymWPlan {
 };
 
 template <int NG, int J>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : 4)))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : (NG < 4 ? 8 : 4))))
 void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ partial, const uint32_t* __restrict__ gtab, const SymWPlan pl,
                    const uint32_t n, const float eps2)
 {
     constexpr uint32_t S = 128u * NG;          // rows per super-block = one wave's residents
+    constexpr int GW = NG < 4 ? NG : 4;        // packed groups evaluated stage-major together
     constexpr uint32_t CH = 64u * J;           // travelers per chunk
     constexpr uint32_t CPS = S / CH;           // chunks per super-block
     const int lane = threadIdx.x & 63;
@@ -1264,42 +1265,42 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
                 for (int u = 0; u < J; ++u) {
                     const nb_f2 px = nb_f2{tx[u], tx[u]}, py = nb_f2{ty[u], ty[u]}, pz = nb_f2{tz[u], tz[u]}, pm = nb_f2{tm[u], tm[u]};
 #pragma unroll
-                    for (int c0g = 0; c0g < NG; c0g += 4) {          // stage-major over groups of four
-                        nb_f2 dx[4], dy[4], dz[4], d2[4], r[4], si[4], sj[4];
+                    for (int c0g = 0; c0g < NG; c0g += GW) {         // stage-major over groups of (up to) four
+                        nb_f2 dx[GW], dy[GW], dz[GW], d2[GW], r[GW], si[GW], sj[GW];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) dx[c] = px - xi[c0g + c];                                   // :233
+                        for (int c = 0; c < GW; ++c) dx[c] = px - xi[c0g + c];                                   // :233
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) dy[c] = py - yi[c0g + c];
+                        for (int c = 0; c < GW; ++c) dy[c] = py - yi[c0g + c];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) dz[c] = pz - zi[c0g + c];
+                        for (int c = 0; c < GW; ++c) dz[c] = pz - zi[c0g + c];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
+                        for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+                        for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+                        for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) r[c] = d2[c] * d2[c];                                       // :235
+                        for (int c = 0; c < GW; ++c) r[c] = d2[c] * d2[c];                                       // :235
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) r[c] = r[c] * d2[c];
+                        for (int c = 0; c < GW; ++c) r[c] = r[c] * d2[c];
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+                        for (int c = 0; c < GW; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
+                        for (int c = 0; c < GW; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) sj[c] = mi[c0g + c] * r[c];       // (G m_i) inv: traveler side
+                        for (int c = 0; c < GW; ++c) sj[c] = mi[c0g + c] * r[c];       // (G m_i) inv: traveler side
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
+                        for (int c = 0; c < GW; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
+                        for (int c = 0; c < GW; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
+                        for (int c = 0; c < GW; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) bx[u] = __builtin_elementwise_fma(-sj[c], dx[c], bx[u]);   // x_i - x_t = -(x_t - x_i), exactly
+                        for (int c = 0; c < GW; ++c) bx[u] = __builtin_elementwise_fma(-sj[c], dx[c], bx[u]);   // x_i - x_t = -(x_t - x_i), exactly
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) by[u] = __builtin_elementwise_fma(-sj[c], dy[c], by[u]);
+                        for (int c = 0; c < GW; ++c) by[u] = __builtin_elementwise_fma(-sj[c], dy[c], by[u]);
 #pragma unroll
-                        for (int c = 0; c < 4; ++c) bz[u] = __builtin_elementwise_fma(-sj[c], dz[c], bz[u]);
+                        for (int c = 0; c < GW; ++c) bz[u] = __builtin_elementwise_fma(-sj[c], dz[c], bz[u]);
                     }
                 }
 #pragma unroll
@@ -1345,6 +1346,7 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
                      const SymWPlan pl, const uint32_t n, const double G, const double eps2)
 {
     constexpr uint32_t S = 64u * IPL, CH = 64u, CPS = S / CH;
+    constexpr int GW = 4;                      // residents evaluated stage-major together
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (w >= pl.W) return;
@@ -1377,27 +1379,27 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
             double tx = t.x, ty = t.y, tz = t.z, tm = t.w * G, bx = 0, by = 0, bz = 0;
             for (int st = 0; st < 64; ++st) {
 #pragma unroll
-                for (int c0g = 0; c0g < IPL; c0g += 4) {             // stage-major over four residents
-                    double dx[4], dy[4], dz[4], d2[4], y[4], u[4];
+                for (int c0g = 0; c0g < IPL; c0g += GW) {            // stage-major over four residents
+                    double dx[GW], dy[GW], dz[GW], d2[GW], y[GW], u[GW];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) dx[c] = tx - xi[c0g + c];
+                    for (int c = 0; c < GW; ++c) dx[c] = tx - xi[c0g + c];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) dy[c] = ty - yi[c0g + c];
+                    for (int c = 0; c < GW; ++c) dy[c] = ty - yi[c0g + c];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) dz[c] = tz - zi[c0g + c];
+                    for (int c = 0; c < GW; ++c) dz[c] = tz - zi[c0g + c];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) d2[c] = nb_fma(dz[c], dz[c], nb_fma(dy[c], dy[c], nb_fma(dx[c], dx[c], eps2)));
+                    for (int c = 0; c < GW; ++c) d2[c] = nb_fma(dz[c], dz[c], nb_fma(dy[c], dy[c], nb_fma(dx[c], dx[c], eps2)));
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) y[c] = __builtin_amdgcn_rsq(d2[c]);
+                    for (int c = 0; c < GW; ++c) y[c] = __builtin_amdgcn_rsq(d2[c]);
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
+                    for (int c = 0; c < GW; ++c) {
                         const double y2 = y[c] * y[c];
                         const double e = nb_fma(-d2[c], y2, 1.0);
                         const double t3 = y[c] * y2;
                         u[c] = nb_fma(t3 * e, 1.5, t3);
                     }
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
+                    for (int c = 0; c < GW; ++c) {
                         const double si = tm * u[c], sj = mi[c0g + c] * u[c];
                         ax[c0g + c] = nb_fma(si, dx[c], ax[c0g + c]); ay[c0g + c] = nb_fma(si, dy[c], ay[c0g + c]); az[c0g + c] = nb_fma(si, dz[c], az[c0g + c]);
                         bx = nb_fma(-sj, dx[c], bx); by = nb_fma(-sj, dy[c], by); bz = nb_fma(-sj, dz[c], bz);
