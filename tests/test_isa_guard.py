@@ -219,7 +219,7 @@ def test_symmetric_pass_rotation_loop_is_the_pair_arithmetic_and_the_rotation_on
 
     seen = 0
     # (mangled prefix, residents' packed groups NG or residents IPL, travelers J, f64)
-    for pat, ng, j, f64 in ((r"_ZN2nb13nb_force_symwILi4ELi1EEE", 4, 1, False), (r"_ZN2nb13nb_force_symwILi4ELi2EEE", 4, 2, False),
+    for pat, ng, j, f64 in ((r"_ZN2nb13nb_force_symwILi2ELi1EEE", 2, 1, False), (r"_ZN2nb13nb_force_symwILi4ELi1EEE", 4, 1, False), (r"_ZN2nb13nb_force_symwILi4ELi2EEE", 4, 2, False),
                             (r"_ZN2nb13nb_force_symwILi8ELi1EEE", 8, 1, False), (r"_ZN2nb12nb_force_symILi4ELi4ELi2EEE", 4, 2, False),
                             (r"_ZN2nb15nb_force_symw64ILi8EEE", 8, 1, True)):
         m = re.search(r"^(%s\w*):.*?$(.*?)^\.Lfunc_end" % pat, text, re.S | re.M)      # to the end of the function: an s_endpgm may sit mid-body
@@ -236,4 +236,4 @@ def test_symmetric_pass_rotation_loop_is_the_pair_arithmetic_and_the_rotation_on
             assert ops.count("v_rsq_f32_e32") == 2 * ng * j and sum(o.startswith("v_pk_") for o in valu) == 16 * ng * j, pat
             assert len(valu) == (18 * ng + 10) * j, (pat, len(valu))
         seen += 1
-    assert seen == 5
+    assert seen == 6
