@@ -229,11 +229,13 @@ def test_symmetric_pass_rotation_loop_is_the_pair_arithmetic_and_the_rotation_on
         ops = [l.split()[0] for l in loops[0] if not l.endswith(":")]
         valu = [o for o in ops if o.startswith("v_")]
         assert not any(o.startswith("scratch_") or o.startswith("ds_") or o.startswith("global_") or o.startswith("buffer_") for o in ops), pat
-        assert ops.count("v_mov_b32_dpp") == (14 if f64 else 10) * j, (pat, ops.count("v_mov_b32_dpp"))
+        per_step = (14 if f64 else 10) * j
+        u = ops.count("v_mov_b32_dpp") // per_step            # rotation steps per loop iteration (hipcc unrolls the short 4-resident body by 2)
+        assert u >= 1 and ops.count("v_mov_b32_dpp") == per_step * u, (pat, ops.count("v_mov_b32_dpp"))
         if f64:
-            assert ops.count("v_rsq_f64_e32") == ng and len(valu) == ng * 20 + 14, (pat, len(valu))
+            assert ops.count("v_rsq_f64_e32") == ng * u and len(valu) == (ng * 20 + 14) * u, (pat, len(valu))
         else:
-            assert ops.count("v_rsq_f32_e32") == 2 * ng * j and sum(o.startswith("v_pk_") for o in valu) == 16 * ng * j, pat
-            assert len(valu) == (18 * ng + 10) * j, (pat, len(valu))
+            assert ops.count("v_rsq_f32_e32") == 2 * ng * j * u and sum(o.startswith("v_pk_") for o in valu) == 16 * ng * j * u, pat
+            assert len(valu) == (18 * ng + 10) * j * u, (pat, len(valu))
         seen += 1
     assert seen == 6
