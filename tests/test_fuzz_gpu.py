@@ -69,3 +69,58 @@ def test_random_multi_shard_case(seed):
     ra = oracle.accel_f64(b.astype(np.float64), 1.0)
     assert np.abs(aa[:, :3] - ra[:, :3]).max() <= 2e-5 * max(float(np.abs(ra[:, :3]).max()), 1e-30), (seed, n, g)
     assert rel_pos_err(bb, rb, max(float(np.abs(b[:, :3]).max()), 1e-3)) < 1e-5, (seed, n, g)
+
+
+SYM_VARIANTS = [704013, 708013, 708011, 716013, 716011, 708014]
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_random_symmetric_pass_case(seed):
+    """The symmetric force pass on random systems: every resident count / traveler count / workgroup form, random waves per SIMD
+    (or segment counts), sizes from just above one super-block to 30 of them, ragged N, stiff mass ratios, tracers and coincident
+    bodies, random softening and G -- one force evaluation against the fp64 oracle, both precisions."""
+    rng = np.random.default_rng(9000 + seed)
+    variant = int(rng.choice(SYM_VARIANTS))
+    S = 64 * (variant // 1000 % 100) * (4 if variant % 10 == 4 else 1)
+    n = int(rng.integers(S + 1, 30 * S)) if rng.random() < 0.8 else int(S * rng.integers(2, 12))
+    n = min(n, 30000)
+    f64 = variant == 708013 and rng.random() < 0.4
+    jsplit = int(rng.choice([0, 1, 2, 3])) if variant % 10 != 4 else int(rng.choice([0, 3, 7, 16]))
+    eps2 = float(rng.choice([1e-4, 1e-6, 2.5e-3]))
+    G = float(rng.choice([1.0, 1e-4, 7.5]))
+    b, v = random_system(rng, n)
+    tag = dict(seed=seed, n=n, variant=variant, jsplit=jsplit, eps2=eps2, G=G, f64=f64)
+    dt_np = np.float64 if f64 else np.float32
+    with Simulation(n, eps2=eps2, force_variant=variant, jsplit=jsplit, precision="f64" if f64 else "f32") as sim:
+        sim.init(b.astype(dt_np), v.astype(dt_np))
+        sim.simulate(1, 1e-4, G)
+        bb, vv, aa = sim.read()
+        tag["name"] = sim.variant
+    if n > S:
+        assert "sym" in tag["name"], tag
+    ra = oracle.accel_f64(b.astype(np.float64), G, eps2=eps2)
+    scale = max(float(np.abs(ra[:, :3]).max()), 1e-30)
+    assert np.isfinite(bb).all() and np.isfinite(aa).all(), tag
+    tag["acc_err"] = float(np.abs(aa[:, :3] - ra[:, :3]).max() / scale)
+    assert tag["acc_err"] <= (1e-12 if f64 else 2e-5), tag
+    assert np.array_equal(bb[:, 3], b[:, 3].astype(dt_np)) and np.all(aa[:, 3] == 0), tag
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_rank_form_case(seed):
+    """nb_multi in the rank form (>= 2,048 rows per shard): random shard counts and sizes, f32 and f64."""
+    rng = np.random.default_rng(7000 + seed)
+    g = int(rng.choice([2, 3, 4, 5, 8]))
+    n = int(rng.integers(2048 * g - 500, 2048 * g + 6000))
+    f64 = rng.random() < 0.35
+    b, v = random_system(rng, n)
+    dt_np = np.float64 if f64 else np.float32
+    with MultiSimulation(n, g, precision="f64" if f64 else "f32") as ms:
+        name = ms.variant
+        ms.init(b.astype(dt_np), v.astype(dt_np))
+        ms.simulate(1, 1e-4, 1.0)
+        bb, vv, aa = ms.read()
+    if -(-n // g) >= 2048:
+        assert "symwrank" in name, (seed, n, g, name)
+    ra = oracle.accel_f64(b.astype(np.float64), 1.0)
+    assert np.abs(aa[:, :3] - ra[:, :3]).max() <= (1e-12 if f64 else 2e-5) * max(float(np.abs(ra[:, :3]).max()), 1e-30), (seed, n, g, name)

@@ -18,9 +18,9 @@ pytestmark = pytest.mark.gpu
 
 TOL_ACC, TOL_TIGHT = 2e-5, 2e-5
 
-# (variant, jsplit): wave-granular form with 8 / 16 residents per lane and 1 / 2 travelers per lane, 1-3 waves per SIMD;
+# (variant, jsplit): wave-granular form with 4 / 8 / 16 residents per lane and 1 / 2 travelers per lane, 1-3 waves per SIMD;
 # the workgroup form with its automatic and two pinned segment counts
-SYM_VARIANTS = [(708013, 0), (708013, 2), (708011, 1), (708011, 3), (716013, 0), (716013, 2), (716011, 1), (708014, 0), (708014, 5), (708014, 13)]
+SYM_VARIANTS = [(704013, 0), (704013, 3), (708013, 0), (708013, 2), (708011, 1), (708011, 3), (716013, 0), (716013, 2), (716011, 1), (708014, 0), (708014, 5), (708014, 13)]
 
 
 def run(b, v, steps, dt=1e-3, G=1.0, **kw):
