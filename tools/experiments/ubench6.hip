@@ -155,9 +155,95 @@ void dpp_cost(const char* name, int n_cu)
     CK(hipFree(d));
 }
 
-template <int NG, int J>
+// Variant: the travelers do not move.  Their positions sit in a wave-private LDS slab and lane l reads slot (l - step) & 63
+// (4 ds_read_b32: the LDS pipe, not the VALU); their sums are accumulated IN LDS with ds_add_f32 (conflict-free: 64 lanes, 64
+// slots; one wave's LDS operations execute in order, so step s+1 sees step s).  VALU work per step: the pair arithmetic only.
+template <int NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void k_sym_lds(const float4* __restrict__ res, const float4* __restrict__ trv, float4* __restrict__ out_r, float4* __restrict__ out_t,
+               float eps2, int sweeps)
+{
+    __shared__ float tpos[4][4][64];
+    __shared__ float tsum[4][3][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const float4 b0 = res[(size_t)wave * 128 * NG + (2 * g) * 64 + lane], b1 = res[(size_t)wave * 128 * NG + (2 * g + 1) * 64 + lane];
+        xi[g] = nb_f2{b0.x, b1.x}; yi[g] = nb_f2{b0.y, b1.y}; zi[g] = nb_f2{b0.z, b1.z}; mi[g] = nb_f2{b0.w, b1.w};
+        ax[g] = nb_f2{0, 0}; ay[g] = nb_f2{0, 0}; az[g] = nb_f2{0, 0};
+    }
+    const float4 t = trv[(size_t)wave * 64 + lane];
+    tpos[wv][0][lane] = t.x; tpos[wv][1][lane] = t.y; tpos[wv][2][lane] = t.z; tpos[wv][3][lane] = t.w;
+    tsum[wv][0][lane] = 0; tsum[wv][1][lane] = 0; tsum[wv][2][lane] = 0;
+    const nb_f2 e2 = nb_f2{eps2, eps2};
+    for (int s = 0; s < sweeps * 64; ++s) {
+        const int slot = (lane - s) & 63;
+        const float tx = tpos[wv][0][slot], ty = tpos[wv][1][slot], tz = tpos[wv][2][slot], tm = tpos[wv][3][slot];
+        const nb_f2 px = nb_f2{tx, tx}, py = nb_f2{ty, ty}, pz = nb_f2{tz, tz}, pm = nb_f2{tm, tm};
+        nb_f2 bx, by, bz;
+#pragma unroll
+        for (int c0g = 0; c0g < NG; c0g += 4) {
+            nb_f2 dx[4], dy[4], dz[4], d2[4], r[4], si[4], st[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dx[c] = px - xi[c0g + c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dy[c] = py - yi[c0g + c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) dz[c] = pz - zi[c0g + c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = d2[c] * d2[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+#pragma unroll
+            for (int c = 0; c < 4; ++c) si[c] = pm * r[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) st[c] = mi[c0g + c] * r[c];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
+            // traveler side: the first product starts the chain (no zeroing), the rest accumulate
+            if (c0g == 0) { bx = -st[0] * dx[0]; by = -st[0] * dy[0]; bz = -st[0] * dz[0]; }
+#pragma unroll
+            for (int c = (c0g == 0 ? 1 : 0); c < 4; ++c) bx = __builtin_elementwise_fma(-st[c], dx[c], bx);
+#pragma unroll
+            for (int c = (c0g == 0 ? 1 : 0); c < 4; ++c) by = __builtin_elementwise_fma(-st[c], dy[c], by);
+#pragma unroll
+            for (int c = (c0g == 0 ? 1 : 0); c < 4; ++c) bz = __builtin_elementwise_fma(-st[c], dz[c], bz);
+        }
+        // both halves of the packed sums go to the traveler's slot (ds_add_f32, no return value)
+        __hip_atomic_fetch_add(&tsum[wv][0][slot], bx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&tsum[wv][0][slot], bx.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&tsum[wv][1][slot], by.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&tsum[wv][1][slot], by.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&tsum[wv][2][slot], bz.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(&tsum[wv][2][slot], bz.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        out_r[(size_t)wave * 128 * NG + (2 * g) * 64 + lane] = float4{ax[g].x, ay[g].x, az[g].x, 0};
+        out_r[(size_t)wave * 128 * NG + (2 * g + 1) * 64 + lane] = float4{ax[g].y, ay[g].y, az[g].y, 0};
+    }
+    out_t[(size_t)wave * 64 + lane] = float4{tsum[wv][0][lane], tsum[wv][1][lane], tsum[wv][2][lane], 0};
+}
+
+template <int NG, int J, bool LDS = false>
 void run(const char* name, int n_cu)
 {
+    auto kern = [](auto... a) {};
+    (void)kern;
     const int waves = n_cu * 16, wgs = waves / 4;                 // 4 waves per SIMD
     const size_t nr = (size_t)waves * 128 * NG, nt = (size_t)waves * 64 * J;
     std::vector<float4> hr(nr), ht(nt);
@@ -169,7 +255,7 @@ void run(const char* name, int n_cu)
     CK(hipMalloc(&dr, nr * 16)); CK(hipMalloc(&dt, nt * 16)); CK(hipMalloc(&orr, nr * 16)); CK(hipMalloc(&ott, nt * 16));
     CK(hipMemcpy(dr, hr.data(), nr * 16, hipMemcpyHostToDevice)); CK(hipMemcpy(dt, ht.data(), nt * 16, hipMemcpyHostToDevice));
     // correctness: one sweep, wave 0 and the last wave against an fp64 direct sum
-    hipLaunchKernelGGL((k_sym<NG, J>), dim3(wgs), dim3(256), 0, 0, dr, dt, orr, ott, 1e-4f, 1);
+    if constexpr (LDS) hipLaunchKernelGGL((k_sym_lds<NG>), dim3(wgs), dim3(256), 0, 0, dr, dt, orr, ott, 1e-4f, 1); else hipLaunchKernelGGL((k_sym<NG, J>), dim3(wgs), dim3(256), 0, 0, dr, dt, orr, ott, 1e-4f, 1);
     CK(hipDeviceSynchronize());
     std::vector<float4> gr(nr), gt(nt);
     CK(hipMemcpy(gr.data(), orr, nr * 16, hipMemcpyDeviceToHost)); CK(hipMemcpy(gt.data(), ott, nt * 16, hipMemcpyDeviceToHost));
@@ -200,13 +286,13 @@ void run(const char* name, int n_cu)
         }
     }
     // timing
-    const int sweeps = 40;
+    const int sweeps = 200;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int k = 0; k < 3; ++k) hipLaunchKernelGGL((k_sym<NG, J>), dim3(wgs), dim3(256), 0, 0, dr, dt, orr, ott, 1e-4f, sweeps);
+    for (int k = 0; k < 3; ++k) { if constexpr (LDS) hipLaunchKernelGGL((k_sym_lds<NG>), dim3(wgs), dim3(256), 0, 0, dr, dt, orr, ott, 1e-4f, sweeps); else hipLaunchKernelGGL((k_sym<NG, J>), dim3(wgs), dim3(256), 0, 0, dr, dt, orr, ott, 1e-4f, sweeps); }
     CK(hipEventRecord(e0, 0));
     const int reps = 5;
-    for (int k = 0; k < reps; ++k) hipLaunchKernelGGL((k_sym<NG, J>), dim3(wgs), dim3(256), 0, 0, dr, dt, orr, ott, 1e-4f, sweeps);
+    for (int k = 0; k < reps; ++k) { if constexpr (LDS) hipLaunchKernelGGL((k_sym_lds<NG>), dim3(wgs), dim3(256), 0, 0, dr, dt, orr, ott, 1e-4f, sweeps); else hipLaunchKernelGGL((k_sym<NG, J>), dim3(wgs), dim3(256), 0, 0, dr, dt, orr, ott, 1e-4f, sweeps); }
     CK(hipEventRecord(e1, 0));
     CK(hipEventSynchronize(e1));
     float ms = 0;
@@ -237,5 +323,8 @@ int main()
     run<4, 2>("NG4 J2", cu);
     run<2, 2>("NG2 J2", cu);
     run<2, 4>("NG2 J4", cu);
+    run<8, 1>("NG8 J1 dpp", cu);
+    run<8, 1, true>("NG8 J1 lds", cu);
+    run<4, 1, true>("NG4 J1 lds", cu);
     return 0;
 }
