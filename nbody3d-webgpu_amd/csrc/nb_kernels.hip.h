@@ -6,10 +6,13 @@
 // place (:283) while other workgroups still stage them (:257) -- a cross-workgroup race.
 // Here a step is well defined in both of its forms:
 //
-//   two kernels   K1 nb_force*   (reads positions only)  ->  K2 nb_integrate (after all of K1)
+//   two kernels   K1 nb_force*   (reads positions only)  ->  K2 nb_integrate* (after all of K1)
 //   one kernel    nb_step_fused  (reads bodies_in, writes bodies_out: ping-pong buffers)
 //
-//   K1 forms:   nb_force_pk_sgpr<NG,WS>  f32, packed math, j broadcast from SGPRs (large systems)
+//   K1 forms:   nb_force_symw<NG,J>      f32, SYMMETRIC pass (default from N ~ 13,000): every unordered pair once, both
+//               nb_force_symw64<8>       accelerations; residents in registers, travelers rotate through the wave by DPP
+//               nb_force_sym<WS,NG,J>    (f64 form; workgroup form with LDS-combined traveler sums: A/B arm)
+//               nb_force_pk_sgpr<NG,WS>  f32, packed math, ordered pairs, j broadcast from SGPRs (shards without the native exchange)
 //               nb_force_pk<NG,LS,TL>    f32, packed math, j-tile staged in LDS
 //               nb_force<T,IPL,LS>       scalar template: f64, and the unpacked f32 shapes
 //   fused form: nb_step_fused<NG,LS,TL>  nb_force_pk's loop over ALL j + the integrator in the
