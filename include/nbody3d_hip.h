@@ -297,6 +297,32 @@ const char *nb_variant_name(nb_sim *s);
 int nb_shape_info(nb_sim *s, uint32_t *jsplit, uint32_t *j_per_split, uint32_t *own_split0,
                   uint32_t *own_splits);
 
+/* The launch plan nb_create WOULD build for `cfg` on a device with n_cu compute units at clock_hz -- the engine's planner
+ * (kernel form, j-partitions, the symmetric pass's super-block ring, its wave ranges and layer table) run on the host
+ * alone.  No device is needed or touched: with n_cu > 0 and clock_hz > 0 the call works on a machine without a GPU (the
+ * planner's occupancy queries then use their built-in defaults); n_cu <= 0 or clock_hz <= 0 means "as on cfg->device".
+ * For reports, for sizing runs ahead of time, and for the host-side tests of the planner (tests/test_planner_cpu.py walks
+ * the plan the way the kernels do and checks that every pair is covered exactly once).  No reference analogue: the
+ * reference's dispatch is the one line ceil(N / 256) of nbody3d.js:478.
+ *   kind/ipl/ls/x      the force_variant digits K, II, LL, X of the chosen form
+ *   jsplit..own_splits as nb_shape_info
+ *   sym*               symmetric pass only: padded rows, partial-sum layers, the rank form's super-block range, and the
+ *                      plan words the kernels receive (nb::SymWPlan: np, nsb, W, total_hi, total_lo, n_hi, H, r_layer0,
+ *                      t_layer0, L, p0; workgroup form nb::SymPlan: np, nsb, q, total_hi, total_lo, n_hi, H, r_layer0, t_layer0)
+ *   tab                (caller's array of tab_cap words, may be NULL) first wave and wave count of every super-block's
+ *                      list, 2 * nsb words; tab_len reports how many there are */
+typedef struct nb_plan_info {
+  uint32_t struct_size; /* sizeof(nb_plan_info), set by the caller */
+  uint32_t kind, ipl, ls, x;
+  uint32_t jsplit, j_per_split, own_split0, own_splits;
+  uint32_t sym, symw, sym_rank, sym_np, sym_layers, sym_g0, sym_g1;
+  uint32_t sym_plan[11];
+  uint32_t tab_len;
+  char variant[112];
+} nb_plan_info;
+int nb_plan_query(const nb_config *cfg, int n_cu, double clock_hz, nb_plan_info *out, uint32_t *tab,
+                  uint32_t tab_cap);
+
 /* ---- viewer frame feed ------------------------------------------------
  * The reference's render pass reads bodyBuffer and velBuffer in place every frame
  * (nbody3d.js:408-415,482-487: billboard position + radius from (x,y,z,mass), colour from

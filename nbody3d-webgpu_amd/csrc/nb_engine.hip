@@ -386,7 +386,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
             const void* fn = kernel_of(s->f64, c.sh);
             if (!fn) continue;
             int occ = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, nb::kBlock, 0) != hipSuccess || occ < 1) {
+            if (s->no_device || hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, nb::kBlock, 0) != hipSuccess || occ < 1) {
                 (void)hipGetLastError();
                 occ = 4;
             }
@@ -463,7 +463,7 @@ void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
                 if (pinned && sh.x != x) continue;
                 const int ws = jpk_ws(x);
                 int occ = 0;
-                if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel_of(false, jsh), 64 * ws, 0) != hipSuccess || occ < 1) {
+                if (s->no_device || hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel_of(false, jsh), 64 * ws, 0) != hipSuccess || occ < 1) {
                     (void)hipGetLastError();
                     occ = 28 / ws;
                 }
@@ -969,25 +969,36 @@ int nb_device_count(void)
     return c;
 }
 
+// nb_create's and nb_plan_query's reading of a caller's nb_config: a normalised copy, the shard and the softening
+static int read_config(const nb_config* cfg_in, const char* who, nb_config* cfg, uint32_t* sb_out, uint32_t* sc_out, double* eps2_out)
+{
+    const std::string w(who);
+    if (cfg_in->struct_size < offsetof(nb_config, reserved))
+        return fail(nullptr, NB_ERR_INVALID, w + ": struct_size too small (set it to sizeof(nb_config))");
+    memset(cfg, 0, sizeof *cfg);
+    memcpy(cfg, cfg_in, cfg_in->struct_size < sizeof *cfg ? cfg_in->struct_size : sizeof *cfg);
+    if (cfg->n == 0) return fail(nullptr, NB_ERR_INVALID, w + ": n must be >= 1");
+    if (cfg->precision > NB_F64) return fail(nullptr, NB_ERR_INVALID, w + ": unknown precision");
+    if (cfg->tile != 0 && cfg->tile != (uint32_t)nb::kTile)
+        return fail(nullptr, NB_ERR_INVALID, w + ": only tile = 256 is built (reference TILE_SIZE)");
+    const double eps2 = cfg->eps2 == 0.0 ? 1e-4 : cfg->eps2;
+    if (!(eps2 >= 1e-12))
+        return fail(nullptr, NB_ERR_INVALID, w + ": eps2 must be >= 1e-12 (branch-free self term needs it)");
+    uint32_t sb = cfg->shard_begin, sc = cfg->shard_count;
+    if (sc == 0) { sb = 0; sc = cfg->n; }
+    if ((uint64_t)sb + sc > cfg->n) return fail(nullptr, NB_ERR_INVALID, w + ": shard exceeds n");
+    *sb_out = sb; *sc_out = sc; *eps2_out = eps2;
+    return NB_OK;
+}
+
 int nb_create(const nb_config* cfg_in, nb_sim** out)
 {
     if (out) *out = nullptr;
     if (!cfg_in || !out) return fail(nullptr, NB_ERR_INVALID, "nb_create: null argument");
-    if (cfg_in->struct_size < offsetof(nb_config, reserved))
-        return fail(nullptr, NB_ERR_INVALID, "nb_create: struct_size too small (set it to sizeof(nb_config))");
     nb_config cfg;
-    memset(&cfg, 0, sizeof cfg);
-    memcpy(&cfg, cfg_in, cfg_in->struct_size < sizeof cfg ? cfg_in->struct_size : sizeof cfg);
-    if (cfg.n == 0) return fail(nullptr, NB_ERR_INVALID, "nb_create: n must be >= 1");
-    if (cfg.precision > NB_F64) return fail(nullptr, NB_ERR_INVALID, "nb_create: unknown precision");
-    if (cfg.tile != 0 && cfg.tile != (uint32_t)nb::kTile)
-        return fail(nullptr, NB_ERR_INVALID, "nb_create: only tile = 256 is built (reference TILE_SIZE)");
-    const double eps2 = cfg.eps2 == 0.0 ? 1e-4 : cfg.eps2;
-    if (!(eps2 >= 1e-12))
-        return fail(nullptr, NB_ERR_INVALID, "nb_create: eps2 must be >= 1e-12 (branch-free self term needs it)");
-    uint32_t sb = cfg.shard_begin, sc = cfg.shard_count;
-    if (sc == 0) { sb = 0; sc = cfg.n; }
-    if ((uint64_t)sb + sc > cfg.n) return fail(nullptr, NB_ERR_INVALID, "nb_create: shard exceeds n");
+    uint32_t sb, sc;
+    double eps2;
+    if (const int rc = read_config(cfg_in, "nb_create", &cfg, &sb, &sc, &eps2)) return rc;
 
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
@@ -1371,6 +1382,46 @@ int nb_shape_info(nb_sim* s, uint32_t* jsplit, uint32_t* j_per_split, uint32_t* 
     if (j_per_split) *j_per_split = s->j_per_split;
     if (own_split0) *own_split0 = s->own_split0;
     if (own_splits) *own_splits = s->own_splits;
+    return NB_OK;
+}
+
+int nb_plan_query(const nb_config* cfg_in, int n_cu, double clock_hz, nb_plan_info* out, uint32_t* tab, uint32_t tab_cap)
+{
+    if (!cfg_in || !out) return fail(nullptr, NB_ERR_INVALID, "nb_plan_query: null argument");
+    if (out->struct_size < sizeof(nb_plan_info)) return fail(nullptr, NB_ERR_INVALID, "nb_plan_query: set out->struct_size to sizeof(nb_plan_info)");
+    nb_config cfg;
+    uint32_t sb, sc;
+    double eps2;
+    if (const int rc = read_config(cfg_in, "nb_plan_query", &cfg, &sb, &sc, &eps2)) return rc;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 0; }
+    if (n_cu <= 0 || !(clock_hz > 0)) {           // "as on the current device"
+        if (count <= 0) return fail(nullptr, NB_ERR_NO_DEVICE, "nb_plan_query: n_cu / clock_hz not given and there is no HIP device to read them from");
+        int dev = cfg.device;
+        if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+        hipDeviceProp_t prop;
+        if (dev >= count || hipSetDevice(dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+            return fail(nullptr, NB_ERR_HIP, "nb_plan_query: cannot read the device properties");
+        if (n_cu <= 0) n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+        if (!(clock_hz > 0)) clock_hz = prop.clockRate > 0 ? 1e3 * prop.clockRate : 2.4e9;
+    }
+    nb_sim tmp;                                    // host fields only: nothing of it is ever allocated on a device
+    tmp.n = cfg.n; tmp.sb = sb; tmp.sc = sc; tmp.f64 = cfg.precision == NB_F64; tmp.esz = tmp.f64 ? 8 : 4; tmp.eps2 = eps2;
+    tmp.no_device = count <= 0;
+    choose_shape(&tmp, cfg, n_cu, clock_hz);
+    const Shape sh = shape_of(&tmp);
+    const uint32_t size = out->struct_size;
+    memset(out, 0, sizeof *out);
+    out->struct_size = size;
+    out->kind = (uint32_t)sh.kind; out->ipl = (uint32_t)sh.ipl; out->ls = (uint32_t)sh.ls; out->x = (uint32_t)sh.x;
+    out->jsplit = tmp.jsplit; out->j_per_split = tmp.j_per_split; out->own_split0 = tmp.own_split0; out->own_splits = tmp.own_splits;
+    out->sym = tmp.sym; out->symw = tmp.symw; out->sym_rank = tmp.sym_rank;
+    out->sym_np = tmp.sym_np; out->sym_layers = tmp.sym_layers; out->sym_g0 = tmp.sym_g0; out->sym_g1 = tmp.sym_g1;
+    static_assert(sizeof(out->sym_plan) == sizeof(tmp.sym_plan), "nb_plan_info::sym_plan mirrors nb_sim::sym_plan");
+    memcpy(out->sym_plan, tmp.sym_plan, sizeof out->sym_plan);
+    out->tab_len = (uint32_t)tmp.sym_tab_host.size();
+    snprintf(out->variant, sizeof out->variant, "%s", tmp.variant.c_str());
+    if (tab) memcpy(tab, tmp.sym_tab_host.data(), sizeof(uint32_t) * (out->tab_len < tab_cap ? out->tab_len : tab_cap));
     return NB_OK;
 }
 

@@ -35,6 +35,7 @@ struct nb_sim {
     bool f64 = false;
     size_t esz = 4;
     int device = 0;
+    bool no_device = false;        // nb_plan_query on a host without a GPU: the planner skips its occupancy queries
     double eps2 = 1e-4;
     hipStream_t stream = nullptr;
     bool own_stream = false;

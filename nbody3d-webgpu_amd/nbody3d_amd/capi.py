@@ -50,6 +50,13 @@ class nb_config(C.Structure):
     ]
 
 
+class nb_plan_info(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32)] + [(k, C.c_uint32) for k in (
+        "kind", "ipl", "ls", "x", "jsplit", "j_per_split", "own_split0", "own_splits",
+        "sym", "symw", "sym_rank", "sym_np", "sym_layers", "sym_g0", "sym_g1")] + [
+        ("sym_plan", C.c_uint32 * 11), ("tab_len", C.c_uint32), ("variant", C.c_char * 112)]
+
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
 EXCHANGE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
@@ -62,7 +69,7 @@ SYMBOLS = ["nb_abi_version", "nb_device_count", "nb_create", "nb_destroy", "nb_u
            "nb_multi_download", "nb_multi_sync", "nb_multi_last_error", "nb_multi_variant_name",
            "nb_multi_diagnostics", "nb_multi_set_collective", "nb_multi_collective_info",
            "nb_rccl_unique_id", "nb_rccl_attach", "nb_rccl_detach", "nb_rccl_info",
-           "nb_step_times", "nb_integrate_pass", "nb_frame_request", "nb_frame_acquire", "nb_shape_info"]
+           "nb_step_times", "nb_integrate_pass", "nb_frame_request", "nb_frame_acquire", "nb_shape_info", "nb_plan_query"]
 
 _lib = None
 
@@ -124,6 +131,7 @@ def load_library():
                                 C.POINTER(C.c_uint32)]
     L.nb_integrate_pass.argtypes = [vp, C.c_uint32, C.POINTER(C.c_double)]
     L.nb_shape_info.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
+    L.nb_plan_query.argtypes = [C.POINTER(nb_config), C.c_int, C.c_double, C.POINTER(nb_plan_info), C.POINTER(C.c_uint32), C.c_uint32]
     L.nb_frame_request.argtypes = [vp]
     L.nb_frame_acquire.argtypes = [vp, C.c_int, C.POINTER(C.POINTER(C.c_float)), C.POINTER(C.POINTER(C.c_float)),
                                    C.POINTER(C.c_uint64)]
@@ -151,6 +159,41 @@ def rccl_unique_id():
 
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+SYMW_PLAN_WORDS = ("np", "nsb", "W", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "t_layer0", "L", "p0")
+SYM_PLAN_WORDS = ("np", "nsb", "q", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "t_layer0")
+
+
+def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=0, n_cu=256, clock_hz=2.4e9, device=-1):
+    """nb_plan_query: the launch plan nb_create would build -- the engine's planner run on the host alone (works without a
+    GPU when n_cu and clock_hz are given; 0 means "as on the device").  Returns a dict: the shape digits, the j-partitions,
+    and for the symmetric pass `plan` (the words the kernels receive, by name) and `tab` (first wave, wave count per super-block)."""
+    L = load_library()
+    cfg = nb_config()
+    cfg.struct_size = C.sizeof(nb_config)
+    cfg.n = int(n)
+    cfg.precision = NB_F64 if precision in ("f64", NB_F64, np.float64) else NB_F32
+    cfg.device = device
+    if shard is not None:
+        cfg.shard_begin, cfg.shard_count = int(shard[0]), int(shard[1])
+    cfg.force_variant, cfg.jsplit, cfg.flags = int(force_variant), int(jsplit), int(flags)
+    info = nb_plan_info()
+    info.struct_size = C.sizeof(nb_plan_info)
+    rc = L.nb_plan_query(C.byref(cfg), int(n_cu), float(clock_hz), C.byref(info), None, 0)
+    if rc != 0:
+        raise NBodyError(rc, L.nb_last_error(None).decode())
+    tab = np.zeros(info.tab_len, np.uint32)
+    if info.tab_len:
+        rc = L.nb_plan_query(C.byref(cfg), int(n_cu), float(clock_hz), C.byref(info), tab.ctypes.data_as(C.POINTER(C.c_uint32)), tab.size)
+        if rc != 0:
+            raise NBodyError(rc, L.nb_last_error(None).decode())
+    out = {k: int(getattr(info, k)) for k, _ in nb_plan_info._fields_[1:16]}
+    out["variant"] = info.variant.decode()
+    if info.sym:
+        out["plan"] = dict(zip(SYMW_PLAN_WORDS if info.symw else SYM_PLAN_WORDS, (int(w) for w in info.sym_plan)))
+        out["tab"] = tab.reshape(-1, 2)
+    return out
 
 
 class Simulation:

@@ -1,0 +1,224 @@
+"""The engine's launch planner on the host (nb_plan_query: no GPU needed).  These tests walk the plan the C++ planner built
+the way the kernels walk it (nb_force_symw / nb_force_sym, nb_integrate_symw, csrc/nb_kernels.hip.h) and check the
+properties the symmetric pass rests on: every unordered pair of bodies is evaluated exactly once, no partial-sum row is
+written twice, and the integrate kernel reads exactly the rows that were written.  The reference has no counterpart (its
+dispatch is ceil(N / 256) workgroups, nbody3d.js:478); the path these plans serve is nbody3d.js:245-272."""
+import numpy as np
+import pytest
+
+from nbody3d_amd import capi
+
+NB_FLAG_NO_SYM, NB_FLAG_SYM_SHARD = 64, 128
+
+
+def walk_symw(q, n, rank=False):
+    """Every chunk-sweep of a wave-granular plan as arrays (one entry per list position of this handle)."""
+    pl, tab = q["plan"], q["tab"]
+    J = 2 if q["x"] == 1 else 1
+    S, CH = 64 * q["ipl"], 64 * J
+    cps = S // CH
+    nsb, W, L, p0 = pl["nsb"], pl["W"], pl["L"], pl["p0"]
+    assert pl["np"] == nsb * S and nsb == -(-n // S)
+    H, n_hi = pl["H"], pl["n_hi"]
+    assert H == (nsb - 1) // 2 and n_hi == (0 if nsb % 2 else nsb // 2)
+    assert pl["total_lo"] == (H + 1) * cps and pl["total_hi"] == (H + 1 + (1 if n_hi else 0)) * cps
+    p = p0 + np.arange(L, dtype=np.int64)
+    first_lo = n_hi * pl["total_hi"]
+    hi = p < first_lo
+    g = np.where(hi, p // pl["total_hi"], n_hi + (p - first_lo) // pl["total_lo"])
+    k = np.where(hi, p - g * pl["total_hi"], (p - first_lo) - (g - n_hi) * pl["total_lo"])
+    total = np.where(hi, pl["total_hi"], pl["total_lo"])
+    ring = total - cps
+    sym = k < ring
+    d = k // cps
+    tb = np.where(sym, (g + 1 + d) % nsb, g)
+    c = np.where(sym, k % cps, k - ring)
+    tstart = tb * S + c * CH
+    # the wave that sweeps each position: W floor/ceil-equal ranges of the handle's L positions
+    starts = p0 + (np.arange(W + 1, dtype=np.int64) * L) // W
+    assert np.all(np.diff(starts) >= 0) and starts[0] == p0 and starts[-1] == p0 + L
+    assert np.diff(starts).max() - np.diff(starts).min() <= 1                    # balanced to one chunk-sweep
+    w = np.searchsorted(starts, p, side="right") - 1
+    assert np.all((w >= 0) & (w < W))
+    return dict(S=S, CH=CH, cps=cps, nsb=nsb, H=H, n_hi=n_hi, g=g, k=k, sym=sym, d=d, tb=tb, c=c, tstart=tstart, w=w, pl=pl, tab=tab)
+
+
+def check_whole_plan(q, n):
+    """A whole-system wave-granular plan: pair coverage, layer writes, and K2's read set."""
+    wk = walk_symw(q, n)
+    nsb, cps, H, n_hi, pl, tab = wk["nsb"], wk["cps"], wk["H"], wk["n_hi"], wk["pl"], wk["tab"]
+    g, sym, d, tb, c, w = wk["g"], wk["sym"], wk["d"], wk["tb"], wk["c"], wk["w"]
+    assert pl["p0"] == 0 and pl["L"] == n_hi * pl["total_hi"] + (nsb - n_hi) * pl["total_lo"]
+    # (1) unordered pairs of DIFFERENT super-blocks: each (resident block, traveler chunk) at most once, and for a != b
+    #     either a sweeps all of b's chunks or b all of a's -- never both, never neither
+    visits = np.zeros((nsb, nsb, cps), np.int32)
+    np.add.at(visits, (g[sym], tb[sym], c[sym]), 1)
+    assert visits.max() == 1
+    per_pair = visits.sum(axis=2)
+    assert np.all(np.diag(per_pair) == 0)
+    both = per_pair + per_pair.T
+    off = ~np.eye(nsb, dtype=bool)
+    assert np.all(both[off] == cps) and np.all((per_pair[off] == 0) | (per_pair[off] == cps))
+    # (2) pairs INSIDE a super-block: its own chunks once each, resident-only
+    own = np.zeros((nsb, cps), np.int32)
+    np.add.at(own, (g[~sym], c[~sym]), 1)
+    assert np.all(own == 1) and np.all(tb[~sym] == g[~sym])
+    # (3) ring distances stay inside the traveler layers
+    assert np.all(d[sym] < H + (g[sym] < n_hi)) and pl["t_layer0"] + H + (1 if n_hi else 0) == q["sym_layers"]
+    # (4) resident layers: wave w writes layer r_layer0 + (w - first wave of g); the table is what the traversal does
+    for b in range(nsb):
+        ws = np.unique(w[g == b])
+        assert ws[0] == tab[b, 0] and len(ws) == tab[b, 1] and ws[-1] - ws[0] + 1 == len(ws), b
+    assert pl["r_layer0"] == 0 and tab[:, 1].max() == pl["t_layer0"] == q["jsplit"]
+    # (5) traveler layers: K2 (nb_integrate_symw) reads layers t_layer0 + [0, H + (n_hi and b >= n_hi)) of every row of b --
+    #     exactly the set written, once each (a chunk of padding rows only is skipped by K1 and never read by K2)
+    tl = np.zeros((nsb, cps, H + 1), np.int32)
+    np.add.at(tl, (tb[sym], c[sym], d[sym]), 1)
+    for b in range(nsb):
+        nt = H + (1 if (n_hi and b >= n_hi) else 0)
+        assert np.all(tl[b, :, :nt] == 1) and np.all(tl[b, :, nt:] == 0), b
+    return wk
+
+
+SIZES = [8193, 13000, 14000, 16384, 20000, 24001, 32768, 40002, 65536, 100000, 131072, 262144]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_default_plan_covers_every_pair_once(n):
+    q = capi.plan_query(n)
+    if not q["sym"]:
+        pytest.skip("planner keeps an ordered-pair kernel at N=%d: %s" % (n, q["variant"]))
+    assert q["symw"] and q["variant"].startswith("f32pk_symw_")
+    check_whole_plan(q, n)
+
+
+@pytest.mark.parametrize("variant", [704013, 708013, 708011, 716013, 716011])
+@pytest.mark.parametrize("n,jsplit", [(2049, 0), (9001, 1), (30000, 2), (33000, 3), (70001, 0)])
+def test_pinned_wave_granular_plans(variant, n, jsplit):
+    q = capi.plan_query(n, force_variant=variant, jsplit=jsplit)
+    S = 64 * (variant // 1000 % 100)
+    if n <= S:
+        assert not q["sym"]
+        return
+    assert q["symw"] and q["ipl"] == variant // 1000 % 100 and q["x"] == variant % 10
+    wk = check_whole_plan(q, n)
+    assert wk["pl"]["W"] % 4 == 0 and wk["pl"]["W"] <= max(4, wk["pl"]["L"] + 3)
+
+
+@pytest.mark.parametrize("n", [40002, 262144])
+def test_f64_plan(n):
+    q = capi.plan_query(n, precision="f64")
+    assert q["variant"].startswith("f64_symw_ipl8_j1")
+    check_whole_plan(q, n)
+
+
+@pytest.mark.parametrize("n,jsplit", [(4097, 0), (20000, 3), (40002, 0), (65536, 16), (262144, 0)])
+def test_workgroup_form_plan(n, jsplit):
+    """nb_force_sym<4,4,2>: workgroup (g, q) sweeps chunks [q total / Q, (q+1) total / Q) of g's list."""
+    q = capi.plan_query(n, force_variant=708014, jsplit=jsplit)
+    assert q["sym"] and not q["symw"] and q["variant"].startswith("f32pk_sym_ipl8_ws4")
+    pl = q["plan"]
+    S, CH = 2048, 128
+    cps, nsb, Q, H, n_hi = S // CH, pl["nsb"], pl["q"], pl["H"], pl["n_hi"]
+    assert nsb == -(-n // S) and pl["np"] == nsb * S and 1 <= Q <= pl["total_hi"]
+    visits = np.zeros((nsb, nsb, cps), np.int32)
+    own = np.zeros((nsb, cps), np.int32)
+    for g in range(nsb):
+        ring = (H + (1 if g < n_hi else 0)) * cps
+        total = ring + cps
+        assert total == (pl["total_hi"] if g < n_hi else pl["total_lo"])
+        cuts = [(s * total) // Q for s in range(Q + 1)]
+        assert cuts[0] == 0 and cuts[-1] == total and all(b >= a for a, b in zip(cuts, cuts[1:]))
+        for k in range(total):
+            if k < ring:
+                visits[g, (g + 1 + k // cps) % nsb, k % cps] += 1
+            else:
+                own[g, k - ring] += 1
+    per_pair = visits.sum(axis=2)
+    off = ~np.eye(nsb, dtype=bool)
+    assert visits.max() <= 1 and np.all(own == 1) and np.all((per_pair + per_pair.T)[off] == cps)
+    assert pl["t_layer0"] == Q and q["sym_layers"] == Q + H + (1 if n_hi else 0)
+
+
+@pytest.mark.parametrize("n,g,prec", [(8192, 2, "f32"), (65536, 8, "f32"), (262144, 8, "f32"), (262144, 3, "f32"), (1048576, 8, "f32"),
+                                     (16384, 4, "f64"), (262144, 8, "f64")])
+def test_rank_form_plans_tile_the_pair_list(n, g, prec):
+    """NB_FLAG_SYM_SHARD: rank r sweeps the chunk lists of its own super-blocks only; the ranks' ranges follow one another
+    and together are the whole system's list -- so the union evaluates every unordered pair exactly once."""
+    align = 512 if prec == "f64" else 1024
+    rows = -(-(-(-n // g)) // align) * align
+    whole = capi.plan_query(n, precision=prec, force_variant=(708013 if prec == "f64" else 716013), jsplit=1)
+    assert whole["symw"]
+    end = 0
+    for r in range(g):
+        b = min(r * rows, n)
+        cnt = min(rows, n - b)
+        if cnt == 0:
+            continue
+        q = capi.plan_query(n, precision=prec, shard=(b, cnt), flags=NB_FLAG_SYM_SHARD)
+        assert q["sym_rank"] and "symwrank" in q["variant"], q["variant"]
+        pl = q["plan"]
+        assert {k: pl[k] for k in ("np", "nsb", "total_hi", "total_lo", "n_hi", "H")} == {k: whole["plan"][k] for k in ("np", "nsb", "total_hi", "total_lo", "n_hi", "H")}
+        assert pl["p0"] == end
+        end = pl["p0"] + pl["L"]
+        S = 64 * q["ipl"]
+        assert q["sym_g0"] == b // S and q["sym_g1"] == (b + cnt) // S
+        wk = walk_symw(q, n, rank=True)
+        assert wk["g"].min() == q["sym_g0"] and wk["g"].max() == q["sym_g1"] - 1         # only its own super-blocks are resident
+        for sb in range(q["sym_g0"], q["sym_g1"]):
+            ws = np.unique(wk["w"][wk["g"] == sb])
+            assert ws[0] == q["tab"][sb, 0] and len(ws) == q["tab"][sb, 1]
+        assert q["tab"][:, 1].max() == pl["t_layer0"]
+    assert end == whole["plan"]["L"]
+
+
+def test_rank_form_needs_whole_super_blocks():
+    assert not capi.plan_query(262144, shard=(1000, 32768), flags=NB_FLAG_SYM_SHARD)["sym"]           # unaligned rows
+    assert not capi.plan_query(262144, shard=(0, 32768), flags=NB_FLAG_SYM_SHARD | NB_FLAG_NO_SYM)["sym"]
+    assert not capi.plan_query(262144, shard=(0, 32768))["sym"]                                      # a plain shard: ordered pairs
+    assert capi.plan_query(262144, precision="f64", shard=(0, 32768), flags=NB_FLAG_SYM_SHARD)["ipl"] == 8
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 1024, 4000, 8192, 12000, 40002, 262144])
+@pytest.mark.parametrize("flags", [NB_FLAG_NO_SYM, NB_FLAG_NO_SYM | 4, NB_FLAG_NO_SYM | 8])
+def test_ordered_pair_plans_partition_j(n, flags):
+    """The ordered-pair forms: the j-partitions cover [0, n) (multiples of 8 bodies, at most 128 of them)."""
+    q = capi.plan_query(n, flags=flags)
+    assert not q["sym"] and 1 <= q["jsplit"] <= 128
+    if q["kind"] == 6:          # j-packed fused step: whole 4-pair units per wave
+        assert q["jsplit"] * q["j_per_split"] >= n
+    else:
+        assert q["j_per_split"] % 8 == 0 and (q["jsplit"] - 1) * q["j_per_split"] < n <= q["jsplit"] * q["j_per_split"]
+    assert q["own_splits"] == 0
+
+
+@pytest.mark.parametrize("n,g", [(262144, 2), (262144, 4), (262144, 8), (1048576, 8), (100000, 3)])
+def test_shard_own_splits_lie_inside_the_shard(n, g):
+    """Plain i-shards (ordered pairs): the j-partitions the overlapped exchange issues first are whole and inside the shard."""
+    rows = -(-n // g)
+    for r in range(g):
+        b, cnt = r * rows, min(rows, n - r * rows)
+        q = capi.plan_query(n, shard=(b, cnt))
+        lo, hi = q["own_split0"] * q["j_per_split"], (q["own_split0"] + q["own_splits"]) * q["j_per_split"]
+        if q["own_splits"]:
+            assert lo >= b and min(hi, n) <= b + cnt
+            assert lo - b < q["j_per_split"] and (b + cnt) - min(hi, n) < q["j_per_split"]      # and as many as fit
+        else:
+            assert cnt < 2 * q["j_per_split"]
+
+
+def test_model_choice_table():
+    """The automatic choice at the sizes DESIGN.md quotes (256 CUs, 2.4 GHz): a change of the cost model shows up here."""
+    want = {1024: "f32pk_fused_regs1024", 10000: "f32pk_fused_jpairs", 16384: "f32pk_symw_ipl8_j1_w2048", 40002: "f32pk_symw_ipl16_j1_w1024",
+            65536: "f32pk_symw_ipl16_j1_w2048", 262144: "f32pk_symw_ipl16_j1_w2048_r10t128", 1048576: "f32pk_symw_ipl16_j1_w2048"}
+    for n, prefix in want.items():
+        assert capi.plan_query(n)["variant"].startswith(prefix), (n, capi.plan_query(n)["variant"])
+    assert capi.plan_query(262144, precision="f64")["variant"].startswith("f64_symw_ipl8_j1_w2048")
+    assert capi.plan_query(2500000)["sym"] == 0            # the layers would not fit the budget: ordered pairs
+
+
+def test_bad_arguments_are_errors():
+    with pytest.raises(capi.NBodyError):
+        capi.plan_query(0)
+    with pytest.raises(capi.NBodyError):
+        capi.plan_query(1000, shard=(900, 200))

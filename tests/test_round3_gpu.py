@@ -432,3 +432,12 @@ def test_default_shape_at_an_auto_selected_jpk_size_with_poisoned_partials():
         assert np.isfinite(a).all(), p[3]
     for x, y, z in zip(p[:3], q[:3], r[:3]):
         assert x.tobytes() == y.tobytes() == z.tobytes(), q[3]
+
+
+@pytest.mark.parametrize("n,prec", [(1000, "f32"), (5000, "f32"), (12000, "f32"), (16384, "f32"), (40002, "f32"), (100000, "f32"), (40002, "f64")])
+def test_plan_query_is_what_create_builds(n, prec):
+    """nb_plan_query (the planner on the host alone, tests/test_planner_cpu.py) and nb_create agree on this device."""
+    q = capi.plan_query(n, precision=prec, n_cu=0, clock_hz=0)
+    with Simulation(n, precision=prec) as sim:
+        assert sim.variant == q["variant"]
+        assert sim.shape_info() == {k: q[k] for k in ("jsplit", "j_per_split", "own_split0", "own_splits")}
