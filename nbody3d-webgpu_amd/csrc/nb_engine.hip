@@ -48,14 +48,7 @@ using nbi::fail;
             return fail((s), NB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));              \
     } while (0)
 
-uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
-
-enum Kind { kScalar = 1, kPkLds = 2, kPkSgpr = 3, kFused = 4, kDirect = 5, kJpk = 6, kSym = 7 };   // kDirect: fused, registers only (x = MAXJ/16)
-struct Shape { int kind, ipl, ls, x; };   // x: tile units (LDS kinds) or j-splitting waves (SGPR kind)
-
-bool pow2(int v) { return v >= 1 && (v & (v - 1)) == 0; }
-int sgpr_ws(int x) { return x == 5 ? 4 : x; }   // SGPR kind: x = 5 is WS = 4 with 64-bit pair loads
-int jpk_ws(int x) { return x == 6 ? 16 : x; }    // j-packed kind: x = 6 is 16 waves per workgroup
+using namespace nbp;     // Kind, Shape, ceil_div, ipb_of, ... (nb_plan.h)
 
 // ---- kernel tables ---------------------------------------------------------------------------
 // packed LDS kernels: NG in {1,2,4}, LS in {1,2,4,8,16,32,64}, TL = 1; TL = 4 for LS >= 16
@@ -159,465 +152,28 @@ const void* kernel_of(bool f64, const Shape& sh)
     }
 }
 
-// i-bodies per workgroup
-uint32_t ipb_of(const Shape& sh)
+// Runs the planner (nb_plan.cpp) for a handle and copies its answer into the handle's launch fields.
+void plan_handle(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
 {
-    if (sh.kind == kJpk) return 64;
-    if (sh.kind == kSym) return 64u * (uint32_t)sh.ipl * (sh.x == 4 ? 4u : 1u);      // rows per super-block
-    if (sh.kind == kPkSgpr) return (uint32_t)(nb::kBlock / sgpr_ws(sh.x)) * sh.ipl;
-    return (uint32_t)(nb::kBlock / sh.ls) * sh.ipl;
-}
-
-// force_variant codes: the 6-digit K II LL X form of nbody3d_hip.h, plus the short codes of ABI 1.
-bool decode_variant(uint32_t v, Shape* out)
-{
-    switch (v) {
-        case 1: *out = {kScalar, 1, 1, 1}; return true;
-        case 2: *out = {kScalar, 2, 1, 1}; return true;
-        case 4: *out = {kScalar, 4, 1, 1}; return true;
-        case 14: *out = {kScalar, 1, 4, 1}; return true;
-        case 116: *out = {kScalar, 1, 16, 1}; return true;
-        case 164: *out = {kScalar, 1, 64, 1}; return true;
-        case 22: *out = {kPkLds, 2, 1, 1}; return true;
-        case 24: *out = {kPkLds, 4, 1, 1}; return true;
-        case 28: *out = {kPkLds, 8, 1, 1}; return true;
-        case 34: *out = {kPkSgpr, 4, 1, 1}; return true;
-        case 38: *out = {kPkSgpr, 8, 1, 1}; return true;
-        default: break;
-    }
-    if (v < 100000) return false;
-    Shape sh{(int)(v / 100000), (int)(v / 1000 % 100), (int)(v / 10 % 100), (int)(v % 10)};
-    if (sh.kind < kScalar || sh.kind > kSym || !pow2(sh.ls)) return false;
-    if (sh.kind == kScalar) sh.x = 1;
-    *out = sh;
-    return true;
-}
-
-void name_variant(nb_sim* s, const Shape& sh)
-{
-    char buf[112];
-    if (sh.kind == kPkSgpr)
-        snprintf(buf, sizeof buf, "f32pk_sgpr_ipl%d%s_js%u", sh.ipl, sh.x == 4 ? "_ws4" : sh.x == 5 ? "_ws4p" : "", s->jsplit);
-    else if (sh.kind == kFused)
-        snprintf(buf, sizeof buf, "f32pk_fused_lds%d_ipl%d_ls%d", nb::kTile * sh.x, sh.ipl, sh.ls);
-    else if (sh.kind == kDirect)
-        snprintf(buf, sizeof buf, "f32pk_fused_regs%d_ipl%d_ls%d", 64 * 16 * sh.x, sh.ipl, sh.ls);
-    else if (sh.kind == kJpk)
-        snprintf(buf, sizeof buf, "f32pk_fused_jpairs_ws%d_js%u", jpk_ws(sh.x), s->jsplit);
-    else if (sh.kind == kSym)
-        snprintf(buf, sizeof buf, s->f64 ? (s->sym_rank ? "f64_symwrank_ipl%d_j%d_w%u_r%ut%u" : "f64_symw_ipl%d_j%d_w%u_r%ut%u") : s->sym_rank ? "f32pk_symwrank_ipl%d_j%d_w%u_r%ut%u" : s->symw ? "f32pk_symw_ipl%d_j%d_w%u_r%ut%u" : "f32pk_sym_ipl%d_ws%d_q%u_r%ut%u", sh.ipl, s->symw ? (sh.x == 3 ? 1 : 2) : sh.x,
-                 s->sym_plan[2], s->sym_plan[8] - s->sym_plan[7], s->sym_layers - (s->sym_plan[8] - s->sym_plan[7]));     // words 7, 8: r_layer0, t_layer0 in both plans
-    else
-        snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", s->f64 ? "f64" : "f32", sh.kind == kPkLds ? "pk" : "",
-                 nb::kTile * (sh.kind == kPkLds ? sh.x : 1), sh.ipl, sh.ls, s->jsplit);
-    s->variant = buf;
-}
-
-// Launch-shape model (inputs measured on MI355X: profiles/r01/sweep_*.txt, profiles/r02/).
-//   grid = (i-blocks, jsplit) workgroups of 4 waves, all with the same amount of work, so a
-//   launch runs in rounds of `slots` resident workgroups.  For every kernel shape and split count
-//     t = sum over rounds [ max(compute, latency) + prologue ] / balance + what follows K1
-//       compute  = loop iterations per wave * SIMD cycles per iteration * resident workgroups
-//                  per CU (the waves of a SIMD share its issue port) / fill
-//       latency  = tile stages per wave * ~3000 cycles (global load + LDS store + barrier)
-//       balance  = 1 - 0.03 / rounds, 0.045 for the SGPR kernel (more rounds even out DVFS/tail)
-//       follows  = two-kernel step: the K1 -> K2 boundary (~1.5 us) + K2 reading every split's
-//                  partial back; fused step: nothing (its epilogue is the integrator)
-//   and keeps the minimum.  A split is any multiple of 8 bodies >= 128 -- not a multiple of
-//   the 256-body tile: the kernels run an exact trip count on the last, partial tile -- and
-//   there are at most 128 splits.
-struct Cand { Shape sh; double cyc_iter; };   // SIMD cycles of one wave per loop iteration (= LS j-bodies)
-
-// Constants of the launch-shape model.  A release build compiles them in; the calibration build (`make tuning`:
-// -DNB_TUNING, libnbody3d_hip_tuning.so, used by tools/fit_model.py) reads the NB_MODEL_* environment variables instead.
-struct ModelKnobs {
-    double tile_latency = 3000.0, prologue = 3000.0, hand_over = 350.0, lanes_scale = 1.0;
-    double boundary = 4e-6;    // K1 -> K2 boundary + the K2 launch (refit on shape_scan_final_2k_16k.txt:
-                               // worst regret 8.5 -> 4.8 %, mean 1.6 -> 1.0 % over 14 sizes; fused shapes now to N = 12,000)
-    double sustained = 0.958;  // share of hipDeviceProp_t::clockRate the chip holds under this kernel's load
-                               // (2.24-2.29 of 2.4 GHz measured, profiles/r02/rocprof_f32_default: GRBM_GUI_ACTIVE)
-    double jpk_lo = 7000, jpk_hi = 12500;   // sizes at which the j-packed step is scored at all (see choose_shape)
-};
-#ifdef NB_TUNING
-// calibration build: read on every nb_create, so that one process can walk a grid of constants (tools/fit_model.py)
-ModelKnobs model_knobs()
-{
-    ModelKnobs m;
-    auto knob = [](const char* name, double dflt) { const char* e = getenv(name); return e && *e ? atof(e) : dflt; };
-    m.tile_latency = knob("NB_MODEL_TILE_LATENCY", m.tile_latency); m.prologue = knob("NB_MODEL_PROLOGUE", m.prologue);
-    m.hand_over = knob("NB_MODEL_HANDOVER", m.hand_over); m.lanes_scale = knob("NB_MODEL_LANES_SCALE", m.lanes_scale);
-    m.boundary = knob("NB_MODEL_BOUNDARY", m.boundary); m.sustained = knob("NB_MODEL_SUSTAINED", m.sustained);
-    m.jpk_lo = knob("NB_MODEL_JPK_LO", m.jpk_lo); m.jpk_hi = knob("NB_MODEL_JPK_HI", m.jpk_hi);
-    return m;
-}
-#else
-inline ModelKnobs model_knobs() { return ModelKnobs(); }       // release build: the compiled-in constants, no environment access
-#endif
-
-
-// The symmetric pass, wave-granular form (nb_force_symw<NG, 1>): predicted step time for n bodies with 2*NG residents per lane
-// and k waves per SIMD.  A chunk-sweep is 64 rotation steps of NG * (16 packed + 2 transcendental) + 10 DPP issue slots; the
-// loop runs at 93.5 % of that.  The L chunk-sweeps are cut into W = k * SIMDs equal ranges:
-//   k = 1: ceil(L / SIMDs) sweeps per SIMD, 1.9 % slower per sweep (nothing hides a chunk's traveler loads);
-//   k = 2: a wave gets floor or ceil(L / 2 SIMDs) sweeps; with a share p of ceil-waves a SIMD's two waves both round up
-//          about min(1, 2p) of the time somewhere on the chip: 2 floor + 2 min(1, 2p) sweeps, 1 % over the bare rate
-//          (N = 40,002: 13.64 predicted, 13.66 measured; 32,768: 8.5 / 8.9; 65,536: 33 / 32.7; 14,000: 4 / 4.1);
-//   + 3.5 us of kernel fixed cost, 1.5 us per super-block a range touches, the K1 -> K2 boundary and K2's layer traffic
-//   (12 B per layer and body at ~5 TB/s: the layers are Infinity-Cache resident).  16 residents per lane run ~1.5 % closer to
-//   their issue count than 8 (half the rotations per pair).
-// Fitted on profiles/r03/sym_variants_scan_wave_granular*.txt (N = 12,000 .. 262,144, both resident counts: within 2 %);
-// 4 residents per lane (half the chunk-sweep of 8: finer rounding) win from N ~ 14,000 to 18,000 (sym_4_residents_per_lane.txt);
-// k = 3 measured behind k = 2 (N = 131,072: 2,682 vs 2,615 us).
-struct SymChoice { int ipl; uint32_t k; double t; };
-
-// Bytes of partial-sum layers a symmetric handle allocates: one traveler layer per ring distance, i.e. ~ 3 * esz * N^2 / (2 S)
-// (N = 1,048,576 with 1,024-row super-blocks: 6.4 GB; it grows with N^2, so very large systems fall back to the ordered-pair kernels).
-double sym_layer_bytes(uint32_t n, uint32_t S, size_t esz)
-{
-    const double nsb = std::ceil((double)n / S);
-    return (nsb / 2.0 + 8.0) * nsb * S * 3.0 * (double)esz;
-}
-constexpr double kSymLayerBudget = 16.0e9;
-
-SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64)
-{
-    SymChoice best{0, 0, 1e300};
-    for (int ipl : {4, 8, 16}) {
-        if (f64 && ipl != 8) continue;              // nb_force_symw64<8>: 8 residents per lane, 19 DP instructions + v_rsq_f64 per pair
-        const uint32_t NG = (uint32_t)ipl / 2, S = 64u * (uint32_t)ipl, cps = S / 64u;
-        const uint32_t nsb = ceil_div(n, S);
-        if (nsb < 4) continue;
-        if (sym_layer_bytes(n, S, f64 ? 8 : 4) > kSymLayerBudget) continue;
-        const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
-        const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (uint64_t)(H + 1) * cps;
-        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo;
-        // f64: 92 issue cycles per resident and step + 14 DPP; the loop runs at 96 % of that (N = 262,144: 23.7 ms, profiles/r03/sym_f64_first.txt)
-        const double t_chunk = f64 ? 64.0 * (92.0 * ipl + 56.0) / 0.96 / clock : 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.95 : 0.935) / clock;
-        const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
-        if (per_simd < 1.0) continue;
-        for (uint32_t k = 1; k <= 2; ++k) {
-            const double pw = per_simd / 2.0, fl = std::floor(pw);
-            const double sweeps = k == 1 ? std::ceil(per_simd) * 1.019 : (2.0 * fl + 2.0 * std::min(1.0, 2.0 * (pw - fl))) * 1.01;
-            const double segs = per_simd / k / (double)total_lo + 1.0;             // super-blocks a wave's range touches
-            const double layers = (double)(H + 1) + (double)total_hi * k / per_simd + 1.0;     // traveler + resident layers K2 reads per body
-            const double t = sweeps * t_chunk + 3.5e-6 + segs * 1.5e-6 + boundary + layers * n * (f64 ? 24.0 : 12.0) / 5.0e12;
-            if (t < best.t) best = {ipl, k, t};
-        }
-    }
-    return best;
-}
-
-void choose_shape(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
-{
-    const uint32_t sc = s->sc, n = s->n;
-    const uint32_t kMaxSplit = 128, kMinSplitLen = 128;
-    const ModelKnobs mk = model_knobs();
-    const double kTileLatency = mk.tile_latency, kPrologue = mk.prologue, kClock = clock_hz * mk.sustained;
-    const double kHandOver = mk.hand_over, kLanesScale = mk.lanes_scale, kBoundary = mk.boundary;
-    auto split_len = [&](uint32_t js) { return ceil_div(ceil_div(n, js), 8u) * 8u; };
-    // an explicit shard (even one that covers every row: a 1-rank distributed run) keeps the
-    // two-kernel step, whose position array stays put for the exchange
-    const bool whole = sc == n && s->sb == 0 && cfg.shard_count == 0;
-    const bool may_fuse = !s->f64 && whole && !cfg.ext_bodies && !(cfg.flags & NB_FLAG_NO_FUSE);
-
-    std::vector<Cand> cands;
-    if (s->f64) {
-        // 15 DP instructions (4 cycles) + v_rsq_f64 (16) per pair, +7 % for LDS reads / loop (ubench3)
-        cands = {{{kScalar, 4, 1, 1}, 326}, {{kScalar, 2, 1, 1}, 172}, {{kScalar, 1, 1, 1}, 92},
-                 {{kScalar, 1, 4, 1}, 98}, {{kScalar, 1, 16, 1}, 100}, {{kScalar, 1, 64, 1}, 104}};
-    } else {
-        // packed: 64 issue cycles per (j, 2 i-bodies) + ~6 % LDS/loop overhead
-        for (int ipl : {8, 4, 2})
-            for (int ls : {1, 2, 4, 8, 16, 32, 64})
-                for (int tl : {1, 4, 8}) {
-                    if (tl == 4 && ls < 16) continue;
-                    if (tl == 8 && ls < 32) continue;
-                    // 2 per lane: lane-sharing shapes carry no mass v_mov any more (0.97, refit on shape_scan_after_hi_broadcast.txt);
-                    // one lane per body keeps the round-2 figure (1.05): 0.97 there pulled N = 12,000 .. 32,768 off the SGPR kernel (-1..-6 %)
-                    const double cyc = 34.0 * ipl * (ipl == 2 ? (ls == 1 ? 1.05 : 0.97) : 1.0);
-                    cands.push_back({{kPkLds, ipl, ls, tl}, cyc});
-                    if (may_fuse) cands.push_back({{kFused, ipl, ls, tl}, cyc});
-                }
-        // SGPR loop, bodies fetched as quads (s_load_dwordx4).  Since z is taken from the (z, m) SGPR pair by an explicit
-        // low-half broadcast and the loop body is one basic block, it carries NO VALU instruction beside the pair
-        // arithmetic (224 / 448 per 8 bodies at 4 / 8 bodies per lane; the mass moves by s_mov_b32).  The 64-bit
-        // pair-load form (X = 5: twice the scalar requests, measured ahead only while the quad form still copied z and
-        // m through VGPRs) is now behind it at every size -- N=262,144: 14.58 vs 14.70 ms, N=40,002: 351 vs 357 us
-        // (profiles/r02/ab_sgpr_zbcast.txt) -- and stays selectable as an A/B arm only.
-        for (int ipl : {8, 4})
-            for (int ws : {1, 4}) cands.push_back({{kPkSgpr, ipl, 1, ws}, (ipl == 8 ? 32.0 : 32.2) * ipl});
-        // registers-only fused step: no tile hand-over at all (64 issue cycles per j, nothing to wait for)
-        if (may_fuse && n <= 1024) cands.push_back({{kDirect, 2, 64, 1}, 64.0});
-        if (may_fuse && n <= 1536) cands.push_back({{kDirect, 2, 64, 2}, 64.0});   // at 2,048 the 2,048-body LDS stage is 5 % ahead
-    }
-
-    Shape sh{s->f64 ? kScalar : kPkLds, 2, 1, 1};
-    uint32_t js = cfg.jsplit, sym_k = 0;
-    // NB_FLAG_SYM_SHARD: a rank's shard whose cross-rank reduction the engine's native exchange provides takes the RANK form of the
-    // symmetric pass when its rows are whole super-blocks (1,024 rows, or 512); otherwise the flag is ignored
-    int rank_ipl = 0;
-    if ((cfg.flags & NB_FLAG_SYM_SHARD) && !(cfg.flags & NB_FLAG_NO_SYM) && !cfg.ext_bodies && cfg.shard_count != 0)
-        for (uint32_t S : {1024u, 512u})
-            if (!rank_ipl && !(s->f64 && S != 512u) && s->sb % S == 0 && sc % S == 0 && n % S == 0 && n / S >= 2 &&        // f64: 8 residents per lane only
-                sym_layer_bytes(n, S, s->esz) <= kSymLayerBudget) rank_ipl = (int)(S / 64u);
-    const uint32_t variant = rank_ipl ? 0u : cfg.force_variant;
-    bool pinned = false;
-    if (rank_ipl) { sh = {kSym, rank_ipl, 1, 3}; pinned = true; if (js == 0) js = 0xffffffffu; }     // js: placeholder, set with the plan below
-    if (variant != 0) {
-        Shape want;
-        if (decode_variant(variant, &want)) {
-            if (s->f64 && want.kind != kScalar && want.kind != kSym) want = {kScalar, want.ipl > 4 ? 4 : want.ipl, 1, 1};
-            if ((want.kind == kFused || want.kind == kDirect) && !may_fuse && !s->f64) want = {kPkLds, want.ipl, want.ls, 1};   // same loop, two kernels
-            if (want.kind == kDirect && n > 1024u * (uint32_t)want.x) want = {kFused, 2, 64, 4};
-            if (want.kind == kJpk && !may_fuse) want = {kPkSgpr, 4, 1, 4};      // whole-system f32 handles only
-            if (want.kind == kSym && (!whole || cfg.ext_bodies || !kernel_of(s->f64, want) || n <= ipb_of(want) ||       // likewise; >= 2 super-blocks,
-                                      sym_layer_bytes(n, ipb_of(want), s->esz) > 4.0 * kSymLayerBudget))                  // and layers that fit (pinned: 64 GB)
-                want = s->f64 ? Shape{kScalar, 4, 1, 1} : Shape{kPkSgpr, 8, 1, 4};
-            if (kernel_of(s->f64, want)) { sh = want; pinned = true; }
-        }
-    }
-    if (!rank_ipl && (!pinned || js == 0)) {
-        struct Scored { Shape sh; uint32_t q; double t; };
-        std::vector<Scored> scored;
-        double best_t = 1e300;
-        for (const Cand& c : cands) {
-            if (pinned && !(c.sh.kind == sh.kind && c.sh.ipl == sh.ipl && c.sh.ls == sh.ls && c.sh.x == sh.x)) continue;
-            if (!pinned && (cfg.flags & NB_FLAG_LDS_ONLY) && c.sh.kind == kPkSgpr) continue;
-            const void* fn = kernel_of(s->f64, c.sh);
-            if (!fn) continue;
+    PlanInput in;
+    in.n = s->n; in.sb = s->sb; in.sc = s->sc; in.f64 = s->f64; in.cfg = cfg; in.n_cu = n_cu; in.clock_hz = clock_hz;
+    if (!s->no_device)
+        in.occupancy = [f64 = s->f64](const Shape& sh, int block) {
             int occ = 0;
-            if (s->no_device || hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, nb::kBlock, 0) != hipSuccess || occ < 1) {
-                (void)hipGetLastError();
-                occ = 4;
-            }
-            if (occ > 8) occ = 8;
-            const uint64_t slots = (uint64_t)occ * n_cu;
-            const uint32_t iblocks = ceil_div(sc, ipb_of(c.sh));
-            uint32_t js_hi = n / kMinSplitLen;
-            if (js_hi < 1) js_hi = 1;
-            if (js_hi > kMaxSplit) js_hi = kMaxSplit;
-            if (c.sh.kind == kFused || c.sh.kind == kDirect) js_hi = 1;
-            uint32_t js_lo = cfg.jsplit ? cfg.jsplit : 1, js_top = cfg.jsplit ? cfg.jsplit : js_hi;
-            if (c.sh.kind == kFused || c.sh.kind == kDirect) { if (cfg.jsplit > 1) continue; js_lo = js_top = 1; }
-            for (uint32_t q = js_lo; q <= js_top; ++q) {
-                const uint32_t len = split_len(q), used = ceil_div(n, len);
-                if (c.sh.kind == kPkSgpr && len / sgpr_ws(c.sh.x) < 256) continue;   // SGPR loop wants >= 256 bodies per wave
-                if (c.sh.kind == kPkSgpr && c.sh.x == 5 && len / 4 < (c.sh.ipl == 8 ? 6144u : 320u)) continue;   // pair loads: long loops only
-                const uint64_t blocks = (uint64_t)iblocks * used;
-                if (c.sh.kind == kPkSgpr && c.sh.x == 5 && c.sh.ipl == 4 && 2 * blocks < 3 * slots) continue;   // >= 1.5 rounds
-                const uint64_t full = blocks / slots, rem = blocks % slots;
-                const double tile = c.sh.kind == kPkSgpr ? 256.0 : 256.0 * c.sh.x;
-                const double wave_len = c.sh.kind == kPkSgpr ? (double)len / sgpr_ws(c.sh.x) : (double)len;
-                const double stages = c.sh.kind == kDirect ? 0.5 : std::ceil(wave_len / tile);
-                const double iters = std::ceil(wave_len / c.sh.ls);
-                // a SIMD with fewer than 4 resident waves cannot keep its issue port full
-                // (measured with the pure-ALU loop, profiles/r01/ubench_run1.txt, profiles/r02/ubench3_*.txt)
-                // Share of the issue rate a SIMD reaches with 4 / 3 / 2 / 1 resident waves, and the hand-over
-                // cost per tile stage: least-regret fit over 208 (size, shape) timings, N = 1,024 .. 65,536
-                // (profiles/r02/shape_scan_run5_calibrated.txt, shape_scan_run6_tl8.txt; worst mis-pick 1.6 %).
-                // SGPR loop: no barriers, no tile hand-over.  LDS tiles shared by LS > 1 lanes: 45 % of a tile
-                // period was hand-over at low occupancy with register staging (ubench4_tile_phases.txt); with
-                // LDS-DMA staging the per-stage charge went from 500 to 350 cycles (tools/fit_model.py over
-                // profiles/r02/shape_scan_dma_{a,b}.txt: worst regret 2.9 %, mean 0.5 % at 16 sizes).  LS = 1: the round-1 figures.
-                const bool sg = c.sh.kind == kPkSgpr, lanes = !sg && c.sh.ls > 1;
-                auto round_cycles = [&](double per_cu) {
-                    const int k = per_cu >= 4 ? 0 : per_cu >= 3 ? 1 : per_cu >= 2 ? 2 : 3;
-                    static const double f_sgpr[4] = {1.0, 0.92, 0.94, 0.62}, f_lanes[4] = {0.72, 0.75, 0.85, 0.75},
-                                        f_tile[4] = {1.0, 0.92, 0.82, 0.62};
-                    const double fill = sg ? f_sgpr[k] : lanes ? f_lanes[k] * kLanesScale : f_tile[k];
-                    return std::max(iters * per_cu * c.cyc_iter / fill, stages * kTileLatency) + kPrologue + (lanes ? stages * kHandOver : 0.0);
-                };
-                double cyc = full * round_cycles(occ);
-                if (rem) cyc += round_cycles((double)ceil_div((uint32_t)rem, (uint32_t)n_cu));
-                const double rounds = (double)full + (rem ? 1 : 0);
-                // every i-block streams all n rows through L2 once per step: what rules out many
-                // lanes per body at large N (f64, 64 lanes per body, N=262,144: 550 GB per step)
-                const double stream_s = (double)iblocks * n * 4 * s->esz / 8.0e12;
-                // K2 reads every split's partial back (and K1 writes it): priced at 2 TB/s so that, when the
-                // balance gain is a wash (N = 262,144: 8 vs 16 splits), the smaller HBM footprint wins
-                const double after = (c.sh.kind == kFused || c.sh.kind == kDirect) ? 0.0 : (double)used * sc * 4 * s->esz / 2.0e12 + kBoundary;
-                // balance: the last round runs partly empty and the first at a lower clock.  SGPR kernel at
-                // N = 262,144: 2 / 3 / 4 / 6 / 8 rounds lose 2.0 / 1.1 / 0.7 / 0.5 / 0 % (sweep_sgpr_pair_loads.txt)
-                const double t = std::max(cyc / kClock, stream_s) / (1.0 - (sg ? 0.045 : 0.03) / rounds) + after;
-                scored.push_back({c.sh, q, t});
-                if (t < best_t) best_t = t;
-            }
-        }
-        // The j-packed fused step (force_variant K = 6; whole-system f32 handles): 64 i-bodies per workgroup of ws
-        // waves, the j-pairs split over ws waves x q workgroups.  One scalar request (4 pairs, 256 issue cycles)
-        // is in flight per wave and returns after ~1,100 cycles, so a SIMD needs > 4 resident waves to stay
-        // busy.  Since its partial rows go out write-through (no release fence per workgroup) its split forms are the
-        // fastest ORDERED-PAIR step from N ~ 8,000 to ~ 18,000 (through the engine: 8,192 19.9 vs 20.4 us, 10,000 28.7 vs 31.7,
-        // 12,000 39.1 vs 41.2, 14,000 50.8 vs 51.4, 16,384 64.5 vs 65.3; level at 20,000 and behind above and below:
-        // profiles/r02/shape_scan_jpk_sc1.txt).  The automatic choice offers it from 7,000 to 12,500, where it wins by 5-10 %
-        // whatever split count this model lands on; from 13,000 to 20,000 the margin is 1-2 % with the best split and the
-        // model's split choice is off by more than that (size_scan_jpk_auto.txt), so the SGPR step stays there.
-        // The two bounds are model constants (ModelKnobs::jpk_lo / jpk_hi).  Scored at every size instead (profiles/r03/
-        // size_scan_2k_15k_jpk_no_window.txt) this cost model picks it at 5,000 / 6,000 (1-4 % behind the LDS-tile step) and at
-        // 13,000 (5 % behind the symmetric pass), and wins 8 % at 14,000: its estimate is good to ~5 %, the window is where it
-        // wins by more than that.
-        if (may_fuse && (pinned ? sh.kind == kJpk : (!(cfg.flags & NB_FLAG_LDS_ONLY) && n >= (uint32_t)mk.jpk_lo && n <= (uint32_t)mk.jpk_hi))) {
-            const uint32_t units = ((ceil_div(ceil_div(n, 2u), 4u) + 1u) & ~1u);
-            for (int x : {4, 8, 6}) {
-                const Shape jsh{kJpk, 1, 1, x};
-                if (pinned && sh.x != x) continue;
-                const int ws = jpk_ws(x);
-                int occ = 0;
-                if (s->no_device || hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kernel_of(false, jsh), 64 * ws, 0) != hipSuccess || occ < 1) {
-                    (void)hipGetLastError();
-                    occ = 28 / ws;
-                }
-                const uint32_t iblocks = ceil_div(n, 64u);
-                const uint32_t q_lo = cfg.jsplit ? cfg.jsplit : 1, q_hi = cfg.jsplit ? cfg.jsplit : 16;
-                for (uint32_t q = q_lo; q <= q_hi; ++q) {
-                    const uint32_t upw = 2 * ceil_div(units / 2, (uint32_t)ws * q);
-                    if (upw < 8 && !cfg.jsplit && q > 1) continue;              // at least 64 bodies per wave
-                    const uint64_t blocks = (uint64_t)iblocks * q, slots = (uint64_t)occ * n_cu;
-                    const uint64_t full = blocks / slots, rem = blocks % slots;
-                    auto round_cycles = [&](double per_cu) {
-                        const double waves_per_simd = per_cu * ws / 4.0;
-                        return upw * std::max(260.0 * waves_per_simd, 1100.0) + 4000.0;
-                    };
-                    double cyc = full * round_cycles(occ);
-                    if (rem) cyc += round_cycles((double)ceil_div((uint32_t)rem, (uint32_t)n_cu));
-                    const double rounds = (double)full + (rem ? 1 : 0);
-                    const double t = cyc / kClock / (1.0 - 0.03 / rounds) + (q > 1 ? 1.0e-6 : 0.0);
-                    scored.push_back({jsh, q, t});
-                    if (t < best_t) best_t = t;
-                }
-            }
-        }
-        // Among the shapes within 0.4 % of the best estimate take the one with the FEWEST j-splits:
-        // measured at N = 262,144, 8 / 16 / 32 splits differ by 0.1-0.3 % in step time
-        // (profiles/r02/sweep_jsplit_n262144.txt) while every split is another partial array
-        // written by K1 and read back by K2.
-        const Scored* pick = nullptr;
-        for (const Scored& c : scored) {
-            if (c.t > best_t * 1.004) continue;
-            if (!pick || c.q < pick->q || (c.q == pick->q && c.t < pick->t)) pick = &c;
-        }
-        if (pick) { if (!pinned) sh = pick->sh; js = pick->q; }
-        // the symmetric pass (whole-system f32 handles; every unordered pair once): from N ~ 14,000 up it beats every
-        // ordered-pair shape above (N = 16,384: 61.7 vs 65.7 us, 40,002: 270 vs 357 us, 262,144: 10.5 vs 14.6 ms)
-        if (!pinned && whole && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
-            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, s->f64);
-            if (sc2.ipl && sc2.t < 0.98 * (pick ? pick->t : best_t)) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; }     // a clear win only: both estimates are good to ~3 %
-        }
-    }
-    if (js < 1) {   // pinned shape outside the model's candidate list: fill ~4096 workgroups
-        js = ceil_div((uint32_t)n_cu * 16, ceil_div(sc, ipb_of(sh)));
-        const uint32_t hi = n / kMinSplitLen < 1 ? 1 : (n / kMinSplitLen > kMaxSplit ? kMaxSplit : n / kMinSplitLen);
-        if (js > hi) js = hi;
-        if (js < 1) js = 1;
-    }
-    if (sh.kind == kFused || sh.kind == kDirect) js = 1;
-    if (sh.kind == kSym && sh.x != 4) {
-        // wave-granular form: super-block = one wave's residents; the chunk lists of all super-blocks laid end to end are cut
-        // into W equal ranges, W = cfg.jsplit (default 1) waves per SIMD of the chip.
-        const uint32_t S = ipb_of(sh), J = sh.x == 3 ? 1u : 2u, cps = S / (64u * J);
-        const uint32_t nsb = ceil_div(n, S), H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
-        nb::SymWPlan pl;
-        pl.np = nsb * S; pl.nsb = nsb;
-        pl.total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps; pl.total_lo = (H + 1) * cps;
-        pl.n_hi = n_hi; pl.H = H;
-        auto offset_of = [&](uint32_t g) { return g <= n_hi ? g * pl.total_hi : n_hi * pl.total_hi + (g - n_hi) * pl.total_lo; };
-        // a whole system sweeps every super-block's list; a rank (rank_ipl) only those of its own rows
-        const uint32_t g0 = rank_ipl ? s->sb / S : 0u, g1 = rank_ipl ? (s->sb + sc) / S : nsb;
-        pl.p0 = offset_of(g0);
-        pl.L = offset_of(g1) - pl.p0;
-        const uint32_t kw = sym_k ? sym_k : (cfg.jsplit ? cfg.jsplit : (rank_ipl && pl.L >= 16u * (uint32_t)n_cu ? 2u : 1u));
-        uint32_t W = 4u * (uint32_t)n_cu * kw;
-        if (W > pl.L) W = (pl.L + 3u) & ~3u;
-        pl.W = W;
-        auto start_of = [&](uint32_t w) { return (uint32_t)(((uint64_t)w * pl.L) / pl.W); };
-        auto wave_of = [&](uint32_t p) {              // p: position inside this handle's range
-            uint32_t w = (uint32_t)(((uint64_t)p * pl.W) / pl.L);
-            while (w + 1 < pl.W && start_of(w + 1) <= p) ++w;
-            while (w > 0 && start_of(w) > p) --w;
-            return w;
+            const void* fn = kernel_of(f64, sh);
+            if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, fn, block, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+            return occ;
         };
-        s->sym_tab_host.assign(2 * (size_t)nsb, 0);
-        uint32_t max_r = 1;
-        for (uint32_t g = g0; g < g1; ++g) {
-            const uint32_t total = g < n_hi ? pl.total_hi : pl.total_lo;
-            const uint32_t off = offset_of(g) - pl.p0;
-            const uint32_t first = wave_of(off), last = wave_of(off + total - 1);
-            s->sym_tab_host[2 * g] = first; s->sym_tab_host[2 * g + 1] = last - first + 1;
-            if (last - first + 1 > max_r) max_r = last - first + 1;
-        }
-        s->sym_rank = rank_ipl != 0; s->sym_g0 = g0; s->sym_g1 = g1;
-        pl.r_layer0 = 0; pl.t_layer0 = max_r;
-        static_assert(sizeof(pl) <= sizeof(s->sym_plan), "nb_sim::sym_plan holds a SymWPlan");
-        memcpy(s->sym_plan, &pl, sizeof pl);
-        s->sym = true; s->symw = true; s->sym_np = pl.np; s->sym_layers = max_r + H + (n_hi ? 1u : 0u);
-        s->ipl = sh.ipl; s->ls = 1; s->packed = !s->f64; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
-        s->ws = sh.x; s->tl = 1;
-        s->jsplit = max_r; s->j_per_split = ceil_div(pl.L, pl.W) * 64u * J; s->swap_acc = false; s->own_split0 = 0; s->own_splits = 0;
-        name_variant(s, sh);
-        return;
-    }
-    if (sh.kind == kSym) {
-        // workgroup form: super-blocks of S rows on a ring; workgroup (g, q) sweeps segment q of Q of g's chunk list (the H or
-        // H+1 super-blocks ahead on the ring, then g itself in resident-only mode).  cfg.jsplit, if given, is Q.
-        // One wave per SIMD already issues this loop at ~90 % of its rate (profiles/r03/symsweep_*.txt), so what matters is
-        // that every CU gets the same number of equal workgroups: time ~ ceil(nsb * Q / CUs) * ceil(chunks / Q) sweeps.
-        const uint32_t S = ipb_of(sh), cps = S / 128u;
-        const uint32_t nsb = ceil_div(n, S), H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
-        const uint32_t total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (H + 1) * cps;     // + the resident-only chunks of g itself
-        uint32_t q = cfg.jsplit;
-        if (q == 0) {
-            double best = 1e300;
-            for (uint32_t c = 1; c <= total_hi && c <= 512; ++c) {
-                const double t = (double)ceil_div(nsb * c, (uint32_t)n_cu) * (ceil_div(total_hi, c) + 0.15);   // + ~15 % of a sweep per workgroup
-                if (t < best * 0.999) { best = t; q = c; }
-            }
-        }
-        if (q > total_hi) q = total_hi;
-        if (q < 1) q = 1;
-        nb::SymPlan pl;
-        pl.np = nsb * S; pl.nsb = nsb; pl.q = q; pl.total_hi = total_hi; pl.total_lo = total_lo;
-        pl.n_hi = n_hi; pl.H = H; pl.r_layer0 = 0; pl.t_layer0 = q;
-        static_assert(sizeof(pl) <= sizeof(s->sym_plan), "nb_sim::sym_plan holds a SymPlan");
-        memcpy(s->sym_plan, &pl, sizeof pl);
-        s->sym = true; s->sym_np = pl.np; s->sym_layers = q + H + (n_hi ? 1u : 0u);
-        s->ipl = sh.ipl; s->ls = 1; s->packed = true; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
-        s->ws = sh.x; s->tl = 1;
-        s->jsplit = q; s->j_per_split = ceil_div(total_hi, q) * 128u; s->swap_acc = false; s->own_split0 = 0; s->own_splits = 0;
-        name_variant(s, sh);
-        return;
-    }
-    s->ipl = sh.ipl; s->ls = sh.ls;
-    s->packed = sh.kind != kScalar; s->sgpr = sh.kind == kPkSgpr;
-    s->fused = sh.kind == kFused || sh.kind == kDirect || sh.kind == kJpk;
-    s->direct = sh.kind == kDirect;
-    s->jpk = sh.kind == kJpk;
-    s->ws = (sh.kind == kPkSgpr || sh.kind == kJpk) ? sh.x : 1;
-    s->tl = (sh.kind == kPkLds || sh.kind == kFused || sh.kind == kDirect) ? sh.x : 1;
-    if (s->jpk) {
-        // j in whole 4-pair units, an even number per wave; splits that would be empty are dropped
-        const uint32_t units = ((ceil_div(ceil_div(n, 2u), 4u) + 1u) & ~1u);
-        if (js > 64) js = 64;
-        s->junits = 2 * ceil_div(units / 2, (uint32_t)jpk_ws(sh.x) * js);
-        s->jsplit = ceil_div(units, s->junits * (uint32_t)jpk_ws(sh.x));
-        s->j_per_split = s->junits * (uint32_t)jpk_ws(sh.x) * 8;
-        s->swap_acc = false; s->own_split0 = 0; s->own_splits = 0;
-        name_variant(s, sh);
-        return;
-    }
-    s->j_per_split = split_len(js);
-    s->jsplit = ceil_div(n, s->j_per_split);   // a split may end up empty after rounding
-    s->swap_acc = !s->fused && s->jsplit == 1;
-    // j-splits that lie ENTIRELY inside this shard's own rows: what the overlapped exchange issues before it waits for
-    // the other ranks' rows (an in-place all-gather never writes the rank's own rows).  The shard need not be a whole
-    // number of splits: a split that straddles a shard boundary simply belongs to the second launch.
-    s->own_split0 = 0; s->own_splits = 0;
-    if (sc < n) {
-        const uint32_t end = s->sb + sc;
-        const uint32_t first = ceil_div(s->sb, s->j_per_split);
-        const uint32_t last = end == n ? s->jsplit : end / s->j_per_split;     // one past the last whole split inside
-        if (last > first) { s->own_split0 = first; s->own_splits = last - first; }
-    }
-    name_variant(s, sh);
+    LaunchPlan p = plan_launch(in);
+    s->ipl = p.ipl; s->ls = p.ls; s->ws = p.ws; s->tl = p.tl;
+    s->packed = p.packed; s->sgpr = p.sgpr; s->fused = p.fused; s->direct = p.direct; s->jpk = p.jpk; s->swap_acc = p.swap_acc;
+    s->jsplit = p.jsplit; s->j_per_split = p.j_per_split; s->junits = p.junits; s->own_split0 = p.own_split0; s->own_splits = p.own_splits;
+    s->sym = p.sym; s->symw = p.symw; s->sym_rank = p.sym_rank;
+    s->sym_np = p.sym_np; s->sym_layers = p.sym_layers; s->sym_g0 = p.sym_g0; s->sym_g1 = p.sym_g1;
+    static_assert(sizeof(s->sym_plan) == sizeof(p.sym_plan), "nb_sim::sym_plan mirrors LaunchPlan::sym_plan");
+    memcpy(s->sym_plan, p.sym_plan, sizeof s->sym_plan);
+    s->sym_tab_host = std::move(p.sym_tab_host);
+    s->variant = std::move(p.variant);
 }
 
 Shape shape_of(const nb_sim* s)
@@ -1035,7 +591,7 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     if (cfg.ext_stream || (cfg.flags & NB_FLAG_EXT_STREAM)) { s->stream = (hipStream_t)cfg.ext_stream; s->own_stream = false; }
     else { NB_HIPC(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
 
-    choose_shape(s, cfg, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256,
+    plan_handle(s, cfg, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256,
                  prop.clockRate > 0 ? 1e3 * prop.clockRate : 2.4e9);     // clockRate is in kHz
     if (!kernel_of(s->f64, shape_of(s))) return bail(NB_ERR_INVALID, "nb_create: no kernel for shape " + s->variant);
 
@@ -1408,8 +964,9 @@ int nb_plan_query(const nb_config* cfg_in, int n_cu, double clock_hz, nb_plan_in
     nb_sim tmp;                                    // host fields only: nothing of it is ever allocated on a device
     tmp.n = cfg.n; tmp.sb = sb; tmp.sc = sc; tmp.f64 = cfg.precision == NB_F64; tmp.esz = tmp.f64 ? 8 : 4; tmp.eps2 = eps2;
     tmp.no_device = count <= 0;
-    choose_shape(&tmp, cfg, n_cu, clock_hz);
+    plan_handle(&tmp, cfg, n_cu, clock_hz);
     const Shape sh = shape_of(&tmp);
+    if (!kernel_of(tmp.f64, sh)) return fail(nullptr, NB_ERR_INVALID, "nb_plan_query: no kernel for shape " + tmp.variant);
     const uint32_t size = out->struct_size;
     memset(out, 0, sizeof *out);
     out->struct_size = size;

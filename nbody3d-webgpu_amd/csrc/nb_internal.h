@@ -3,6 +3,7 @@
 // nb_multi).  Not part of the ABI.
 #pragma once
 #include "../../include/nbody3d_hip.h"
+#include "nb_plan.h"
 
 #include <hip/hip_runtime.h>
 

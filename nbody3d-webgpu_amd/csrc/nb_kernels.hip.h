@@ -49,6 +49,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "nb_plan.h"
+
 namespace nb {
 
 template <typename T> struct vec4;
@@ -89,8 +91,7 @@ __device__ unsigned long long* nb_stamp_buf;
 #define NB_STAMP_LIGHT(k) do { } while (0)
 #endif
 
-constexpr int kBlock = 256;  // threads per workgroup = reference TILE_SIZE (nbody3d.js:4,240)
-constexpr int kTile = 256;   // j-bodies per LDS tile unit (nbody3d.js:229); TL units are staged at once
+// kBlock (threads per workgroup = reference TILE_SIZE) and kTile (j-bodies per LDS tile unit): nb_plan.h
 
 // Whole-row global loads.  HIP's float4/double4 are structs of scalars: a plain `bodies[j]` is
 // four scalar loads that the backend re-merges as it sees fit (seen: dwordx2 + dwordx3 + dwordx2
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void nb_force(const typename vec4<T>::type*
         const bool more = (t + 1 < ntiles);
         if (more) nxt = stage(t + 1);        // global load in flight under the tile's compute
         // j-bodies of this tile that are inside the split (the last tile of a split is
-        // usually partial: splits are not tile multiples, see choose_shape); the loop runs
+        // usually partial: splits are not tile multiples, see plan_launch in nb_plan.cpp); the loop runs
         // in chunks of CH iterations, entries past the range are staged zero-mass bodies
         const uint32_t left = j1 - (j0 + t * kTile);
         const int cnt = left < (uint32_t)kTile ? (int)left : kTile;
@@ -1041,13 +1042,7 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
 // Rows [n, np) of `bodies` are zero-mass bodies at the origin (np = nsb * S).
 template <typename T> struct SymRowT { T x, y, z; };   // a partial row: 12 bytes in f32 (an ext_vector_type(3) would be padded to 16), 24 in f64
 using SymRow = SymRowT<float>;
-struct SymPlan {
-    uint32_t np, nsb;          // padded rows, super-blocks
-    uint32_t q;                // segments per super-block's chunk list (workgroups per super-block)
-    uint32_t total_hi, total_lo;   // chunks in the list of a super-block g < n_hi (it has the antipodal partner) / of the others
-    uint32_t n_hi, H;          // n_hi = nsb/2 when nsb is even, else 0; H = (nsb-1)/2
-    uint32_t r_layer0, t_layer0;
-};
+// struct SymPlan: nb_plan.h (the host's planner fills it)
 
 __device__ __forceinline__ float wave_rot1(float v)
 {
@@ -1202,14 +1197,7 @@ void nb_force_sym(const float4* __restrict__ bodies, SymRow* __restrict__ partia
 // any N (the workgroup form above needs nsb * Q to land on a multiple of the CU count).  A wave whose range crosses into the
 // next super-block stores its resident sums, reloads its residents and goes on; its resident sums of super-block g go to
 // layer r_layer0 + (w - first wave of g) (table `gtab`: first wave and wave count per super-block, built by the host).
-struct SymWPlan {
-    uint32_t np, nsb, W;
-    uint32_t total_hi, total_lo, n_hi, H;
-    uint32_t r_layer0, t_layer0;
-    uint32_t L;                 // chunk-sweeps of this handle: n_hi * total_hi + (nsb - n_hi) * total_lo for a whole system
-    uint32_t p0;                // where this handle's range starts in the global list (0 for a whole system; a RANK that owns
-                                // the resident super-blocks [g0, g1) works on the lists of those super-blocks only)
-};
+// struct SymWPlan: nb_plan.h
 
 template <int NG, int J>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : (NG < 4 ? 8 : 4))))

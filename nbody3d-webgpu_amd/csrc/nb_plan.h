@@ -1,0 +1,79 @@
+// nb_plan.h -- the launch planner's interface: plain host C++ (no HIP), shared by the engine (nb_engine.hip, nb_comm.hip) and
+// the kernels (nb_kernels.hip.h takes the plan structs below as kernel arguments).
+//
+// The reference dispatches ceil(N / 256) workgroups of one fixed kernel (nbody3d.js:296-311,478).  Here the force pass has
+// several forms (ordered pairs through an LDS tile / SGPR broadcast / fused with the integrator, the symmetric pass), and
+// nb_plan.cpp picks one per handle with a cost model and lays out its partitions.  Everything in here is deterministic
+// host arithmetic on (n, shard, precision, flags, CU count, clock): nb_plan_query exposes it without a device and
+// tests/test_planner_cpu.py checks the plans it produces.
+#pragma once
+#include "../../include/nbody3d_hip.h"
+
+#include <cstdint>
+#include <functional>
+#include <string>
+#include <vector>
+
+namespace nb {
+constexpr int kBlock = 256;  // threads per workgroup = reference TILE_SIZE (nbody3d.js:4,240)
+constexpr int kTile = 256;   // j-bodies per LDS tile unit (nbody3d.js:229); TL units are staged at once
+
+struct SymPlan {
+    uint32_t np, nsb;          // padded rows, super-blocks
+    uint32_t q;                // segments per super-block's chunk list (workgroups per super-block)
+    uint32_t total_hi, total_lo;   // chunks in the list of a super-block g < n_hi (it has the antipodal partner) / of the others
+    uint32_t n_hi, H;          // n_hi = nsb/2 when nsb is even, else 0; H = (nsb-1)/2
+    uint32_t r_layer0, t_layer0;
+};
+
+struct SymWPlan {
+    uint32_t np, nsb, W;
+    uint32_t total_hi, total_lo, n_hi, H;
+    uint32_t r_layer0, t_layer0;
+    uint32_t L;                 // chunk-sweeps of this handle: n_hi * total_hi + (nsb - n_hi) * total_lo for a whole system
+    uint32_t p0;                // where this handle's range starts in the global list (0 for a whole system; a RANK that owns
+                                // the resident super-blocks [g0, g1) works on the lists of those super-blocks only)
+};
+}  // namespace nb
+
+namespace nbp {
+
+enum Kind { kScalar = 1, kPkLds = 2, kPkSgpr = 3, kFused = 4, kDirect = 5, kJpk = 6, kSym = 7 };   // kDirect: fused, registers only (x = MAXJ/16)
+struct Shape { int kind, ipl, ls, x; };   // the force_variant digits K II LL X; x: tile units (LDS kinds), j-splitting waves (SGPR kind), form (kSym)
+
+inline uint32_t ceil_div(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+inline int sgpr_ws(int x) { return x == 5 ? 4 : x; }   // SGPR kind: x = 5 is WS = 4 with 64-bit pair loads
+inline int jpk_ws(int x) { return x == 6 ? 16 : x; }    // j-packed kind: x = 6 is 16 waves per workgroup
+
+// Is there a kernel instantiation for this shape?  (Mirrors kernel_of in nb_engine.hip, which holds the function pointers;
+// nb_create and nb_plan_query fail loudly if the two ever disagree.)
+bool shape_exists(bool f64, const Shape& sh);
+// i-bodies per workgroup (symmetric pass: rows per super-block)
+uint32_t ipb_of(const Shape& sh);
+
+struct PlanInput {
+    uint32_t n = 0, sb = 0, sc = 0;     // bodies; this handle's rows [sb, sb + sc)
+    bool f64 = false;
+    nb_config cfg{};                     // as normalised by the entry point (force_variant, jsplit, flags, shard_count, ext_bodies)
+    int n_cu = 256;
+    double clock_hz = 2.4e9;
+    // resident workgroups per CU of a shape's kernel at the given block size, 0 = unknown (no device): the model's defaults apply
+    std::function<int(const Shape&, int)> occupancy;
+};
+
+// What nb_create allocates and launches by.  Field names follow nb_sim (nb_internal.h), which copies them.
+struct LaunchPlan {
+    Shape sh{kPkLds, 2, 1, 1};
+    int ipl = 1, ls = 1, ws = 1, tl = 1;
+    bool packed = false, sgpr = false, fused = false, direct = false, jpk = false, swap_acc = false;
+    uint32_t jsplit = 1, j_per_split = 0, junits = 0, own_split0 = 0, own_splits = 0;
+    bool sym = false, symw = false, sym_rank = false;
+    uint32_t sym_np = 0, sym_layers = 0, sym_g0 = 0, sym_g1 = 0;
+    uint32_t sym_plan[11] = {0};         // nb::SymWPlan (symw) or nb::SymPlan, as plain words
+    std::vector<uint32_t> sym_tab_host;  // wave-granular form: {first wave, wave count} per super-block
+    std::string variant;
+};
+
+LaunchPlan plan_launch(const PlanInput& in);
+
+}  // namespace nbp

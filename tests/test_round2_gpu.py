@@ -352,7 +352,7 @@ def test_integrate_pass_measures_the_integrator_alone():
                                               (40002, "symw_ipl16_j1_w1024", "sgpr"), (65536, "symw_ipl16", "sgpr"), (131072, "symw_ipl16_j1_w2048", "sgpr"),
                                               (262144, "symw_ipl16_j1_w2048", "sgpr_ipl8_ws4"), (500010, "symw_ipl16", "sgpr"), (1048576, "symw_ipl16", "sgpr")])
 def test_default_launch_shape_family_by_size(n, family, classic):
-    """choose_shape's pick per system size, as measured best (profiles/r02/size_scan_final_4k_65k.txt below N ~ 14,000,
+    """the planner's (csrc/nb_plan.cpp) pick per system size, as measured best (profiles/r02/size_scan_final_4k_65k.txt below N ~ 14,000,
     profiles/r03/sym_variants_scan_wave_granular*.txt above): from there the symmetric pass; with NB_FLAG_NO_SYM the
     ordered-pair families of round 2.  (A refit of one model constant once moved N = 12,000 .. 32,768 onto a shape 1-6 %
     slower without any test noticing.)"""

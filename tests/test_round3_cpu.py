@@ -52,7 +52,7 @@ def _sym_plan(nsb, cps):
 
 @pytest.mark.parametrize("nsb,ranks,waves", [(2, 1, 4), (3, 1, 5), (8, 2, 7), (9, 3, 16), (16, 4, 12), (40, 8, 64), (41, 1, 100), (64, 8, 33)])
 def test_symmetric_pass_partition_covers_every_pair_of_super_blocks_exactly_once(nsb, ranks, waves):
-    """The index arithmetic of nb_force_symw / choose_shape (csrc/nb_kernels.hip.h, nb_engine.hip), restated: super-blocks on a
+    """The index arithmetic of nb_force_symw / plan_launch (csrc/nb_kernels.hip.h, nb_plan.cpp), restated (tests/test_planner_cpu.py walks the planner's own output): super-blocks on a
     ring; super-block g sweeps the chunks of the H = (nsb-1)/2 super-blocks after it (and of the antipodal one when nsb is even
     and g < nsb/2), then its own in resident-only mode.  Rank r owns the super-blocks [r*nsb/ranks, (r+1)*nsb/ranks) and its
     waves cut THEIR lists, laid end to end, into floor/ceil-equal ranges.  Every unordered pair of different super-blocks must be

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Calibration of choose_shape's cost model (csrc/nb_engine.hip) against scanned timings.
+"""Calibration of the planner's cost model (plan_launch, csrc/nb_plan.cpp) against scanned timings.
 
     python tools/fit_model.py picks  > gpurun_out/model_picks.json      (on the GPU box: hipOccupancy needs a device)
     python tools/fit_model.py regret gpurun_out/model_picks.json profiles/r02/shape_scan_dma_*.txt

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Wall time per step (simulate(k) + sync, graph replay included) of every plausible launch shape
-at a list of sizes: what choose_shape's model (csrc/nb_engine.hip) is fitted to and checked
+at a list of sizes: what the planner's cost model (csrc/nb_plan.cpp) is fitted to and checked
 against.  One process, interleaved repeats (cdna_hip_programming.md rule 24).
 
     python tools/shape_scan.py 1024 4096 16384 40002 65536 [--quick]
