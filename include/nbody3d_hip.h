@@ -133,7 +133,11 @@ typedef struct nb_config {
                                See nb_variant_name().                              */
     uint32_t jsplit;        /* number of j-partitions (grid.y)                  */
     uint32_t flags;         /* NB_FLAG_*                                        */
-    uint32_t reserved[5];
+    uint32_t layer_budget_mib; /* most device memory (MiB) the symmetric pass may take for its partial-sum layers
+                               (~ 6 N^2 / S bytes, S = 512 or 1,024 rows: 6.4 GB at N = 1,048,576); a system whose
+                               layers would not fit runs the ordered-pair kernels instead.  0 -> a third of the
+                               device's memory, at most 96 GiB (N up to ~4 M on an MI355X)                          */
+    uint32_t reserved[4];
 } nb_config;
 
 /* Library / ABI version; callable with no device. */

@@ -153,9 +153,10 @@ const void* kernel_of(bool f64, const Shape& sh)
 }
 
 // Runs the planner (nb_plan.cpp) for a handle and copies its answer into the handle's launch fields.
-void plan_handle(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz)
+void plan_handle(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz, double device_mem)
 {
     PlanInput in;
+    if (device_mem > 0) in.device_mem = device_mem;
     in.n = s->n; in.sb = s->sb; in.sc = s->sc; in.f64 = s->f64; in.cfg = cfg; in.n_cu = n_cu; in.clock_hz = clock_hz;
     if (!s->no_device)
         in.occupancy = [f64 = s->f64](const Shape& sh, int block) {
@@ -592,7 +593,7 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     else { NB_HIPC(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
 
     plan_handle(s, cfg, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256,
-                 prop.clockRate > 0 ? 1e3 * prop.clockRate : 2.4e9);     // clockRate is in kHz
+                 prop.clockRate > 0 ? 1e3 * prop.clockRate : 2.4e9, (double)prop.totalGlobalMem);     // clockRate is in kHz
     if (!kernel_of(s->f64, shape_of(s))) return bail(NB_ERR_INVALID, "nb_create: no kernel for shape " + s->variant);
 
     const size_t row = 4 * s->esz;
@@ -950,6 +951,7 @@ int nb_plan_query(const nb_config* cfg_in, int n_cu, double clock_hz, nb_plan_in
     double eps2;
     if (const int rc = read_config(cfg_in, "nb_plan_query", &cfg, &sb, &sc, &eps2)) return rc;
     int count = 0;
+    double device_mem = 0.0;                      // 0: the planner's default (an MI355X's 288 GB)
     if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 0; }
     if (n_cu <= 0 || !(clock_hz > 0)) {           // "as on the current device"
         if (count <= 0) return fail(nullptr, NB_ERR_NO_DEVICE, "nb_plan_query: n_cu / clock_hz not given and there is no HIP device to read them from");
@@ -960,11 +962,12 @@ int nb_plan_query(const nb_config* cfg_in, int n_cu, double clock_hz, nb_plan_in
             return fail(nullptr, NB_ERR_HIP, "nb_plan_query: cannot read the device properties");
         if (n_cu <= 0) n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         if (!(clock_hz > 0)) clock_hz = prop.clockRate > 0 ? 1e3 * prop.clockRate : 2.4e9;
+        device_mem = (double)prop.totalGlobalMem;
     }
     nb_sim tmp;                                    // host fields only: nothing of it is ever allocated on a device
     tmp.n = cfg.n; tmp.sb = sb; tmp.sc = sc; tmp.f64 = cfg.precision == NB_F64; tmp.esz = tmp.f64 ? 8 : 4; tmp.eps2 = eps2;
     tmp.no_device = count <= 0;
-    plan_handle(&tmp, cfg, n_cu, clock_hz);
+    plan_handle(&tmp, cfg, n_cu, clock_hz, device_mem);
     const Shape sh = shape_of(&tmp);
     if (!kernel_of(tmp.f64, sh)) return fail(nullptr, NB_ERR_INVALID, "nb_plan_query: no kernel for shape " + tmp.variant);
     const uint32_t size = out->struct_size;

@@ -148,15 +148,22 @@ inline ModelKnobs model_knobs() { return ModelKnobs(); }       // release build:
 struct SymChoice { int ipl; uint32_t k; double t; };
 
 // Bytes of partial-sum layers a symmetric handle allocates: one traveler layer per ring distance, i.e. ~ 3 * esz * N^2 / (2 S)
-// (N = 1,048,576 with 1,024-row super-blocks: 6.4 GB; it grows with N^2, so very large systems fall back to the ordered-pair kernels).
+// (N = 1,048,576 with 1,024-row super-blocks: 6.4 GB, N = 4 M: 103 GB; it grows with N^2, so very large systems fall back to the
+// ordered-pair kernels).
 double sym_layer_bytes(uint32_t n, uint32_t S, size_t esz)
 {
     const double nsb = std::ceil((double)n / S);
     return (nsb / 2.0 + 8.0) * nsb * S * 3.0 * (double)esz;
 }
-constexpr double kSymLayerBudget = 16.0e9;
+// The budget: nb_config::layer_budget_mib, or a third of the device's memory and at most 96 GiB (K2 reads every layer once per
+// step: 100 GB at N = 4 M is 20 ms against 2.4 s of pair work).
+double sym_layer_budget(const nb_config& cfg, double device_mem)
+{
+    if (cfg.layer_budget_mib) return 1048576.0 * cfg.layer_budget_mib;
+    return std::min(device_mem / 3.0, 96.0 * 1073741824.0);
+}
 
-SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64)
+SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64, double layer_budget)
 {
     SymChoice best{0, 0, 1e300};
     for (int ipl : {4, 8, 16}) {
@@ -164,7 +171,7 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         const uint32_t NG = (uint32_t)ipl / 2, S = 64u * (uint32_t)ipl, cps = S / 64u;
         const uint32_t nsb = ceil_div(n, S);
         if (nsb < 4) continue;
-        if (sym_layer_bytes(n, S, f64 ? 8 : 4) > kSymLayerBudget) continue;
+        if (sym_layer_bytes(n, S, f64 ? 8 : 4) > layer_budget) continue;
         const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
         const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (uint64_t)(H + 1) * cps;
         const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo;
@@ -277,6 +284,7 @@ LaunchPlan plan_launch(const PlanInput& in)
     const bool f64 = in.f64;
     const size_t esz = f64 ? 8 : 4;
     const uint32_t sc = in.sc, n = in.n, sb = in.sb;
+    const double layer_budget = sym_layer_budget(cfg, in.device_mem);
     const uint32_t kMaxSplit = 128, kMinSplitLen = 128;
     const ModelKnobs mk = model_knobs();
     const double kTileLatency = mk.tile_latency, kPrologue = mk.prologue, kClock = clock_hz * mk.sustained;
@@ -326,7 +334,7 @@ LaunchPlan plan_launch(const PlanInput& in)
     if ((cfg.flags & NB_FLAG_SYM_SHARD) && !(cfg.flags & NB_FLAG_NO_SYM) && !cfg.ext_bodies && cfg.shard_count != 0)
         for (uint32_t S : {1024u, 512u})
             if (!rank_ipl && !(f64 && S != 512u) && sb % S == 0 && sc % S == 0 && n % S == 0 && n / S >= 2 &&        // f64: 8 residents per lane only
-                sym_layer_bytes(n, S, esz) <= kSymLayerBudget) rank_ipl = (int)(S / 64u);
+                sym_layer_bytes(n, S, esz) <= layer_budget) rank_ipl = (int)(S / 64u);
     const uint32_t variant = rank_ipl ? 0u : cfg.force_variant;
     bool pinned = false;
     if (rank_ipl) { sh = {kSym, rank_ipl, 1, 3}; pinned = true; if (js == 0) js = 0xffffffffu; }     // js: placeholder, set with the plan below
@@ -338,7 +346,7 @@ LaunchPlan plan_launch(const PlanInput& in)
             if (want.kind == kDirect && n > 1024u * (uint32_t)want.x) want = {kFused, 2, 64, 4};
             if (want.kind == kJpk && !may_fuse) want = {kPkSgpr, 4, 1, 4};      // whole-system f32 handles only
             if (want.kind == kSym && (!whole || cfg.ext_bodies || !shape_exists(f64, want) || n <= ipb_of(want) ||       // likewise; >= 2 super-blocks,
-                                      sym_layer_bytes(n, ipb_of(want), esz) > 4.0 * kSymLayerBudget))                  // and layers that fit (pinned: 64 GB)
+                                      sym_layer_bytes(n, ipb_of(want), esz) > std::max(layer_budget, 0.6 * in.device_mem)))    // and layers that fit (pinned: up to 60 % of the memory)
                 want = f64 ? Shape{kScalar, 4, 1, 1} : Shape{kPkSgpr, 8, 1, 4};
             if (shape_exists(f64, want)) { sh = want; pinned = true; }
         }
@@ -460,7 +468,7 @@ LaunchPlan plan_launch(const PlanInput& in)
         // the symmetric pass (whole-system f32 handles; every unordered pair once): from N ~ 14,000 up it beats every
         // ordered-pair shape above (N = 16,384: 61.7 vs 65.7 us, 40,002: 270 vs 357 us, 262,144: 10.5 vs 14.6 ms)
         if (!pinned && whole && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
-            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, f64);
+            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, f64, layer_budget);
             if (sc2.ipl && sc2.t < 0.98 * (pick ? pick->t : best_t)) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; }     // a clear win only: both estimates are good to ~3 %
         }
     }

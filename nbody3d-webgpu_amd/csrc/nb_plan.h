@@ -57,6 +57,7 @@ struct PlanInput {
     nb_config cfg{};                     // as normalised by the entry point (force_variant, jsplit, flags, shard_count, ext_bodies)
     int n_cu = 256;
     double clock_hz = 2.4e9;
+    double device_mem = 288.0e9;         // bytes of device memory (what cfg.layer_budget_mib == 0 takes a third of); MI355X when unknown
     // resident workgroups per CU of a shape's kernel at the given block size, 0 = unknown (no device): the model's defaults apply
     std::function<int(const Shape&, int)> occupancy;
 };

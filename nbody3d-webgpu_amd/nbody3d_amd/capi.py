@@ -46,7 +46,8 @@ class nb_config(C.Structure):
         ("struct_size", C.c_uint32), ("n", C.c_uint32), ("precision", C.c_uint32), ("tile", C.c_uint32),
         ("eps2", C.c_double), ("device", C.c_int32), ("shard_begin", C.c_uint32), ("shard_count", C.c_uint32),
         ("ext_stream", C.c_void_p), ("ext_bodies", C.c_void_p),
-        ("force_variant", C.c_uint32), ("jsplit", C.c_uint32), ("flags", C.c_uint32), ("reserved", C.c_uint32 * 5),
+        ("force_variant", C.c_uint32), ("jsplit", C.c_uint32), ("flags", C.c_uint32), ("layer_budget_mib", C.c_uint32),
+        ("reserved", C.c_uint32 * 4),
     ]
 
 
@@ -165,7 +166,8 @@ SYMW_PLAN_WORDS = ("np", "nsb", "W", "total_hi", "total_lo", "n_hi", "H", "r_lay
 SYM_PLAN_WORDS = ("np", "nsb", "q", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "t_layer0")
 
 
-def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=0, n_cu=256, clock_hz=2.4e9, device=-1):
+def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=0, n_cu=256, clock_hz=2.4e9, device=-1,
+               layer_budget_mib=0):
     """nb_plan_query: the launch plan nb_create would build -- the engine's planner run on the host alone (works without a
     GPU when n_cu and clock_hz are given; 0 means "as on the device").  Returns a dict: the shape digits, the j-partitions,
     and for the symmetric pass `plan` (the words the kernels receive, by name) and `tab` (first wave, wave count per super-block)."""
@@ -178,6 +180,7 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
     if shard is not None:
         cfg.shard_begin, cfg.shard_count = int(shard[0]), int(shard[1])
     cfg.force_variant, cfg.jsplit, cfg.flags = int(force_variant), int(jsplit), int(flags)
+    cfg.layer_budget_mib = int(layer_budget_mib)
     info = nb_plan_info()
     info.struct_size = C.sizeof(nb_plan_info)
     rc = L.nb_plan_query(C.byref(cfg), int(n_cu), float(clock_hz), C.byref(info), None, 0)
@@ -201,7 +204,7 @@ class Simulation:
     uniforms, compute pipeline) bundle, nbody3d.js:13,179-204,296-311."""
 
     def __init__(self, n, precision="f32", eps2=None, device=-1, shard=None, stream=None, ext_bodies=None,
-                 force_variant=0, jsplit=0, tile=0, flags=0):
+                 force_variant=0, jsplit=0, tile=0, flags=0, layer_budget_mib=0):
         L = load_library()
         self._L = L
         self.n = int(n)
@@ -224,6 +227,7 @@ class Simulation:
         cfg.force_variant = force_variant
         cfg.jsplit = jsplit
         cfg.flags |= int(flags)
+        cfg.layer_budget_mib = int(layer_budget_mib)
         h = C.c_void_p()
         rc = L.nb_create(C.byref(cfg), C.byref(h))
         if rc != 0:

@@ -214,7 +214,9 @@ def test_model_choice_table():
     for n, prefix in want.items():
         assert capi.plan_query(n)["variant"].startswith(prefix), (n, capi.plan_query(n)["variant"])
     assert capi.plan_query(262144, precision="f64")["variant"].startswith("f64_symw_ipl8_j1_w2048")
-    assert capi.plan_query(2500000)["sym"] == 0            # the layers would not fit the budget: ordered pairs
+    # the layers grow with N^2: past the budget (a third of the device memory, at most 96 GiB; nb_config.layer_budget_mib) ordered pairs
+    assert capi.plan_query(2500000)["sym"] == 1 and capi.plan_query(2500000, layer_budget_mib=16384)["sym"] == 0
+    assert capi.plan_query(4500000)["sym"] == 0 and capi.plan_query(1048576, precision="f64")["sym"] == 1
 
 
 def test_bad_arguments_are_errors():

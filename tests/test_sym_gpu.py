@@ -165,8 +165,29 @@ def test_handles_that_cannot_use_the_symmetric_pass_fall_back():
         assert "sgpr" in s.variant, s.variant
     with Simulation(n) as s:
         assert "symw" in s.variant, s.variant
-    with Simulation(2500000) as s:       # the traveler layers grow with N^2 (here 37 GB): past the 16 GB budget the ordered-pair kernel runs
+    with Simulation(2500000, layer_budget_mib=16384) as s:       # the traveler layers grow with N^2 (here 37 GB): past the budget the ordered-pair kernel runs
         assert "sgpr" in s.variant, s.variant
+
+
+def test_two_million_bodies_take_the_symmetric_pass():
+    """Layers beyond the old fixed 16 GB budget (N = 2,000,000: 23.6 GB of partial sums; the default budget is a third of the
+    device memory): one step, sampled rows against an fp64 direct sum, momentum of the pair sums."""
+    n = 2000000
+    b, v = ic.plummer(n, seed=7)
+    with Simulation(n) as s:
+        assert "symw_ipl16" in s.variant, s.variant
+        s.init(b, v)
+        s.simulate(1, 1e-3, 1.0)
+        acc = s.read(bodies=False, vel=False)[2]
+    x = b[:, :3].astype(np.float64)
+    m = b[:, 3].astype(np.float64)
+    for i in (0, 1, 999999, 1234567, n - 1):
+        d = x - x[i]
+        r2 = (d * d).sum(1) + 1e-4
+        want = (m[:, None] * d / (r2 * np.sqrt(r2))[:, None]).sum(0)
+        assert np.abs(acc[i, :3] - want).max() <= 2e-5 * np.abs(want).max(), i
+    f = m[:, None] * acc[:, :3].astype(np.float64)
+    assert np.all(np.abs(f.sum(0)) < 1e-6 * np.abs(f).sum(0))
 
 
 # ---- fp64 (BASELINE config 5) ---------------------------------------------------------------------
