@@ -194,6 +194,7 @@ static napi_value js_create(napi_env env, napi_callback_info info)
     if (get_u32_prop(env, argv[0], "jsplit", &u)) cfg.jsplit = u;
     if (get_u32_prop(env, argv[0], "tile", &u)) cfg.tile = u;
     if (get_u32_prop(env, argv[0], "flags", &u)) cfg.flags = u;
+    if (get_u32_prop(env, argv[0], "layerBudgetMiB", &u)) cfg.layer_budget_mib = u;
     uint32_t shards = 0, collective = 0;
     get_u32_prop(env, argv[0], "shards", &shards);
     get_u32_prop(env, argv[0], "collective", &collective);   /* 0 peer copies, 1 RCCL (nb_multi_collective) */

@@ -60,7 +60,8 @@ function asParticles(particles) {
 }
 
 class Simulation {
-  /** options: {G, dt, f64, eps2, device, shards, collective, shardBegin, shardCount, variant, jsplit, flags}
+  /** options: {G, dt, f64, eps2, device, shards, collective, shardBegin, shardCount, variant, jsplit, flags, layerBudgetMiB}
+   *  layerBudgetMiB: nb_config.layer_budget_mib (device memory the symmetric pass may take for its partial sums; 0 = default).
    *  shards > 1: single-process multi-device (i-shards round-robin over the visible GPUs; all-gather
    *  of positions after every step through collective: 'peer' -- event-ordered device-to-device
    *  copies, the default -- or 'rccl' -- ncclCommInitAll + grouped in-place ncclAllGather;
@@ -102,7 +103,7 @@ class Simulation {
         n: n, f64: this.f64 ? 1 : 0, eps2: o.eps2 !== undefined ? o.eps2 : EPS2,
         device: o.device !== undefined ? o.device : -1, shardBegin: o.shardBegin || 0, shardCount: o.shardCount || 0,
         variant: o.variant || 0, jsplit: o.jsplit || 0, tile: o.tile || 0, shards: o.shards || 0,
-        flags: o.flags || 0, collective: o.collective === 'rccl' ? 1 : 0,
+        flags: o.flags || 0, layerBudgetMiB: o.layerBudgetMiB || 0, collective: o.collective === 'rccl' ? 1 : 0,
       });
       this._frame = null;
     }
