@@ -1,0 +1,579 @@
+// kernels/symmetric.hip.h -- the symmetric force pass (each unordered pair once): nb_force_sym / nb_force_symw / nb_force_symw64, the rank form's reduction kernels, nb_integrate_sym*.
+// Part of nb_kernels.hip.h (include that, not this file).
+#pragma once
+
+namespace nb {
+
+// ---- symmetric force pass (Newton's third law inside a wave) -----------------------------------
+// Every kernel above evaluates each ORDERED pair on its own: 12 v_pk + 2 v_rsq_f32 per two pairs, the instruction-mix
+// ceiling of 62.5 % of the fp32 vector rate.  r = x_j - x_i, r^2, the cube and the reciprocal square root are the same
+// numbers for (i, j) and (j, i) (IEEE subtraction is exactly antisymmetric), so this pass computes them ONCE per
+// unordered pair and accumulates both accelerations -- the per-pair products (G m_j) inv r and (G m_i) inv (-r) are
+// bit for bit the reference's (nbody3d.js:233-236); only the order of the additions differs:
+//   * a lane keeps 8 RESIDENT bodies (4 packed groups, as nb_force_pk_sgpr<4,..>); J = 2 TRAVELING bodies per lane --
+//     a chunk of 128 bodies per wave -- rotate through the 64 lanes with v_mov_b32_dpp wave_ror:1 (full rate on gfx950:
+//     tools/experiments/ubench6.hip), their six packed sums traveling with them; after 64 steps every resident of the
+//     wave has met every traveler of the chunk and the travelers are back in their home lanes;
+//   * per (traveler, packed group): 3 v_pk_add, 3 v_pk_fma, 2 v_pk_mul, 2 v_rsq_f32, v_pk_mul + 3 v_pk_fma for the
+//     resident side, v_pk_mul + 3 v_pk_fma (negated) for the traveler side = 16 packed + 2 transcendental per FOUR
+//     interactions, + 10 v_mov_b32_dpp per traveler and step: 90 issue slots per 16 interactions against 128 --
+//     measured 74.7 % of the fp32 roofline for the bare loop (profiles/r03/ubench6_*.txt) against 60 %;
+//   * coverage: the bodies form nsb SUPER-BLOCKS of S = 512*WS rows (one 512-row block per wave of a workgroup).
+//     Workgroup (g, q) keeps super-block g resident and sweeps segment q (of Q nearly equal ones) of g's chunk list: the chunks of the H =
+//     (nsb-1)/2 super-blocks that follow g on the ring (plus the antipodal one for g < nsb/2 when nsb is even) --
+//     every unordered pair of different super-blocks exactly once -- and then the chunks of super-block g ITSELF in
+//     resident-only mode (traveler sums discarded: every ordered pair inside g once; the self term is exactly 0);
+//   * sums: a wave's resident sums go to layer (r_layer0 + q); the traveler sums of a chunk are added over the WS waves
+//     in wave order through LDS (one barrier per chunk, double buffered) and go to layer (t_layer0 + ring distance - 1).
+//     nb_integrate_sym adds a body's layers in ascending order: deterministic, no float atomics.  A partial row is
+//     12 bytes (x, y, z: one global_store_dwordx3 per lane): the layers are the pass's memory traffic.
+// Rows [n, np) of `bodies` are zero-mass bodies at the origin (np = nsb * S).
+template <typename T> struct SymRowT { T x, y, z; };   // a partial row: 12 bytes in f32 (an ext_vector_type(3) would be padded to 16), 24 in f64
+using SymRow = SymRowT<float>;
+// struct SymPlan: nb_plan.h (the host's planner fills it)
+
+__device__ __forceinline__ float wave_rot1(float v)
+{
+    const int iv = __builtin_bit_cast(int, v);      // old = src: every lane is written, no init move
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(iv, iv, 0x13C /* wave_ror:1 */, 0xF, 0xF, false));
+}
+
+// NG packed groups = 2*NG residents per lane (NG = 4: 128 VGPRs, 4 waves per SIMD; NG = 8: the rotation is amortised over
+// twice the pairs -- one wave per SIMD already issues this loop at ~90 % of its rate, so 2 waves per SIMD are enough);
+// WS waves per workgroup, each with its own 128*NG resident rows; J travelers per lane.
+template <int WS, int NG, int J>
+__global__ __launch_bounds__(64 * WS) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : 4)))
+void nb_force_sym(const float4* __restrict__ bodies, SymRow* __restrict__ partial, const SymPlan pl, const uint32_t n, const float eps2)
+{
+    constexpr uint32_t RB = 128u * NG;         // resident rows per wave
+    constexpr uint32_t S = RB * WS;            // rows per super-block
+    constexpr uint32_t CH = 64u * J;           // travelers per chunk
+    constexpr uint32_t CPS = S / CH;           // chunks per super-block
+    __shared__ float red[WS > 1 ? 2 : 1][WS > 1 ? WS : 1][3 * J][64];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    const uint32_t g = blockIdx.x / pl.q, q = blockIdx.x % pl.q;
+    const uint32_t ring = (pl.H + (g < pl.n_hi ? 1u : 0u)) * CPS;     // symmetric chunks of g; CPS resident-only chunks follow
+    const uint32_t total = ring + CPS;
+    // segment q of Q: chunk ranges of (nearly) equal length, [q * total / Q, (q + 1) * total / Q)
+    const uint32_t c0 = (uint32_t)(((uint64_t)q * total) / pl.q), c1 = (uint32_t)(((uint64_t)(q + 1) * total) / pl.q);
+
+    nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
+    {
+        const float4* rb = bodies + (size_t)g * S + w * RB + lane;
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+            const float4 b0 = ld4(rb + (2 * c) * 64), b1 = ld4(rb + (2 * c + 1) * 64);
+            xi[c] = nb_f2{b0.x, b1.x}; yi[c] = nb_f2{b0.y, b1.y}; zi[c] = nb_f2{b0.z, b1.z}; mi[c] = nb_f2{b0.w, b1.w};
+            ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
+        }
+    }
+    const nb_f2 e2 = nb_f2{eps2, eps2};
+
+    uint32_t done = 0;                                               // symmetric chunks processed: alternates the LDS buffer
+    for (uint32_t k = c0; k < c1; ++k) {
+        const bool sym = k < ring;                                   // wave-uniform
+        const uint32_t d = k / CPS;                                  // ring distance - 1 (symmetric chunks)
+        uint32_t tb = g + 1 + d;
+        if (tb >= pl.nsb) tb -= pl.nsb;
+        const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
+        if (tstart >= n) continue;       // a chunk of padding rows only (zero mass): exerts nothing, and nobody reads its sums
+        float tx[J], ty[J], tz[J], tm[J];
+        nb_f2 bx[J], by[J], bz[J];
+#pragma unroll
+        for (int u = 0; u < J; ++u) {
+            const float4 t = ld4(bodies + tstart + u * 64 + lane);
+            tx[u] = t.x; ty[u] = t.y; tz[u] = t.z; tm[u] = t.w;
+            bx[u] = nb_f2{0, 0}; by[u] = nb_f2{0, 0}; bz[u] = nb_f2{0, 0};
+        }
+        for (int st = 0; st < 64; ++st) {
+#pragma unroll
+            for (int u = 0; u < J; ++u) {
+                const nb_f2 px = nb_f2{tx[u], tx[u]}, py = nb_f2{ty[u], ty[u]}, pz = nb_f2{tz[u], tz[u]}, pm = nb_f2{tm[u], tm[u]};
+                // stage-major over groups of four (as every packed kernel here); NG = 8 runs two such groups
+#pragma unroll
+                for (int c0g = 0; c0g < NG; c0g += 4) {
+                    nb_f2 dx[4], dy[4], dz[4], d2[4], r[4], si[4], sj[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dx[c] = px - xi[c0g + c];                                   // :233
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dy[c] = py - yi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) dz[c] = pz - zi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[c] = d2[c] * d2[c];                                       // :235
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) sj[c] = mi[c0g + c] * r[c];       // (G m_i) inv: traveler side
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bx[u] = __builtin_elementwise_fma(-sj[c], dx[c], bx[u]);   // x_i - x_t = -(x_t - x_i), exactly
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) by[u] = __builtin_elementwise_fma(-sj[c], dy[c], by[u]);
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) bz[u] = __builtin_elementwise_fma(-sj[c], dz[c], bz[u]);
+                }
+            }
+            // the travelers and their sums move on by one lane
+#pragma unroll
+            for (int u = 0; u < J; ++u) {
+                tx[u] = wave_rot1(tx[u]); ty[u] = wave_rot1(ty[u]); tz[u] = wave_rot1(tz[u]); tm[u] = wave_rot1(tm[u]);
+                bx[u] = nb_f2{wave_rot1(bx[u].x), wave_rot1(bx[u].y)};
+                by[u] = nb_f2{wave_rot1(by[u].x), wave_rot1(by[u].y)};
+                bz[u] = nb_f2{wave_rot1(bz[u].x), wave_rot1(bz[u].y)};
+            }
+        }
+        if (sym) {
+            SymRow* out = partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart + lane;
+            if constexpr (WS == 1) {
+#pragma unroll
+                for (int u = 0; u < J; ++u) out[u * 64] = SymRow{bx[u].x + bx[u].y, by[u].x + by[u].y, bz[u].x + bz[u].y};
+            } else {
+                // traveler sums of the chunk: added over the workgroup's waves in wave order, stored by one of them.
+                // One barrier per chunk: the buffers alternate, and the wave that reads buffer b passes the NEXT
+                // barrier only after its reads, which is before anybody writes b again.
+                const int buf = done++ & 1;
+#pragma unroll
+                for (int u = 0; u < J; ++u) {
+                    red[buf][w][3 * u + 0][lane] = bx[u].x + bx[u].y;
+                    red[buf][w][3 * u + 1][lane] = by[u].x + by[u].y;
+                    red[buf][w][3 * u + 2][lane] = bz[u].x + bz[u].y;
+                }
+                __syncthreads();
+                if (w == done % WS) {
+#pragma unroll
+                    for (int u = 0; u < J; ++u) {
+                        float sx = red[buf][0][3 * u + 0][lane], sy = red[buf][0][3 * u + 1][lane], sz = red[buf][0][3 * u + 2][lane];
+#pragma unroll
+                        for (int ww = 1; ww < WS; ++ww) { sx += red[buf][ww][3 * u + 0][lane]; sy += red[buf][ww][3 * u + 1][lane]; sz += red[buf][ww][3 * u + 2][lane]; }
+                        out[u * 64] = SymRow{sx, sy, sz};
+                    }
+                }
+            }
+        }
+    }
+    // resident sums of this segment
+    SymRow* out = partial + (size_t)(pl.r_layer0 + q) * pl.np + (size_t)g * S + w * RB + lane;
+#pragma unroll
+    for (int c = 0; c < NG; ++c) {
+        out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
+        out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
+    }
+}
+
+// The same pass with the WAVE as the unit of work (no LDS, no barrier): a super-block is one wave's 128*NG residents, and
+// the chunk lists of all super-blocks, laid end to end (L chunk-sweeps), are cut into W contiguous ranges of floor/ceil(L/W)
+// sweeps -- one per wave, W a multiple of the chip's SIMD count -- so every SIMD gets the same work to within ONE sweep at
+// any N (the workgroup form above needs nsb * Q to land on a multiple of the CU count).  A wave whose range crosses into the
+// next super-block stores its resident sums, reloads its residents and goes on; its resident sums of super-block g go to
+// layer r_layer0 + (w - first wave of g) (table `gtab`: first wave and wave count per super-block, built by the host).
+// struct SymWPlan: nb_plan.h
+
+template <int NG, int J>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : (NG < 4 ? 8 : 4))))
+void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ partial, const uint32_t* __restrict__ gtab, const SymWPlan pl,
+                   const uint32_t n, const float eps2)
+{
+    constexpr uint32_t S = 128u * NG;          // rows per super-block = one wave's residents
+    constexpr int GW = NG < 4 ? NG : 4;        // packed groups evaluated stage-major together
+    constexpr uint32_t CH = 64u * J;           // travelers per chunk
+    constexpr uint32_t CPS = S / CH;           // chunks per super-block
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));     // the four waves of a workgroup are independent
+    if (w >= pl.W) return;
+    uint32_t p = pl.p0 + (uint32_t)(((uint64_t)w * pl.L) / pl.W);
+    const uint32_t pend = pl.p0 + (uint32_t)(((uint64_t)(w + 1) * pl.L) / pl.W);
+    const nb_f2 e2 = nb_f2{eps2, eps2};
+    const uint32_t first_lo = pl.n_hi * pl.total_hi;
+
+    while (p < pend) {
+        // which super-block's list p lies in, and where
+        uint32_t g, k, total;
+        if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
+        else { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
+        const uint32_t ring = total - CPS;                           // symmetric chunks of g; CPS resident-only chunks follow
+        uint32_t kend = k + (pend - p);
+        if (kend > total) kend = total;
+        p += kend - k;
+
+        nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
+        {
+            const float4* rb = bodies + (size_t)g * S + lane;
+#pragma unroll
+            for (int c = 0; c < NG; ++c) {
+                const float4 b0 = ld4(rb + (2 * c) * 64), b1 = ld4(rb + (2 * c + 1) * 64);
+                xi[c] = nb_f2{b0.x, b1.x}; yi[c] = nb_f2{b0.y, b1.y}; zi[c] = nb_f2{b0.z, b1.z}; mi[c] = nb_f2{b0.w, b1.w};
+                ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
+            }
+        }
+        for (; k < kend; ++k) {
+            const bool sym = k < ring;
+            const uint32_t d = k / CPS;                              // ring distance - 1 (symmetric chunks)
+            uint32_t tb = g + 1 + d;
+            if (tb >= pl.nsb) tb -= pl.nsb;
+            const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
+            if (tstart >= n) continue;   // a chunk of padding rows only (zero mass): exerts nothing, and nobody reads its sums
+            float tx[J], ty[J], tz[J], tm[J];
+            nb_f2 bx[J], by[J], bz[J];
+#pragma unroll
+            for (int u = 0; u < J; ++u) {
+                const float4 t = ld4(bodies + tstart + u * 64 + lane);
+                tx[u] = t.x; ty[u] = t.y; tz[u] = t.z; tm[u] = t.w;
+                bx[u] = nb_f2{0, 0}; by[u] = nb_f2{0, 0}; bz[u] = nb_f2{0, 0};
+            }
+            for (int st = 0; st < 64; ++st) {
+#pragma unroll
+                for (int u = 0; u < J; ++u) {
+                    const nb_f2 px = nb_f2{tx[u], tx[u]}, py = nb_f2{ty[u], ty[u]}, pz = nb_f2{tz[u], tz[u]}, pm = nb_f2{tm[u], tm[u]};
+#pragma unroll
+                    for (int c0g = 0; c0g < NG; c0g += GW) {         // stage-major over groups of (up to) four
+                        nb_f2 dx[GW], dy[GW], dz[GW], d2[GW], r[GW], si[GW], sj[GW];
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) dx[c] = px - xi[c0g + c];                                   // :233
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) dy[c] = py - yi[c0g + c];
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) dz[c] = pz - zi[c0g + c];
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) r[c] = d2[c] * d2[c];                                       // :235
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) sj[c] = mi[c0g + c] * r[c];       // (G m_i) inv: traveler side
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) bx[u] = __builtin_elementwise_fma(-sj[c], dx[c], bx[u]);   // x_i - x_t = -(x_t - x_i), exactly
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) by[u] = __builtin_elementwise_fma(-sj[c], dy[c], by[u]);
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) bz[u] = __builtin_elementwise_fma(-sj[c], dz[c], bz[u]);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < J; ++u) {                        // the travelers and their sums move on by one lane
+                    tx[u] = wave_rot1(tx[u]); ty[u] = wave_rot1(ty[u]); tz[u] = wave_rot1(tz[u]); tm[u] = wave_rot1(tm[u]);
+                    bx[u] = nb_f2{wave_rot1(bx[u].x), wave_rot1(bx[u].y)};
+                    by[u] = nb_f2{wave_rot1(by[u].x), wave_rot1(by[u].y)};
+                    bz[u] = nb_f2{wave_rot1(bz[u].x), wave_rot1(bz[u].y)};
+                }
+            }
+            if (sym) {
+                SymRow* out = partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart + lane;
+#pragma unroll
+                for (int u = 0; u < J; ++u) out[u * 64] = SymRow{bx[u].x + bx[u].y, by[u].x + by[u].y, bz[u].x + bz[u].y};
+            }
+        }
+        // resident sums of this wave's part of g's list
+        SymRow* out = partial + (size_t)(pl.r_layer0 + (w - gtab[2 * g])) * pl.np + (size_t)g * S + lane;
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+            out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
+            out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
+        }
+    }
+}
+
+// The fp64 form (BASELINE config 5): non-packed, IPL residents per lane, one traveler per lane.  Per unordered pair: 3 adds,
+// 3 fma (r^2 + eps2), v_rsq_f64 + first-order correction as in pair(double...) -- y = rsq(d2), e = 1 - d2 y^2,
+// u = y^3 (1 + 3e/2) -- then (G m_t) u and (G m_i) u and six fma: 19 DP instructions + the seed for TWO interactions where
+// nb_force<double,...> spends 15 + the seed on one; 14 v_mov_b32_dpp per traveler and step rotate the seven doubles.
+__device__ __forceinline__ double wave_rot1(double v)
+{
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = (int)(b & 0xffffffffll), hi = (int)(b >> 32);
+    const unsigned rlo = (unsigned)__builtin_amdgcn_update_dpp(lo, lo, 0x13C, 0xF, 0xF, false);
+    const unsigned rhi = (unsigned)__builtin_amdgcn_update_dpp(hi, hi, 0x13C, 0xF, 0xF, false);
+    return __builtin_bit_cast(double, (long long)(((unsigned long long)rhi << 32) | rlo));
+}
+
+template <int IPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __restrict__ partial, const uint32_t* __restrict__ gtab,
+                     const SymWPlan pl, const uint32_t n, const double G, const double eps2)
+{
+    constexpr uint32_t S = 64u * IPL, CH = 64u, CPS = S / CH;
+    constexpr int GW = 4;                      // residents evaluated stage-major together
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (w >= pl.W) return;
+    uint32_t p = pl.p0 + (uint32_t)(((uint64_t)w * pl.L) / pl.W);
+    const uint32_t pend = pl.p0 + (uint32_t)(((uint64_t)(w + 1) * pl.L) / pl.W);
+    const uint32_t first_lo = pl.n_hi * pl.total_hi;
+    while (p < pend) {
+        uint32_t g, k, total;
+        if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
+        else { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
+        const uint32_t ring = total - CPS;
+        uint32_t kend = k + (pend - p);
+        if (kend > total) kend = total;
+        p += kend - k;
+        double xi[IPL], yi[IPL], zi[IPL], mi[IPL], ax[IPL], ay[IPL], az[IPL];
+#pragma unroll
+        for (int c = 0; c < IPL; ++c) {
+            const double4 b = ld4(bodies + (size_t)g * S + c * 64 + lane);
+            xi[c] = b.x; yi[c] = b.y; zi[c] = b.z; mi[c] = b.w * G;
+            ax[c] = 0; ay[c] = 0; az[c] = 0;
+        }
+        for (; k < kend; ++k) {
+            const bool sym = k < ring;
+            const uint32_t d = k / CPS;
+            uint32_t tb = g + 1 + d;
+            if (tb >= pl.nsb) tb -= pl.nsb;
+            const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
+            if (tstart >= n) continue;
+            const double4 t = ld4(bodies + tstart + lane);
+            double tx = t.x, ty = t.y, tz = t.z, tm = t.w * G, bx = 0, by = 0, bz = 0;
+            for (int st = 0; st < 64; ++st) {
+#pragma unroll
+                for (int c0g = 0; c0g < IPL; c0g += GW) {            // stage-major over four residents
+                    double dx[GW], dy[GW], dz[GW], d2[GW], y[GW], u[GW];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) dx[c] = tx - xi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) dy[c] = ty - yi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) dz[c] = tz - zi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) d2[c] = nb_fma(dz[c], dz[c], nb_fma(dy[c], dy[c], nb_fma(dx[c], dx[c], eps2)));
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) y[c] = __builtin_amdgcn_rsq(d2[c]);
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) {
+                        const double y2 = y[c] * y[c];
+                        const double e = nb_fma(-d2[c], y2, 1.0);
+                        const double t3 = y[c] * y2;
+                        u[c] = nb_fma(t3 * e, 1.5, t3);
+                    }
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) {
+                        const double si = tm * u[c], sj = mi[c0g + c] * u[c];
+                        ax[c0g + c] = nb_fma(si, dx[c], ax[c0g + c]); ay[c0g + c] = nb_fma(si, dy[c], ay[c0g + c]); az[c0g + c] = nb_fma(si, dz[c], az[c0g + c]);
+                        bx = nb_fma(-sj, dx[c], bx); by = nb_fma(-sj, dy[c], by); bz = nb_fma(-sj, dz[c], bz);
+                    }
+                }
+                tx = wave_rot1(tx); ty = wave_rot1(ty); tz = wave_rot1(tz); tm = wave_rot1(tm);
+                bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz);
+            }
+            if (sym) partial[(size_t)(pl.t_layer0 + d) * pl.np + tstart + lane] = SymRowT<double>{bx, by, bz};
+        }
+        SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + (w - gtab[2 * g])) * pl.np + (size_t)g * S + lane;
+#pragma unroll
+        for (int c = 0; c < IPL; ++c) out[c * 64] = SymRowT<double>{ax[c], ay[c], az[c]};
+    }
+}
+
+// The RANK form of the pass (multi-GPU: rank r keeps the super-blocks [g0, g1) of its own rows resident and sweeps THEIR chunk
+// lists, so every unordered pair of the system is evaluated by exactly one rank): the traveler sums a rank produces belong
+// to bodies of other ranks as well.  This kernel adds up, for EVERY row of the system, what this rank has for it -- its
+// resident layers (own rows only) and the traveler layers written by the rank's own super-blocks, in the order
+// nb_integrate_symw uses -- into one array A[np]; the ranks then reduce-scatter A (ncclReduceScatter, or peer copies + a
+// fixed-order sum in the single-process handle) and the plain integrate kernel reads the rank's rows of the result.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __restrict__ partial, const uint32_t* __restrict__ gtab,
+                                                       typename vec4<T>::type* __restrict__ A, const SymWPlan pl, uint32_t S, uint32_t g0, uint32_t g1)
+{
+    using SymRow = SymRowT<T>;
+    using V4 = typename vec4<T>::type;
+    const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
+    if (j >= pl.np) return;
+    const uint32_t b = j / S;
+    T sx = 0, sy = 0, sz = 0;
+    if (b >= g0 && b < g1) {
+        const uint32_t nr = gtab[2 * b + 1];
+        for (uint32_t e = 0; e < nr; ++e) { const SymRow r = partial[(size_t)(pl.r_layer0 + e) * pl.np + j]; sx += r.x; sy += r.y; sz += r.z; }
+    }
+    if (g1 - g0 > pl.H) {
+        for (uint32_t d = 0; d <= pl.H; ++d) {                   // few ring distances, many own super-blocks: ascending distance
+            uint32_t g = b + pl.nsb - 1 - d;
+            if (g >= pl.nsb) g -= pl.nsb;
+            if (g < g0 || g >= g1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
+            const SymRow r = partial[(size_t)(pl.t_layer0 + d) * pl.np + j];
+            sx += r.x; sy += r.y; sz += r.z;
+        }
+    } else {
+        for (uint32_t g = g0; g < g1; ++g) {                     // a rank of many: only its own super-blocks can have written a layer of row j
+            uint32_t d = b + pl.nsb - 1 - g;
+            if (d >= pl.nsb) d -= pl.nsb;
+            if (d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
+            const SymRow r = partial[(size_t)(pl.t_layer0 + d) * pl.np + j];
+            sx += r.x; sy += r.y; sz += r.z;
+        }
+    }
+    A[j] = V4{sx, sy, sz, 0};
+}
+
+// The single-process multi-device handle's reduce-scatter by peer copies: stage[d] holds shard d's A rows for THIS shard's
+// row block (shard d = own: its own A); summed in ascending shard order -- deterministic.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_sym_sum_shards(const typename vec4<T>::type* __restrict__ stage, typename vec4<T>::type* __restrict__ out,
+                                                           uint32_t rows, uint32_t shards)
+{
+    using V4 = typename vec4<T>::type;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= rows) return;
+    T sx = 0, sy = 0, sz = 0;
+    for (uint32_t d = 0; d < shards; ++d) { const V4 r = ld4(stage + (size_t)d * rows + i); sx += r.x; sy += r.y; sz += r.z; }
+    out[i] = V4{sx, sy, sz, 0};
+}
+
+// The single-process multi-device handle's exchanges as PULL kernels (peer access: a kernel on device e reads the other
+// shards' arrays directly): one launch per shard instead of g - 1 hipMemcpyAsync -- the host thread that drives all g devices
+// issued ~120 copies per step at g = 8 (0.9-1.4 ms of host time against a 1.4 ms step, profiles/r03/multi_host_cost.txt).
+struct PeerPtrs { const void* p[16]; };
+
+// reduce-scatter: out[i] = sum over shards d (ascending: deterministic) of A_d[e * rows + i]
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_peer_sum(const PeerPtrs src, typename vec4<T>::type* __restrict__ out, uint32_t rows, uint32_t shards, uint32_t e)
+{
+    using V4 = typename vec4<T>::type;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= rows) return;
+    T sx = 0, sy = 0, sz = 0;
+    for (uint32_t d = 0; d < shards; ++d) {
+        const V4 r = ld4((const V4*)src.p[d] + (size_t)e * rows + i);
+        sx += r.x; sy += r.y; sz += r.z;
+    }
+    out[i] = V4{sx, sy, sz, 0};
+}
+
+// all-gather: dst (shard e's replicated array) takes every other shard's own row block from that shard's array
+template <typename T>
+__global__ __launch_bounds__(kBlock) void nb_peer_gather(const PeerPtrs src, typename vec4<T>::type* __restrict__ dst, uint32_t rows, uint32_t shards, uint32_t e)
+{
+    using V4 = typename vec4<T>::type;
+    const uint32_t idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= rows * shards) return;
+    const uint32_t d = idx / rows;
+    if (d == e) return;
+    dst[idx] = ld4((const V4*)src.p[d] + idx);
+}
+
+// K2 for the wave-granular form: resident layers gtab[2g+1] (waves that worked on g's list), then the traveler layers.
+template <typename T, int R>
+__global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::type* __restrict__ bodies, typename vec4<T>::type* __restrict__ vel,
+                                                           typename vec4<T>::type* __restrict__ acc, const SymRowT<T>* __restrict__ partial,
+                                                           const uint32_t* __restrict__ gtab, uint32_t n, const SymWPlan pl, uint32_t S, T dt,
+                                                           typename vec4<T>::type* __restrict__ gout, T G)
+{
+    using V4 = typename vec4<T>::type;
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t il = gid / R, r = gid % R;
+    const bool valid = il < n;
+    T sx = 0, sy = 0, sz = 0;
+    if (valid) {
+        const uint32_t b = il / S;
+        const uint32_t nr = gtab[2 * b + 1];
+        const uint32_t nt = pl.H + ((pl.n_hi && b >= pl.n_hi) ? 1u : 0u);
+        const uint32_t total = nr + nt;
+        auto row = [&](uint32_t e) { return partial + (size_t)(e < nr ? pl.r_layer0 + e : pl.t_layer0 + (e - nr)) * pl.np + il; };
+        uint32_t e = r;
+        for (; e + 3 * R < total; e += 4 * R) {
+            const SymRowT<T> p0 = *row(e), p1 = *row(e + R), p2 = *row(e + 2 * R), p3 = *row(e + 3 * R);
+            sx += p0.x; sy += p0.y; sz += p0.z;
+            sx += p1.x; sy += p1.y; sz += p1.z;
+            sx += p2.x; sy += p2.y; sz += p2.z;
+            sx += p3.x; sy += p3.y; sz += p3.z;
+        }
+        for (; e < total; e += R) {
+            const SymRowT<T> p0 = *row(e);
+            sx += p0.x; sy += p0.y; sz += p0.z;
+        }
+    }
+    if constexpr (R > 1) {
+#pragma unroll
+        for (int m = 1; m < R; m <<= 1) {
+            sx += __shfl_xor(sx, m, 64);
+            sy += __shfl_xor(sy, m, 64);
+            sz += __shfl_xor(sz, m, 64);
+        }
+    }
+    if (!valid || r != 0) return;
+    V4 nx, nv, na;
+    leapfrog<T>(ld4(bodies + il), ld4(vel + il), ld4(acc + il), sx, sy, sz, dt, nx, nv, na);
+    vel[il] = nv;                                                       // :281
+    bodies[il] = nx;                                                    // :283
+    acc[il] = na;                                                       // :290
+    if (gout) gout[il] = V4{nx.x, nx.y, nx.z, G * nx.w};
+}
+
+// K2 for the symmetric pass: a body's acceleration is the sum of its resident layers (one per segment of its
+// super-block's chunk list) and its traveler layers (one per ring distance), in ascending layer order.
+template <int R>
+__global__ __launch_bounds__(kBlock) void nb_integrate_sym(float4* __restrict__ bodies, float4* __restrict__ vel, float4* __restrict__ acc,
+                                                          const SymRow* __restrict__ partial, uint32_t n, const SymPlan pl, uint32_t S, float dt,
+                                                          float4* __restrict__ gout, float G)
+{
+    const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
+    const uint32_t il = gid / R, r = gid % R;
+    const bool valid = il < n;
+    float sx = 0, sy = 0, sz = 0;
+    if (valid) {
+        const uint32_t b = il / S;
+        const uint32_t nr = pl.q;
+        const uint32_t nt = pl.H + ((pl.n_hi && b >= pl.n_hi) ? 1u : 0u);
+        const uint32_t total = nr + nt;
+        auto row = [&](uint32_t e) { return partial + (size_t)(e < nr ? pl.r_layer0 + e : pl.t_layer0 + (e - nr)) * pl.np + il; };
+        uint32_t e = r;
+        for (; e + 3 * R < total; e += 4 * R) {
+            const SymRow p0 = *row(e), p1 = *row(e + R), p2 = *row(e + 2 * R), p3 = *row(e + 3 * R);
+            sx += p0.x; sy += p0.y; sz += p0.z;
+            sx += p1.x; sy += p1.y; sz += p1.z;
+            sx += p2.x; sy += p2.y; sz += p2.z;
+            sx += p3.x; sy += p3.y; sz += p3.z;
+        }
+        for (; e < total; e += R) {
+            const SymRow p0 = *row(e);
+            sx += p0.x; sy += p0.y; sz += p0.z;
+        }
+    }
+    if constexpr (R > 1) {
+#pragma unroll
+        for (int m = 1; m < R; m <<= 1) {
+            sx += __shfl_xor(sx, m, 64);
+            sy += __shfl_xor(sy, m, 64);
+            sz += __shfl_xor(sz, m, 64);
+        }
+    }
+    if (!valid || r != 0) return;
+    float4 nx, nv, na;
+    leapfrog<float>(ld4(bodies + il), ld4(vel + il), ld4(acc + il), sx, sy, sz, dt, nx, nv, na);
+    vel[il] = nv;                                                       // :281
+    bodies[il] = nx;                                                    // :283
+    acc[il] = na;                                                       // :290
+    if (gout) gout[il] = float4{nx.x, nx.y, nx.z, G * nx.w};
+}
+
+}  // namespace nb
