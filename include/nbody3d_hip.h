@@ -136,7 +136,9 @@ typedef struct nb_config {
     uint32_t layer_budget_mib; /* most device memory (MiB) the symmetric pass may take for its partial-sum layers
                                (~ 6 N^2 / S bytes, S = 512 or 1,024 rows: 6.4 GB at N = 1,048,576); a system whose
                                layers would not fit runs the ordered-pair kernels instead.  0 -> a third of the
-                               device's memory, at most 96 GiB (N up to ~4 M on an MI355X)                          */
+                               device's memory, at most 96 GiB (N up to ~4 M on an MI355X).  nb_create also checks
+                               the memory that is FREE: a whole-system handle whose layers would not fit it falls back
+                               the same way (a rank-form shard fails instead: its peers expect the reduce-scatter) */
     uint32_t reserved[4];
 } nb_config;
 

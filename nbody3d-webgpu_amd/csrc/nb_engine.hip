@@ -592,8 +592,20 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     if (cfg.ext_stream || (cfg.flags & NB_FLAG_EXT_STREAM)) { s->stream = (hipStream_t)cfg.ext_stream; s->own_stream = false; }
     else { NB_HIPC(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking)); s->own_stream = true; }
 
-    plan_handle(s, cfg, prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256,
-                 prop.clockRate > 0 ? 1e3 * prop.clockRate : 2.4e9, (double)prop.totalGlobalMem);     // clockRate is in kHz
+    const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    const double clock_hz = prop.clockRate > 0 ? 1e3 * prop.clockRate : 2.4e9;     // clockRate is in kHz
+    plan_handle(s, cfg, n_cu, clock_hz, (double)prop.totalGlobalMem);
+    if (s->sym && !s->sym_rank && !cfg.force_variant) {
+        // The planner budgets the symmetric pass's layers against the device's TOTAL memory; what is FREE right now may be less
+        // (other handles, other processes).  A whole-system handle then takes the ordered-pair kernels instead of failing in
+        // hipMalloc.  (A rank-form shard does not: its peers would still expect the reduce-scatter -- it fails loudly below.)
+        size_t free_b = 0, total_b = 0;
+        const double need = 3.0 * s->esz * s->sym_np * s->sym_layers + 12.0 * s->esz * s->sym_np;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > 0.9 * (double)free_b) {
+            cfg.flags |= NB_FLAG_NO_SYM;
+            plan_handle(s, cfg, n_cu, clock_hz, (double)prop.totalGlobalMem);
+        }
+    }
     if (!kernel_of(s->f64, shape_of(s))) return bail(NB_ERR_INVALID, "nb_create: no kernel for shape " + s->variant);
 
     const size_t row = 4 * s->esz;

@@ -169,6 +169,16 @@ def test_handles_that_cannot_use_the_symmetric_pass_fall_back():
         assert "sgpr" in s.variant, s.variant
 
 
+def test_layers_that_do_not_fit_the_free_memory_fall_back_to_ordered_pairs():
+    """The planner budgets against the device's total memory; nb_create checks what is free: N = 7,000,000 with the budget
+    lifted plans 288 GB of layers -- more than the card has -- and the handle takes the ordered-pair kernels instead of
+    failing in hipMalloc."""
+    n, budget = 7000000, 400000
+    assert capi.plan_query(n, layer_budget_mib=budget)["sym"] == 1
+    with Simulation(n, layer_budget_mib=budget) as s:
+        assert "sgpr" in s.variant, s.variant
+
+
 def test_two_million_bodies_take_the_symmetric_pass():
     """Layers beyond the old fixed 16 GB budget (N = 2,000,000: 23.6 GB of partial sums; the default budget is a third of the
     device memory): one step, sampled rows against an fp64 direct sum, momentum of the pair sums."""
