@@ -124,3 +124,11 @@ def test_random_rank_form_case(seed):
         assert "symwrank" in name, (seed, n, g, name)
     ra = oracle.accel_f64(b.astype(np.float64), 1.0)
     assert np.abs(aa[:, :3] - ra[:, :3]).max() <= (1e-12 if f64 else 2e-5) * max(float(np.abs(ra[:, :3]).max()), 1e-30), (seed, n, g, name)
+
+
+@pytest.mark.parametrize("seed", range(40000, 40048))
+def test_random_api_call_sequence(seed):
+    """simulate(k) across the graph-replay thresholds, dt / G changes, pause, read, snapshot + restore, frames -- on a handle
+    and on the oracle side by side (tests/api_sequence.py; tools/fuzz_api.py runs the long campaign)."""
+    from api_sequence import run_sequence
+    run_sequence(seed, n_max=1500)

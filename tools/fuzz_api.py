@@ -1,94 +1,24 @@
 #!/usr/bin/env python3
-"""Randomised API-sequence test: a handle and a CPU model (the oracle) are driven through the same random sequence of
-calls -- simulate(k) over the graph-replay thresholds, dt / G changes, pause (dt = 0), read, restore from an earlier snapshot,
-viewer frames -- and compared after every read.  Exercises the state the engine keeps between calls: buffer parity of the fused
-steps, captured graphs, the (x, y, z, G m) j-stream copy, the pair-transposed copy, the frame slots.  Needs a GPU.
-usage: fuzz_api.py [sequences] [seed0]"""
+"""Long campaign of tests/api_sequence.py::run_sequence (random API call sequences on a handle and on the CPU oracle side by
+side).  Needs a GPU; the time is mostly the single-threaded oracle's.  usage: fuzz_api.py [sequences] [seed0]"""
 import os
 import sys
 import time
 
-import numpy as np
-
 ROOT = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(ROOT, "nbody3d-webgpu_amd"))
-sys.path.insert(0, ROOT)
-from nbody3d_amd import MultiSimulation, Simulation, ic  # noqa: E402
-from oracle import oracle  # noqa: E402
+for p in (os.path.join(ROOT, "nbody3d-webgpu_amd"), ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+from api_sequence import run_sequence  # noqa: E402
 
 seqs = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 40000
-VARIANTS = [0, 0, 0, 2, 22, 28, 34, 304014, 402644, 502641, 601014, 704013, 704013, 708013, 708011]
 fails, t0 = 0, time.time()
 for q in range(seqs):
-    rng = np.random.default_rng(seed0 + q)
-    f64 = bool(rng.random() < 0.2)
-    multi = bool(rng.random() < 0.15)
-    n = int(rng.integers(300, 2500))
-    variant = 0 if multi else int(rng.choice(VARIANTS))
-    if f64 and variant not in (0, 2, 708013):
-        variant = 708013 if n > 512 else 0
-    dt_np = np.float64 if f64 else np.float32
-    run = oracle.run_f64 if f64 else oracle.run_f32
-    tol = 1e-10 if f64 else 2e-5
-    b, v = ic.plummer(n, seed=int(rng.integers(1 << 30)))
-    mb, mv, ma = b.astype(dt_np), v.astype(dt_np), np.zeros((n, 4), dt_np)          # the model's state
-    dt, G = 1e-3, 1.0
-    log, snap = [], None
     try:
-        ctx = MultiSimulation(n, int(rng.choice([2, 3, 4])), precision="f64" if f64 else "f32") if multi else \
-            Simulation(n, precision="f64" if f64 else "f32", force_variant=variant, jsplit=int(rng.choice([0, 0, 2, 3])) if variant else 0)
-        with ctx as sim:
-            name = sim.variant
-            sim.init(mb, mv)
-            sim.set_params(dt, G)
-            steps_total = 0
-            for _ in range(int(rng.integers(4, 12))):
-                op = rng.choice(["sim", "sim", "sim", "params", "pause", "read", "snap", "restore", "frame"])
-                if op == "sim" and steps_total < 70:
-                    k = int(rng.choice([1, 1, 2, 3, 15, 16, 17, 33]))
-                    sim.simulate(k)
-                    mb, mv, ma = run(mb, mv, ma, dt, G, k)
-                    steps_total += k
-                    log.append("sim%d" % k)
-                elif op == "params":
-                    dt, G = float(rng.choice([1e-3, 5e-4, 2e-3])), float(rng.choice([1.0, 1.0, 0.5, 2.5]))
-                    sim.set_params(dt, G)
-                    log.append("dt=%g,G=%g" % (dt, G))
-                elif op == "pause":
-                    sim.simulate(int(rng.choice([1, 16, 40])), 0.0, G)          # dt = 0: no dispatch (nbody3d.js:474)
-                    sim.set_params(dt, G)
-                    log.append("pause")
-                elif op == "snap":
-                    snap = tuple(x.copy() for x in sim.read())
-                    msnap = (mb.copy(), mv.copy(), ma.copy())
-                    log.append("snap")
-                elif op == "restore" and snap is not None:
-                    sim.init(*snap)
-                    mb, mv, ma = (x.copy() for x in msnap)
-                    log.append("restore")
-                elif op == "frame" and not multi:
-                    sim.request_frame()
-                    fb, fs, _ = sim.frame()
-                    want = np.sqrt((mv[:, :3].astype(np.float64) ** 2).sum(1))
-                    ftol = max(tol * 10, 2e-7)              # the frame is packed to f32 whatever the handle's precision
-                    assert np.abs(np.asarray(fb)[:, :3] - mb[:, :3]).max() <= ftol * max(1.0, np.abs(mb[:, :3]).max()), "frame bodies"
-                    assert np.abs(np.asarray(fs) - want).max() <= 1e-4 * max(1e-3, want.max()), "frame speed"
-                    log.append("frame")
-                else:
-                    bb, vv, aa = sim.read()
-                    scale = max(1.0, float(np.abs(mb[:, :3]).max()))
-                    e_pos = float(np.abs(bb[:, :3] - mb[:, :3]).max() / scale)
-                    e_vel = float(np.abs(vv[:, :3] - mv[:, :3]).max() / max(1e-3, float(np.abs(mv[:, :3]).max())))
-                    e_acc = float(np.abs(aa[:, :3] - ma[:, :3]).max() / max(1e-30, float(np.abs(ma[:, :3]).max()))) if steps_total else 0.0
-                    log.append("read")
-                    assert e_pos <= tol and e_vel <= 10 * tol and e_acc <= 10 * tol, "read: pos %.2e vel %.2e acc %.2e" % (e_pos, e_vel, e_acc)
-            bb = sim.read()[0]
-            e_pos = float(np.abs(bb[:, :3] - mb[:, :3]).max() / max(1.0, float(np.abs(mb[:, :3]).max())))
-            assert e_pos <= tol, "final: pos %.2e" % e_pos
+        run_sequence(seed0 + q)
     except Exception as e:
         fails += 1
-        print("FAIL seq", seed0 + q, dict(n=n, f64=f64, multi=multi, variant=variant), locals().get("name"), " ".join(log), "->", repr(e), flush=True)
+        print("FAIL", repr(e), flush=True)
     if (q + 1) % 50 == 0:
         print("... %d sequences, %d failures, %.0f s" % (q + 1, fails, time.time() - t0), flush=True)
 print("api fuzz: %d sequences from seed %d, %d failures, %.0f s" % (seqs, seed0, fails, time.time() - t0))
