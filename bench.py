@@ -74,8 +74,8 @@ def parse():
     ap.add_argument("--force-dist", action="store_true",
                     help="run the distributed exchange path even with one rank (plumbing test)")
     ap.add_argument("--no-also", action="store_true",
-                    help="skip the secondary single-GPU measurements (BASELINE configs 2 and 5, the reference's default "
-                         "N=40,002 system) that the default 1-GPU headline run appends under the `also` key")
+                    help="skip the secondary single-GPU measurements (BASELINE configs 2 and 5, config 4's N=1,048,576 on one GPU, the "
+                         "reference's default N=40,002 system) that the default 1-GPU headline run appends under the `also` key")
     return ap.parse_args()
 
 
@@ -260,10 +260,11 @@ def sampled_rows_check(bodies64, accel, rows, G, tol):
 def also_measurements(Simulation, ic, device):
     """Secondary measurements appended to the default 1-GPU headline line (same process, same gates): the other
     single-GPU BASELINE configs and the reference's own default workload, each with its own sampled-row check
-    against an fp64 direct sum.  ~1.5 s of GPU time in all; the headline fields are computed before this runs.
+    against an fp64 direct sum.  ~2.5 s of GPU time in all; the headline fields are computed before this runs.
 
       config 2   N=65,536 uniform cube, fp32: the default shape, and the "LDS tile=256" kernel BASELINE names (variant 28)
       config 5   N=262,144 Plummer, fp64
+      config 4   its N=1,048,576 system on this one GPU (3 steps), fp32
       default    the reference's UI defaults (index.html:68-74, nbody3d.js:62-64,163-177): 2 galaxies x 20,000 + 2 = N 40,002,
                  G = dt = 1e-4, central masses 1e7 -- built by js/ic.js::galaxies under Node, digest-checked against the
                  reference generator's own output (tests/golden/galaxy40002_params.json)
@@ -311,6 +312,9 @@ def also_measurements(Simulation, ic, device):
     run("config 2: N=65536 uniform cube, fp32, LDS tile=256 kernel (variant 28)", cb, cv, 1e-3, 1.0, "f32", 28, 150, 250, 20)
     pb, pv = ic.plummer(N_HEADLINE, seed=1)
     run("config 5: N=262144 Plummer sphere, fp64", pb, pv, 1e-3, 1.0, "f64", 0, 1, 3, 3)
+    mb, mv = ic.plummer(1048576, seed=1)
+    run("config 4's system on ONE GPU: N=1048576 Plummer sphere, fp32 (the 8-GPU run shards this)", mb, mv, 1e-3, 1.0, "f32", 0, 1, 3, 3)
+    del mb, mv
     try:
         gb, gv, gp = ic.reference_galaxies(os.path.join(ROOT, "tests", "golden", "galaxy40002_params.json"))
         run("reference default: N=40002, 2 galaxies x 20000 + central masses 1e7, G=dt=1e-4 (index.html:68-74), fp32",
