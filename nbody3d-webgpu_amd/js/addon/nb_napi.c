@@ -54,6 +54,7 @@ static int (*p_multi_collective_info)(nb_multi *, int *, int *, int *);
 static int (*p_step_times)(nb_sim *, double *, double *, double *, uint32_t *);
 static int (*p_frame_request)(nb_sim *);
 static int (*p_frame_acquire)(nb_sim *, int, const float **, const float **, uint64_t *);
+static int (*p_plan_query)(const nb_config *, int, double, nb_plan_info *, uint32_t *, uint32_t);
 
 /* one JS handle = a single-device nb_sim or a single-process multi-device nb_multi */
 typedef struct { nb_sim *sim; nb_multi *multi; uint32_t n; int f64; } handle_t;
@@ -128,6 +129,7 @@ static napi_value js_load(napi_env env, napi_callback_info info)
         SYM(p_multi_variant_name, "nb_multi_variant_name"); SYM(p_multi_diagnostics, "nb_multi_diagnostics");
         SYM(p_multi_set_collective, "nb_multi_set_collective"); SYM(p_multi_collective_info, "nb_multi_collective_info");
         SYM(p_step_times, "nb_step_times"); SYM(p_frame_request, "nb_frame_request"); SYM(p_frame_acquire, "nb_frame_acquire");
+        SYM(p_plan_query, "nb_plan_query");
 #undef SYM
         g_lib = h;
     }
@@ -175,26 +177,60 @@ static int get_f64_prop(napi_env env, napi_value obj, const char *name, double *
 }
 
 /* create({n, f64, eps2, device, shardBegin, shardCount, variant, jsplit, flags, shards, collective}) -> external */
+/* options object -> nb_config (create and planQuery read the same keys) */
+static void read_config(napi_env env, napi_value opts, nb_config *cfg)
+{
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = sizeof *cfg; cfg->device = -1;
+    uint32_t u; double d;
+    if (get_u32_prop(env, opts, "n", &u)) cfg->n = u;
+    if (get_u32_prop(env, opts, "f64", &u)) cfg->precision = u ? NB_F64 : NB_F32;
+    if (get_f64_prop(env, opts, "eps2", &d)) cfg->eps2 = d;
+    if (get_f64_prop(env, opts, "device", &d)) cfg->device = (int32_t)d;
+    if (get_u32_prop(env, opts, "shardBegin", &u)) cfg->shard_begin = u;
+    if (get_u32_prop(env, opts, "shardCount", &u)) cfg->shard_count = u;
+    if (get_u32_prop(env, opts, "variant", &u)) cfg->force_variant = u;
+    if (get_u32_prop(env, opts, "jsplit", &u)) cfg->jsplit = u;
+    if (get_u32_prop(env, opts, "tile", &u)) cfg->tile = u;
+    if (get_u32_prop(env, opts, "flags", &u)) cfg->flags = u;
+    if (get_u32_prop(env, opts, "layerBudgetMiB", &u)) cfg->layer_budget_mib = u;
+}
+
+/* planQuery(options) -> {variant, kind, ipl, ls, x, jsplit, jPerSplit, sym, symRows, symLayers, layerBytes}: nb_plan_query -- the launch
+ * plan nb_create would build, from host arithmetic alone (options.nCU + options.clockHz given: no GPU needed) */
+static napi_value js_plan_query(napi_env env, napi_callback_info info)
+{
+    if (!need_lib(env)) return NULL;
+    size_t argc = 1; napi_value argv[1];
+    CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
+    if (argc < 1) { napi_throw_type_error(env, NULL, "planQuery(options) requires an object"); return NULL; }
+    nb_config cfg; read_config(env, argv[0], &cfg);
+    uint32_t n_cu = 0; double clock = 0.0;
+    get_u32_prop(env, argv[0], "nCU", &n_cu);
+    get_f64_prop(env, argv[0], "clockHz", &clock);
+    nb_plan_info pi; memset(&pi, 0, sizeof pi); pi.struct_size = sizeof pi;
+    int rc = p_plan_query(&cfg, (int)n_cu, clock, &pi, NULL, 0);
+    if (rc != NB_OK) return throw_nb(env, rc, NULL, "nb_plan_query");
+    napi_value o, v;
+    CHECK_NAPI(env, napi_create_object(env, &o));
+    CHECK_NAPI(env, napi_create_string_utf8(env, pi.variant, NAPI_AUTO_LENGTH, &v)); napi_set_named_property(env, o, "variant", v);
+#define PUT_U32(name, val) do { napi_create_uint32(env, (val), &v); napi_set_named_property(env, o, name, v); } while (0)
+    PUT_U32("kind", pi.kind); PUT_U32("ipl", pi.ipl); PUT_U32("ls", pi.ls); PUT_U32("x", pi.x);
+    PUT_U32("jsplit", pi.jsplit); PUT_U32("jPerSplit", pi.j_per_split);
+    PUT_U32("sym", pi.sym); PUT_U32("symRows", pi.sym_np); PUT_U32("symLayers", pi.sym_layers);
+#undef PUT_U32
+    napi_create_double(env, 3.0 * (cfg.precision == NB_F64 ? 8.0 : 4.0) * (double)pi.sym_np * (double)pi.sym_layers, &v);
+    napi_set_named_property(env, o, "layerBytes", v);
+    return o;
+}
+
 static napi_value js_create(napi_env env, napi_callback_info info)
 {
     if (!need_lib(env)) return NULL;
     size_t argc = 1; napi_value argv[1];
     CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     if (argc < 1) { napi_throw_type_error(env, NULL, "create(options) requires an object"); return NULL; }
-    nb_config cfg; memset(&cfg, 0, sizeof cfg);
-    cfg.struct_size = sizeof cfg; cfg.device = -1;
-    uint32_t u; double d;
-    if (get_u32_prop(env, argv[0], "n", &u)) cfg.n = u;
-    if (get_u32_prop(env, argv[0], "f64", &u)) cfg.precision = u ? NB_F64 : NB_F32;
-    if (get_f64_prop(env, argv[0], "eps2", &d)) cfg.eps2 = d;
-    if (get_f64_prop(env, argv[0], "device", &d)) cfg.device = (int32_t)d;
-    if (get_u32_prop(env, argv[0], "shardBegin", &u)) cfg.shard_begin = u;
-    if (get_u32_prop(env, argv[0], "shardCount", &u)) cfg.shard_count = u;
-    if (get_u32_prop(env, argv[0], "variant", &u)) cfg.force_variant = u;
-    if (get_u32_prop(env, argv[0], "jsplit", &u)) cfg.jsplit = u;
-    if (get_u32_prop(env, argv[0], "tile", &u)) cfg.tile = u;
-    if (get_u32_prop(env, argv[0], "flags", &u)) cfg.flags = u;
-    if (get_u32_prop(env, argv[0], "layerBudgetMiB", &u)) cfg.layer_budget_mib = u;
+    nb_config cfg; read_config(env, argv[0], &cfg);
     uint32_t shards = 0, collective = 0;
     get_u32_prop(env, argv[0], "shards", &shards);
     get_u32_prop(env, argv[0], "collective", &collective);   /* 0 peer copies, 1 RCCL (nb_multi_collective) */
@@ -519,7 +555,7 @@ static napi_value init_module(napi_env env, napi_value exports)
         {"setParams", js_set_params}, {"step", js_step}, {"download", js_download}, {"sync", js_sync},
         {"destroy", js_destroy}, {"enableTiming", js_enable_timing}, {"kernelTimes", js_kernel_times},
         {"variant", js_variant}, {"diagnostics", js_diagnostics}, {"stepTimes", js_step_times},
-        {"collectiveInfo", js_collective_info}, {"requestFrame", js_request_frame}, {"frame", js_frame},
+        {"collectiveInfo", js_collective_info}, {"requestFrame", js_request_frame}, {"frame", js_frame}, {"planQuery", js_plan_query},
     };
     for (size_t i = 0; i < sizeof fns / sizeof fns[0]; ++i) {
         napi_value f;

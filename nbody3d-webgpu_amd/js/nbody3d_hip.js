@@ -47,6 +47,14 @@ function deviceCount() {
   return addon.deviceCount();
 }
 
+/** The launch plan the engine would build for {n, f64, variant, jsplit, flags, layerBudgetMiB, shardBegin, shardCount}
+ *  (nb_plan_query): kernel form, j-partitions, and the symmetric pass's padded rows / partial-sum layers / bytes.  With nCU and
+ *  clockHz given (an MI355X: 256, 2.4e9) it needs no GPU -- capacity planning; otherwise the current device's figures are used. */
+function planQuery(options) {
+  load();
+  return addon.planQuery(options || {});
+}
+
 function asParticles(particles) {
   // generateGalaxy returns [pos, vel] (nbody3d.js:132); objects are accepted too
   let bodies, vel, accel = null;
@@ -235,6 +243,6 @@ function read() { return need().read(); }
 
 module.exports = {
   Simulation: Simulation, init: init, step: step, simulate: simulate, read: read,
-  load: load, deviceCount: deviceCount, TILE_SIZE: TILE_SIZE, EPS2: EPS2, DEFAULT_G: DEFAULT_G, DEFAULT_DT: DEFAULT_DT,
+  load: load, deviceCount: deviceCount, planQuery: planQuery, TILE_SIZE: TILE_SIZE, EPS2: EPS2, DEFAULT_G: DEFAULT_G, DEFAULT_DT: DEFAULT_DT,
   get current() { return current; }, get abiVersion() { return abi; },
 };

@@ -38,6 +38,10 @@ if (mode === 'cpu') {
   if (nb.deviceCount() === 0) {
     check('no_device_throws', throws(function () { nb.init([b0, v0]); }, /no HIP device.*NB_2|NB_2/));
   }
+  // 2a. the launch planner from JavaScript, no GPU needed (nb_plan_query)
+  const pq = nb.planQuery({ n: 262144, nCU: 256, clockHz: 2.4e9 }), pq2 = nb.planQuery({ n: 1024, nCU: 256, clockHz: 2.4e9 });
+  check('plan_query', /^f32pk_symw_ipl16_j1_w2048/.test(pq.variant) && pq.sym === 1 && pq.symRows === 262144 && pq.layerBytes === 12 * 262144 * pq.symLayers &&
+    /^f32pk_fused_regs1024/.test(pq2.variant) && pq2.sym === 0 && throws(function () { nb.planQuery({ n: 0, nCU: 256, clockHz: 2.4e9 }); }, /NB_1/), pq);
   check('step_before_init_throws', throws(function () { new nb.Simulation().step(1e-3); }, /not initialised/));
   check('bad_particles_throws', throws(function () { new nb.Simulation().init({}); }, /expected/));
   // 2b. the seedable generateGalaxy port reproduces, bit for bit, the arrays the
