@@ -37,13 +37,27 @@ int main(int argc, char **argv)
     cfg.struct_size = sizeof cfg;
     cfg.n = n;
     cfg.device = -1;
+    /* the launch planner needs no device: what an MI355X (256 CUs, 2.4 GHz) would run for the headline system */
+    {
+        nb_config big = cfg;
+        big.n = 262144;
+        nb_plan_info pi;
+        memset(&pi, 0, sizeof pi);
+        pi.struct_size = sizeof pi;
+        uint32_t tab[512];
+        int prc = nb_plan_query(&big, 256, 2.4e9, &pi, tab, 512);
+        int ok = prc == NB_OK && pi.sym == 1 && pi.symw == 1 && pi.sym_np == 262144 && pi.tab_len == 512 && tab[0] == 0 && tab[1] >= 1 &&
+                 strncmp(pi.variant, "f32pk_symw_ipl16_j1_w2048", 25) == 0;
+        printf("%s plan query without a device: %s, %u layers\n", ok ? "ok" : "FAIL", pi.variant, pi.sym_layers);
+        if (!ok) fails++;
+    }
     nb_sim *sim = NULL;
     int rc = nb_create(&cfg, &sim);
     if (nb_device_count() == 0) {
         /* reference: alert + return when WebGPU is missing (nbody3d.js:151-155) */
         int ok = rc == NB_ERR_NO_DEVICE && sim == NULL && strstr(nb_last_error(NULL), "no CPU fallback") != NULL;
         printf("%s no-device contract (rc=%d, \"%s\")\n", ok ? "ok" : "FAIL", rc, nb_last_error(NULL));
-        return ok ? 0 : 1;
+        return ok && !fails ? 0 : 1;
     }
     if (rc != NB_OK) { printf("FAIL nb_create: %s\n", nb_last_error(NULL)); return 1; }
 

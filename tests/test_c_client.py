@@ -28,7 +28,8 @@ def run():
 
 @pytest.mark.skipif(have_gpu(), reason="checks the no-device contract")
 def test_c_client_reports_missing_device():
-    assert "no-device contract" in run()
+    out = run()
+    assert "no-device contract" in out and "ok plan query without a device" in out
 
 
 @pytest.mark.gpu
