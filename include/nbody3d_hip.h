@@ -93,7 +93,7 @@ typedef enum nb_array { NB_BODIES = 0, NB_VEL = 1, NB_ACCEL = 2 } nb_array;
  */
 typedef struct nb_config {
     uint32_t struct_size;  /* sizeof(nb_config), for ABI evolution             */
-    uint32_t n;            /* total bodies N (any N >= 1; reference is only
+    uint32_t n;            /* total bodies N (any 1 <= N <= 2^30; reference is only
                               defined for N % 256 == 0)        */
     uint32_t precision;    /* nb_precision; default NB_F32                     */
     uint32_t tile;         /* j-tile staged in LDS; 0 -> 256 (nbody3d.js:4)    */

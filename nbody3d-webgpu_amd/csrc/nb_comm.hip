@@ -312,6 +312,7 @@ int nb_multi_create(const nb_config* cfg_in, uint32_t n_shards, const int32_t* d
     memset(&cfg, 0, sizeof cfg);
     memcpy(&cfg, cfg_in, cfg_in->struct_size < sizeof cfg ? cfg_in->struct_size : sizeof cfg);
     if (cfg.n == 0) return mfail(nullptr, NB_ERR_INVALID, "nb_multi_create: n must be >= 1");
+    if (cfg.n > (1u << 30) - 1024u * n_shards) return mfail(nullptr, NB_ERR_INVALID, "nb_multi_create: n too large (the padded system must stay <= 2^30 rows)");
     if (cfg.shard_count || cfg.ext_bodies || cfg.ext_stream)
         return mfail(nullptr, NB_ERR_INVALID, "nb_multi_create: shard/ext_* fields are managed by the multi handle");
     const int count = nb_device_count();

@@ -535,6 +535,7 @@ static int read_config(const nb_config* cfg_in, const char* who, nb_config* cfg,
     memset(cfg, 0, sizeof *cfg);
     memcpy(cfg, cfg_in, cfg_in->struct_size < sizeof *cfg ? cfg_in->struct_size : sizeof *cfg);
     if (cfg->n == 0) return fail(nullptr, NB_ERR_INVALID, w + ": n must be >= 1");
+    if (cfg->n > (1u << 30)) return fail(nullptr, NB_ERR_INVALID, w + ": n must be <= 2^30 (32-bit row arithmetic; the reference passes N as an f32, exact to 2^24: nbody3d.js:246)");
     if (cfg->precision > NB_F64) return fail(nullptr, NB_ERR_INVALID, w + ": unknown precision");
     if (cfg->tile != 0 && cfg->tile != (uint32_t)nb::kTile)
         return fail(nullptr, NB_ERR_INVALID, w + ": only tile = 256 is built (reference TILE_SIZE)");

@@ -224,3 +224,6 @@ def test_bad_arguments_are_errors():
         capi.plan_query(0)
     with pytest.raises(capi.NBodyError):
         capi.plan_query(1000, shard=(900, 200))
+    with pytest.raises(capi.NBodyError):
+        capi.plan_query((1 << 30) + 1)
+    assert capi.plan_query(1 << 30)["sym"] == 0            # the largest system the 32-bit row arithmetic takes: ordered pairs
