@@ -72,6 +72,7 @@ bool decode_variant(uint32_t v, Shape* out)
 
 static void name_variant(LaunchPlan* s, bool f64, const Shape& sh)
 {
+    s->sh = sh;          // every path of plan_launch ends here: the plan carries the shape it was laid out for
     char buf[112];
     if (sh.kind == kPkSgpr)
         snprintf(buf, sizeof buf, "f32pk_sgpr_ipl%d%s_js%u", sh.ipl, sh.x == 4 ? "_ws4" : sh.x == 5 ? "_ws4p" : "", s->jsplit);

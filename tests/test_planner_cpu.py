@@ -3,6 +3,10 @@ the way the kernels walk it (nb_force_symw / nb_force_sym, nb_integrate_symw, cs
 properties the symmetric pass rests on: every unordered pair of bodies is evaluated exactly once, no partial-sum row is
 written twice, and the integrate kernel reads exactly the rows that were written.  The reference has no counterpart (its
 dispatch is ceil(N / 256) workgroups, nbody3d.js:478); the path these plans serve is nbody3d.js:245-272."""
+import os
+import shutil
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -227,3 +231,21 @@ def test_bad_arguments_are_errors():
     with pytest.raises(capi.NBodyError):
         capi.plan_query((1 << 30) + 1)
     assert capi.plan_query(1 << 30)["sym"] == 0            # the largest system the 32-bit row arithmetic takes: ordered pairs
+
+
+def test_planner_under_address_and_ub_sanitizers(tmp_path):
+    """nb_plan.cpp is host-only C++: compiled with -fsanitize=address,undefined and driven over ~170,000 configurations."""
+    gxx = shutil.which("g++")
+    if gxx is None:
+        pytest.skip("no g++")
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    csrc = os.path.join(root, "nbody3d-webgpu_amd", "csrc")
+    exe = str(tmp_path / "plan_sanitize")
+    cc = subprocess.run([gxx, "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-I", csrc,
+                         os.path.join(root, "tests", "c", "plan_sanitize.cpp"), os.path.join(csrc, "nb_plan.cpp"), "-o", exe],
+                        capture_output=True, text=True, timeout=300)
+    if cc.returncode != 0 and ("asan" in cc.stderr or "ubsan" in cc.stderr or "sanitize" in cc.stderr):
+        pytest.skip("this g++ has no sanitizer runtime: " + cc.stderr[-200:])
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
+    assert run.returncode == 0 and "under ASan + UBSan" in run.stdout, run.stdout[-1000:] + run.stderr[-3000:]
