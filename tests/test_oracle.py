@@ -1,5 +1,7 @@
 """CPU tests of the oracle (oracle/nb_oracle.c) -- the pins SURVEY.md §8(c)
 asks for, since the reference holds no tests or golden vectors of its own."""
+import os
+
 import numpy as np
 import pytest
 
@@ -142,3 +144,23 @@ def test_plummer_generator_sanity():
     assert abs(2 * ke / -pe - 1.0) < 0.1          # virial equilibrium
     assert abs(ke + pe + 0.25) < 0.03             # N-body units: E = -1/4
     assert np.all(np.abs(mom) < 1e-6)
+
+
+def test_oracle_under_address_and_ub_sanitizers(tmp_path):
+    """The checker itself under -fsanitize=address,undefined (CPU only): golden fixture bit for bit, ragged ranges, the threaded
+    baseline kernel, odd sizes (tests/c/oracle_sanitize.c)."""
+    import shutil
+    import subprocess
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    root = os.path.normpath(os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    exe = str(tmp_path / "oracle_sanitize")
+    cc = subprocess.run([gcc, "-std=c99", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-ffp-contract=off",
+                         "-fno-fast-math", "-fopenmp", os.path.join(root, "tests", "c", "oracle_sanitize.c"),
+                         os.path.join(root, "oracle", "nb_oracle.c"), "-o", exe, "-lm"], capture_output=True, text=True, timeout=300)
+    if cc.returncode != 0 and "sanitize" in cc.stderr:
+        pytest.skip("this gcc has no sanitizer runtime")
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([exe, os.path.join(root, "tests", "golden")], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0 and "ok oracle under ASan + UBSan" in run.stdout, run.stdout[-1000:] + run.stderr[-3000:]
