@@ -4,21 +4,31 @@
     pair-interactions/s (and % fp32 roofline) at N=262,144; 1/2/4/8 GPU
 
 One "step" = one pass of the hot path (force kernel + integrate kernel, and for
-N>1 the position all-gather) over the whole particle set, inputs already
-resident in HBM.  Prints ONE JSON line on rank 0.
+N>1 the exchange: reduce-scatter of the partial accelerations + all-gather of the
+positions) over the whole particle set, inputs already resident in HBM.  Prints
+ONE JSON line on rank 0.
 
     python bench.py                      # 1 GPU, N=262,144 Plummer sphere
     python bench.py --gpus 8             # starts its own 8 ranks (torch.distributed.run child)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 \
         --master-addr 127.0.0.1 --master-port 29500 bench.py --gpus 8     # or under a launcher
 
-Multi-GPU: one process per GPU; the i-bodies are sharded (rank r owns a
-contiguous row block); every rank keeps the full bodies array
-in HBM and the ranks all-gather their new rows each step: the engine's own
-in-place ncclAllGather (RCCL over xGMI) enqueued right after the integrate
-kernel (--exchange native, default), or torch.distributed's all-gather through
-the exchange hook (--exchange torch).  Default --scaling strong: the metric is
-quoted at N=262,144 for every GPU count.
+Multi-GPU: one process per GPU; rank r owns a contiguous block of rows
+ and every rank keeps the full bodies array in HBM.  Two
+protocols, both measured by ONE N>1 launch:
+  * default (`config.parallelism` = pairshardN+reducescatter+allgather): the
+    rank form of the symmetric force pass -- every UNORDERED pair of the system
+    is evaluated by exactly one rank (the one whose rows keep it resident), each
+    rank adds up what it has for every row, the engine reduce-scatters those
+    partial accelerations (in-place ncclReduceScatter, RCCL over xGMI), integrates
+    its rows and all-gathers the new positions (in-place ncclAllGather);
+  * `also[0]` (ishardN+allgather, NB_FLAG_NO_SYM = --flags 64): the protocol
+    north_star spells out -- ordered-pair force pass over the rank's own rows x
+    all j, integrate, all-gather of the positions.
+--exchange torch routes the all-gather through torch.distributed instead of the
+engine's own RCCL calls.  `per_rank` breaks a step into force / sym_reduce /
+reduce_scatter / integrate / allgather (nb_step_times2), next to ms_per_step.
+Default --scaling strong: the metric is quoted at N=262,144 for every GPU count.
 
 The line is only printed with a value when the run's own correctness checks
 pass (a sampled row of the benchmarked launch shape against an fp64 direct sum,
@@ -341,12 +351,19 @@ def main():
     if not os.path.exists(capi.library_path()):
         # fresh checkout: rank 0 compiles the engine (never a CPU fallback); the other ranks wait until it has finished
         # (the process group does not exist yet, so the rendezvous is a stamp file of this launch, written after the build)
+        # The stamp is unique to this launch (torchrun's run id + master port + the launcher's pid) and node-local: each
+        # node's LOCAL_RANK 0 builds for its node; it is removed before the build and again at exit.
+        import atexit
         import tempfile
-        stamp = os.path.join(tempfile.gettempdir(), "nb_engine_built_%s" % os.environ.get("MASTER_PORT", "0"))   # per launch
-        if rank == 0:
+        launch = "%s_%s_%s" % (os.environ.get("TORCHELASTIC_RUN_ID", "none"), os.environ.get("MASTER_PORT", "0"), os.getppid())
+        stamp = os.path.join(tempfile.gettempdir(), "nb_engine_built_" + "".join(c if c.isalnum() else "_" for c in launch))
+        if local_rank == 0:
+            if os.path.exists(stamp):
+                os.unlink(stamp)
             import __graft_entry__
             __graft_entry__.build()
             open(stamp, "w").write("ok\n")
+            atexit.register(lambda: os.path.exists(stamp) and os.unlink(stamp))
         else:
             t_wait = time.time()
             while not (os.path.exists(stamp) and os.path.exists(capi.library_path())):
@@ -385,91 +402,14 @@ def main():
     G, dt = 1.0, 1e-3
     bodies, vel = (ic.plummer(n, seed=1) if args.workload == "plummer" else ic.uniform_cube(n, seed=2))
     np_dtype = np.float64 if args.precision == "f64" else np.float32
+    esz = 8 if args.precision == "f64" else 4
     # native exchange: rows in whole super-blocks of 1,024 (f64: 512), so that the ranks can take the rank form of the symmetric force
     # pass (NB_FLAG_SYM_SHARD: each unordered pair evaluated by ONE rank, partial accelerations reduce-scattered by the engine)
     sym_shard = dist_wanted and args.exchange == "native" and not args.variant and not (args.flags & capi.NB_FLAG_NO_SYM)
     plan = ShardPlan(n, world, rank, align=1024 if sym_shard else 256)
     bodies_p, vel_p = plan.pad(bodies.astype(np_dtype)), plan.pad(vel.astype(np_dtype))
-
     overlap = args.overlap or os.environ.get("NB_OVERLAP") == "1"
-    kw = dict(precision=args.precision, device=local_rank, force_variant=args.variant, jsplit=args.jsplit,
-              flags=args.flags)
-    exchange = {"kind": "none"}
-    t_bodies = None
-    if dist is not None:
-        sim = None
-        if args.exchange == "native":
-            # the engine owns stream and buffers; the only thing the host moves is the ncclUniqueId.
-            # Every rank must take the SAME path: ncclCommInitRank blocks until all ranks have called it, so the ranks
-            # first agree that each of them CAN call it (librccl loads, the handle exists, the partition is the one
-            # ncclAllGather needs), then all call it, then agree on the outcome; one failure anywhere sends every rank
-            # to the torch path together (a lone rank falling back would leave the others in mismatched collectives).
-            def agree(flag):
-                t = torch.tensor([1 if flag else 0], device="cuda", dtype=torch.int32)
-                dist.all_reduce(t, op=dist.ReduceOp.MIN)
-                return bool(t.item())
-
-            why = None
-            try:
-                my_uid = capi.rccl_unique_id()          # loads librccl on EVERY rank (rank 0's id is the one used)
-                sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count),
-                                 **dict(kw, flags=kw["flags"] | (capi.NB_FLAG_SYM_SHARD if sym_shard else 0)))
-                if plan.padded_n != world * plan.count or plan.begin != rank * plan.count:
-                    raise RuntimeError("partition is not nranks equal row blocks")
-            except Exception as e:
-                why = "precondition: " + str(e)
-            if agree(why is None):
-                uid = torch.zeros(capi.NB_RCCL_ID_BYTES, dtype=torch.uint8, device="cuda")
-                if rank == 0:
-                    uid.copy_(torch.frombuffer(bytearray(my_uid), dtype=torch.uint8))
-                dist.broadcast(uid, src=0)
-                try:
-                    sim.rccl_attach(bytes(uid.cpu().numpy().tobytes()), world, rank, overlap=overlap)
-                except Exception as e:
-                    why = "attach: " + str(e)
-                if not agree(why is None) and why is None:
-                    why = "attach failed on another rank"
-            elif why is None:
-                why = "precondition failed on another rank"
-            if why is None:
-                nr, rk, ver = sim.rccl_info()
-                shp = sim.shape_info()
-                exchange = {"kind": ("rccl-native: in-place ncclReduceScatter of the partial accelerations (rank form of the symmetric pass) + "
-                                     if "symwrank" in sim.variant else "rccl-native ") + "in-place ncclAllGather of the positions on the engine stream" +
-                                    (" (overlapped: own-row force work first)" if overlap and "symwrank" not in sim.variant else ""),
-                            "rccl_nranks": nr, "rccl_rank": rk, "rccl_version": ver,
-                            "overlap_requested": bool(overlap),
-                            # the overlapped form only hides the gather when some j-partitions lie inside the rank's own rows
-                            "overlap_engaged": bool(overlap and shp["own_splits"] > 0 and "symwrank" not in sim.variant),
-                            "own_splits": shp["own_splits"], "jsplit": shp["jsplit"]}
-            else:                      # keep the run alive on torch's collective -- every rank together -- and say so
-                if sim is not None:
-                    sim.close()
-                sim = None
-                exchange = {"native_attach_failed": why}
-        if sim is None:
-            # torch owns the replicated bodies array so its collective runs on it directly
-            stream = torch.cuda.current_stream()
-            t_bodies = torch.empty((plan.padded_n, 4), device="cuda",
-                                   dtype=torch.float64 if args.precision == "f64" else torch.float32)
-            sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count), stream=stream.cuda_stream,
-                             ext_bodies=t_bodies.data_ptr(), **kw)
-            if rehearsal:
-                sim.set_exchange(torch_allgather_via_host_hook(t_bodies, plan))
-                exchange["kind"] = "REHEARSAL host-staged gloo"
-            elif overlap:
-                sim.set_exchange_overlapped(*torch_allgather_overlapped_hooks(t_bodies, plan))
-                exchange["kind"] = "torch.distributed all_gather_into_tensor (nccl = RCCL), async, via exchange hooks"
-                shp = sim.shape_info()
-                exchange.update({"overlap_requested": True, "overlap_engaged": shp["own_splits"] > 0,
-                                 "own_splits": shp["own_splits"], "jsplit": shp["jsplit"]})
-            else:
-                sim.set_exchange(torch_allgather_hook(t_bodies, plan))
-                exchange["kind"] = "torch.distributed all_gather_into_tensor (nccl = RCCL) via exchange hook"
-    else:
-        sim = Simulation(plan.padded_n, **kw)
-    sim.init(bodies_p, vel_p)
-    sim.set_params(dt, G)
+    cpu_dev = "cpu" if rehearsal else "cuda"
 
     def barrier():
         torch.cuda.synchronize()
@@ -480,87 +420,201 @@ def main():
     def all_ranks(flag):
         if dist is None:
             return bool(flag)
-        t = torch.tensor([1 if flag else 0], device="cpu" if rehearsal else "cuda", dtype=torch.int32)
+        t = torch.tensor([1 if flag else 0], device=cpu_dev, dtype=torch.int32)
         dist.all_reduce(t, op=dist.ReduceOp.MIN)
         return bool(t.item())
 
-    e_start = None
-    if world == 1 and dist is None:
-        ke0, pe0, _ = sim.diagnostics()          # fp64 on the device; outside the timed region
-        e_start = ke0 + pe0
+    def open_sim(flags):
+        """The handle of one protocol: (sim, exchange description, torch-owned bodies or None)."""
+        kw = dict(precision=args.precision, device=local_rank, force_variant=args.variant, jsplit=args.jsplit, flags=flags)
+        exchange = {"kind": "none"}
+        if dist is None:
+            return Simulation(plan.padded_n, **kw), exchange, None
+        sim = None
+        if args.exchange == "native":
+            # the engine owns stream and buffers; the only thing the host moves is the ncclUniqueId.
+            # Every rank must take the SAME path: ncclCommInitRank blocks until all ranks have called it, so the ranks
+            # first agree that each of them CAN call it (librccl loads, the handle exists, the partition is the one
+            # ncclAllGather needs), then all call it, then agree on the outcome; one failure anywhere sends every rank
+            # to the torch path together (a lone rank falling back would leave the others in mismatched collectives).
+            why = None
+            try:
+                my_uid = capi.rccl_unique_id()          # loads librccl on EVERY rank (rank 0's id is the one used)
+                sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count),
+                                 **dict(kw, flags=flags | (capi.NB_FLAG_SYM_SHARD if sym_shard else 0)))
+                if plan.padded_n != world * plan.count or plan.begin != rank * plan.count:
+                    raise RuntimeError("partition is not nranks equal row blocks")
+            except Exception as e:
+                why = "precondition: " + str(e)
+            if all_ranks(why is None):
+                uid = torch.zeros(capi.NB_RCCL_ID_BYTES, dtype=torch.uint8, device="cuda")
+                if rank == 0:
+                    uid.copy_(torch.frombuffer(bytearray(my_uid), dtype=torch.uint8))
+                dist.broadcast(uid, src=0)
+                try:
+                    sim.rccl_attach(bytes(uid.cpu().numpy().tobytes()), world, rank, overlap=overlap)
+                except Exception as e:
+                    why = "attach: " + str(e)
+                if not all_ranks(why is None) and why is None:
+                    why = "attach failed on another rank"
+            elif why is None:
+                why = "precondition failed on another rank"
+            if why is None:
+                nr, rk, ver = sim.rccl_info()
+                shp = sim.shape_info()
+                rank_form = "symwrank" in sim.variant
+                exchange = {"kind": ("rccl-native: in-place ncclReduceScatter of the partial accelerations (rank form of the symmetric pass) + "
+                                     if rank_form else "rccl-native ") + "in-place ncclAllGather of the positions on the engine stream" +
+                                    (" (overlapped: own-row force work first)" if overlap else ""),
+                            "rccl_nranks": nr, "rccl_rank": rk, "rccl_version": ver,
+                            "overlap_requested": bool(overlap),
+                            # the overlapped form only hides the gather when some of the force work reads the rank's own rows only
+                            "overlap_engaged": bool(overlap and shp["own_splits"] > 0),
+                            "own_splits": shp["own_splits"], "jsplit": shp["jsplit"]}
+                return sim, exchange, None
+            if sim is not None:                # keep the run alive on torch's collective -- every rank together -- and say so
+                sim.close()
+            sim = None
+            exchange = {"native_attach_failed": why}
+        # torch owns the replicated bodies array so its collective runs on it directly
+        stream = torch.cuda.current_stream()
+        t_bodies = torch.empty((plan.padded_n, 4), device="cuda", dtype=torch.float64 if args.precision == "f64" else torch.float32)
+        sim = Simulation(plan.padded_n, shard=(plan.begin, plan.count), stream=stream.cuda_stream, ext_bodies=t_bodies.data_ptr(), **kw)
+        if rehearsal:
+            sim.set_exchange(torch_allgather_via_host_hook(t_bodies, plan))
+            exchange["kind"] = "REHEARSAL host-staged gloo"
+        elif overlap:
+            sim.set_exchange_overlapped(*torch_allgather_overlapped_hooks(t_bodies, plan))
+            exchange["kind"] = "torch.distributed all_gather_into_tensor (nccl = RCCL), async, via exchange hooks"
+            shp = sim.shape_info()
+            exchange.update({"overlap_requested": True, "overlap_engaged": shp["own_splits"] > 0,
+                             "own_splits": shp["own_splits"], "jsplit": shp["jsplit"]})
+        else:
+            sim.set_exchange(torch_allgather_hook(t_bodies, plan))
+            exchange["kind"] = "torch.distributed all_gather_into_tensor (nccl = RCCL) via exchange hook"
+        return sim, exchange, t_bodies
 
-    # gate 1: the benchmarked launch shape itself -- accelerations of the first step, a few rows of
-    # this rank's shard, against an fp64 direct sum (done in numpy here; not the oracle)
-    sim.simulate(1)
-    acc = sim.read(bodies=False, vel=False)[2]
-    lo, hi = plan.begin, min(plan.begin + plan.count, n)
-    rows = np.unique(np.linspace(lo, hi - 1, 6).astype(np.int64)) if hi > lo else np.array([], np.int64)
-    shape_check = sampled_rows_check(bodies.astype(np.float64), acc, rows, G,
-                                     1e-11 if args.precision == "f64" else 2e-5)
-    shape_check["kernel_variant"] = sim.variant
-    shape_ok = all_ranks(shape_check["pass"])
+    def protocol_name(variant):
+        if world == 1 and dist is None:
+            return "1gpu"
+        if "symwrank" in variant:       # each unordered pair evaluated by ONE rank; partial accelerations reduce-scattered, positions all-gathered
+            return "pairshard%d+reducescatter+allgather%s" % (world, "(overlapped)" if overlap else "")
+        return "ishard%d+allgather%s" % (world, "(overlapped)" if overlap else "")
 
-    sim.simulate(max(args.warmup - 1, 0))
-    barrier()
-    sim.enable_timing(True)
-    t0 = time.perf_counter()
-    sim.simulate(args.steps)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    f_ms, i_ms, x_ms, launches = sim.step_times()
-    sim.enable_timing(False)
+    def measure(flags, want_energy):
+        """One protocol, start to finish: handle, gates, warm-up, the timed steps, the per-part breakdown.  Returns (result, sim)
+        with the handle still open (the caller closes it)."""
+        sim, exchange, t_bodies = open_sim(flags)
+        sim._bench_keepalive = t_bodies          # torch-owned position array (exchange through torch): lives as long as the handle
+        sim.init(bodies_p, vel_p)
+        sim.set_params(dt, G)
+        res = {"variant": sim.variant, "exchange": exchange, "e_start": None}
+        if want_energy:
+            ke0, pe0, _ = sim.diagnostics()          # fp64 on the device; outside the timed region
+            res["e_start"] = ke0 + pe0
+        # gate 1: the benchmarked launch shape itself -- accelerations of the first step, a few rows of
+        # this rank's shard, against an fp64 direct sum (done in numpy here; not the oracle)
+        sim.simulate(1)
+        acc = sim.read(bodies=False, vel=False)[2]
+        lo, hi = plan.begin, min(plan.begin + plan.count, n)
+        rows = np.unique(np.linspace(lo, hi - 1, 6).astype(np.int64)) if hi > lo else np.array([], np.int64)
+        shape_check = sampled_rows_check(bodies.astype(np.float64), acc, rows, G, 1e-11 if args.precision == "f64" else 2e-5)
+        shape_check["kernel_variant"] = sim.variant
+        res["shape_check"] = shape_check
+        res["shape_ok"] = all_ranks(shape_check["pass"])
 
-    if dist is not None:
-        t = torch.tensor([elapsed], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        sim.simulate(max(args.warmup - 1, 0))
+        barrier()
+        sim.enable_timing(True)
+        t0 = time.perf_counter()
+        sim.simulate(args.steps)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        parts = sim.step_breakdown()
+        sim.enable_timing(False)
+        if dist is not None:
+            t = torch.tensor([elapsed], device=cpu_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        res["elapsed"], res["parts"] = elapsed, parts
+        ms_step = 1e3 * elapsed / args.steps
 
-    # gate 2 (distributed runs): every rank must hold the same replicated position array
-    replicas_ok, replica_note = True, None
-    if dist is not None:
-        mine = sim.read(vel=False, accel=False)[0]
-        digest = float(np.abs(mine[:n, :3].astype(np.float64)).sum())
-        t = torch.tensor([digest, -digest], device="cpu" if rehearsal else "cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        replicas_ok = bool(t[0].item() == -t[1].item()) and bool(np.isfinite(digest))
-        replica_note = {"abs_sum_of_positions_max_over_ranks": float(t[0].item()),
-                        "abs_sum_of_positions_min_over_ranks": float(-t[1].item()), "pass": replicas_ok}
-
-    pairs_step = n * (n - 1)
-    value = pairs_step * args.steps / elapsed
-    roof_pairs = PEAK_FP32_TFLOPS * 1e12 / FLOPS_PER_PAIR * (0.5 if args.precision == "f64" else 1.0)
-    out = {
-        "metric": "pair-interactions/s", "value": value, "unit": "pair-interactions/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-        "dtype": args.precision, "data": "synthetic",
-        "config": {"workload": "N=%d %s, dt=1e-3, G=1, eps2=1e-4, i-sharded over %d GPU(s)" % (
-            n, "Plummer sphere" if args.workload == "plummer" else "uniform cube", world),
-            "n": n, "kernel_variant": sim.variant,
-            "parallelism": ("ishard%d+allgather%s" % (world, "(overlapped)" if overlap else "")) if world > 1 else "1gpu"},
-        "frac_of_fp32_roofline": value / (roof_pairs * world),
-        "shape_check": shape_check,
-    }
-    if dist is not None:
-        exchange["avg_ms"] = x_ms
-        exchange["bytes_sent_per_rank"] = int(plan.count * 4 * (8 if args.precision == "f64" else 4))
-        out["exchange"] = exchange
-        out["per_rank"] = {"rank": rank, "rows": plan.count, "force_kernel_avg_ms": f_ms, "integrate_kernel_avg_ms": i_ms,
-                           "exchange_avg_ms": x_ms}
-        out["replica_check"] = replica_note
-    if rehearsal:
-        out["REHEARSAL"] = "ranks share one GPU, exchange staged through host memory over gloo: not a result"
-        if rank == 0:   # the sharded state must equal an unsharded run of the same number of steps
+        # gate 2 (distributed runs): every rank must hold the same replicated position array
+        res["replicas_ok"], res["replica_check"] = True, None
+        if dist is not None:
+            mine = sim.read(vel=False, accel=False)[0]
+            digest = float(np.abs(mine[:n, :3].astype(np.float64)).sum())
+            t = torch.tensor([digest, -digest], device=cpu_dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            res["replicas_ok"] = bool(t[0].item() == -t[1].item()) and bool(np.isfinite(digest))
+            res["replica_check"] = {"abs_sum_of_positions_max_over_ranks": float(t[0].item()),
+                                    "abs_sum_of_positions_min_over_ranks": float(-t[1].item()), "pass": res["replicas_ok"]}
+            # what the collectives move, per rank and step (payload; a ring forwards each block g - 1 times):
+            #   all-gather: this rank's new position rows go to every other rank;
+            #   reduce-scatter (rank form): g - 1 of the g row blocks of this rank's partial-acceleration array go out, one block comes back summed
+            blk = int(plan.count * 4 * esz)
+            rank_form = "symwrank" in sim.variant
+            timed_ag = parts["allgathers"] > 0
+            exchange.update({
+                "allgather_ms": parts["allgather_ms"] if timed_ag else None,
+                "reduce_scatter_ms": parts["reduce_scatter_ms"] if rank_form else None,
+                "avg_ms": parts["allgather_ms"] + parts["reduce_scatter_ms"],            # every native collective of a step
+                "allgather_bytes_sent_per_rank": blk,
+                "reduce_scatter_bytes_sent_per_rank": blk * (world - 1) if rank_form else 0,
+                "bytes_sent_per_rank": blk + (blk * (world - 1) if rank_form else 0),
+                "note": None if timed_ag else "the overlapped all-gather runs on its own stream and is not timed by the engine"})
+            names = ["force_ms", "sym_reduce_ms", "reduce_scatter_ms", "integrate_ms", "allgather_ms", "span_ms"]
+            mine_parts = [parts[k] for k in names]
+            tmax = torch.tensor(mine_parts, device=cpu_dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            total = sum(mine_parts[:5])
+            res["per_rank"] = {"rank": rank, "rows": plan.count,
+                               "force_kernel_avg_ms": parts["force_ms"], "sym_reduce_kernel_avg_ms": parts["sym_reduce_ms"],
+                               "reduce_scatter_avg_ms": parts["reduce_scatter_ms"], "integrate_kernel_avg_ms": parts["integrate_ms"],
+                               "allgather_avg_ms": parts["allgather_ms"], "exchange_avg_ms": parts["allgather_ms"] + parts["reduce_scatter_ms"],
+                               "sum_of_parts_ms": total, "span_ms": parts["span_ms"], "ms_per_step": ms_step,
+                               "sum_of_parts_over_ms_per_step": total / ms_step if ms_step > 0 else None,
+                               "max_over_ranks": dict(zip(names, [float(v) for v in tmax.tolist()]))}
+        if rehearsal and rank == 0:   # the sharded state must equal an unsharded run of the same number of steps
             got = sim.read(vel=False, accel=False)[0][:n]
             with Simulation(n, precision=args.precision, device=local_rank) as ref:
                 ref.init(bodies.astype(np_dtype), vel.astype(np_dtype))
                 ref.simulate(max(args.warmup, 1) + args.steps, dt, G)
                 want = ref.read(vel=False, accel=False)[0]
-            out["rehearsal_max_rel_diff_vs_unsharded"] = float(
-                np.abs(got[:, :3] - want[:, :3]).max() / np.abs(want[:, :3]).max())
+            res["rehearsal_max_rel_diff_vs_unsharded"] = float(np.abs(got[:, :3] - want[:, :3]).max() / np.abs(want[:, :3]).max())
+        return res, sim
+
+    pairs_step = n * (n - 1)
+    roof_pairs = PEAK_FP32_TFLOPS * 1e12 / FLOPS_PER_PAIR * (0.5 if args.precision == "f64" else 1.0)
+    main_res, sim = measure(args.flags, world == 1 and dist is None)
+    elapsed, parts, variant = main_res["elapsed"], main_res["parts"], main_res["variant"]
+    f_ms, i_ms, launches = parts["force_ms"], parts["integrate_ms"], parts["launches"]
+    value = pairs_step * args.steps / elapsed
+    out = {
+        "metric": "pair-interactions/s", "value": value, "unit": "pair-interactions/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+        "dtype": args.precision, "data": "synthetic",
+        "config": {"workload": "N=%d %s, dt=1e-3, G=1, eps2=1e-4, %s over %d GPU(s)" % (
+            n, "Plummer sphere" if args.workload == "plummer" else "uniform cube",
+            "unordered pairs sharded by the rows that keep them resident" if "symwrank" in variant else "i-sharded", world),
+            "n": n, "kernel_variant": variant, "parallelism": protocol_name(variant)},
+        "frac_of_fp32_roofline": value / (roof_pairs * world),
+        "shape_check": main_res["shape_check"],
+    }
+    if dist is not None:
+        out["exchange"] = main_res["exchange"]
+        out["per_rank"] = main_res["per_rank"]
+        out["replica_check"] = main_res["replica_check"]
+    if rehearsal:
+        out["REHEARSAL"] = "ranks share one GPU, exchange staged through host memory over gloo: not a result"
+        if "rehearsal_max_rel_diff_vs_unsharded" in main_res:
+            out["rehearsal_max_rel_diff_vs_unsharded"] = main_res["rehearsal_max_rel_diff_vs_unsharded"]
     if launches:
-        # K1 on THIS rank: algorithmic flops of one launch / measured launch time
-        flops_launch = FLOPS_PER_PAIR * plan.count * (n - 1) if world > 1 else FLOPS_PER_PAIR * pairs_step
+        # K1 on THIS rank: algorithmic flops of one launch / measured launch time.  The rank form divides the system's
+        # UNORDERED pairs equally over the ranks: a rank's launch delivers 1/world of the N(N-1) ordered interactions.
+        flops_launch = FLOPS_PER_PAIR * pairs_step / world if "symwrank" in variant else (
+            FLOPS_PER_PAIR * plan.count * (n - 1) if world > 1 else FLOPS_PER_PAIR * pairs_step)
         peak = PEAK_FP32_TFLOPS * (0.5 if args.precision == "f64" else 1.0)
         achieved = flops_launch / (f_ms * 1e-3) / 1e12
         # HBM bytes per launch come from the PMC profile of the SAME kernel variant (separate
@@ -570,12 +624,12 @@ def main():
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
             if (tj.get("n") == n and tj.get("n_gpus", 1) == world and tj.get("dtype") == args.precision and
-                    tj.get("kernel_variant") == sim.variant):
+                    tj.get("kernel_variant") == variant):
                 traffic, traffic_src = tj.get("bytes_per_launch"), "profiles/k1_hbm_traffic.json (" + tj.get("source", "") + ")"
-        fused = "fused" in sim.variant
-        kname = ("nb_force_symw" if "symw" in sim.variant else "nb_force_sym" if "_sym_" in sim.variant else "nb_step_jpk" if "jpairs" in sim.variant
-                 else "nb_step_direct" if "fused_regs" in sim.variant else "nb_step_fused" if fused else "nb_force")
-        out["roofline"] = {"kernel": kname + "<%s> (%s)" % (args.precision, sim.variant),
+        fused = "fused" in variant
+        kname = ("nb_step_symf" if "symf" in variant else "nb_force_symw" if "symw" in variant else "nb_force_sym" if "_sym_" in variant
+                 else "nb_step_jpk" if "jpairs" in variant else "nb_step_direct" if "fused_regs" in variant else "nb_step_fused" if fused else "nb_force")
+        out["roofline"] = {"kernel": kname + "<%s> (%s)" % (args.precision, variant),
                            "bound": "valu",
                            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": f_ms, "launches": launches,
@@ -585,25 +639,43 @@ def main():
                                    "N(N-1) ORDERED pair interactions (SURVEY.md §8(d)) / launch time" +
                                    ("; the symmetric pass delivers them by evaluating each unordered pair once (r, r^2, the cube and "
                                     "the rsqrt are shared; both accelerations accumulated), 18 packed/transcendental issue slots + "
-                                    "rotation per TWO interactions instead of 16 per one" if "sym" in sim.variant else ""),
+                                    "rotation per TWO interactions instead of 16 per one" if "sym" in variant else ""),
                            "integrate_kernel_avg_ms": i_ms}
         if i_ms > 0:
             # algorithmic 96 B per body; "moved" adds the jsplit partials K2 sums.
             # At this size the state is cache-resident: the HBM figure of K2 is tools/k2_hbm.py (N >= 4M)
-            moved = _k2_bytes_per_body(sim.variant)
+            moved = _k2_bytes_per_body(variant)
             out["roofline"]["integrate_kernel_GBps"] = 96.0 * plan.count / (i_ms * 1e-3) / 1e9
             out["roofline"]["integrate_kernel_GBps_moved"] = moved * plan.count / (i_ms * 1e-3) / 1e9
             out["roofline"]["integrate_bytes_moved_over_algorithmic"] = moved / 96.0
-    if e_start is not None:
+    if main_res["e_start"] is not None:
         # total-energy drift of THIS run (north_star: "with total-energy drift reported"): one extra
         # untimed step so that KE(vel after call n) pairs with PE(positions before call n)
         _, pe_prev, _ = sim.diagnostics()
         sim.step()
         ke, _, _ = sim.diagnostics()
         out["energy_drift_over_run"] = {"steps": max(args.warmup, 1) + args.steps + 1,
-                                        "dE_rel": abs((ke + pe_prev - e_start) / e_start)}
+                                        "dE_rel": abs((ke + pe_prev - main_res["e_start"]) / main_res["e_start"])}
     sim.close()
-    ok = shape_ok and replicas_ok
+    ok = main_res["shape_ok"] and main_res["replicas_ok"]
+    if dist is not None and "symwrank" in variant and not rehearsal:
+        # The same launch also measures the protocol north_star spells out -- i-sharded ordered-pair force pass + per-step
+        # all-gather of the positions (NB_FLAG_NO_SYM) -- so that both are on record from ONE run: same ranks, same
+        # workload, same gates; its own communicator.
+        lit, sim2 = measure(args.flags | capi.NB_FLAG_NO_SYM, False)
+        sim2.close()
+        lval = pairs_step * args.steps / lit["elapsed"]
+        lp = lit["parts"]
+        out["also"] = [{"workload": "the same system through the north_star-literal protocol: i-shard + per-step RCCL all-gather(positions)",
+                        "config": {"kernel_variant": lit["variant"], "parallelism": protocol_name(lit["variant"]), "n": n},
+                        "value": lval if lit["shape_ok"] and lit["replicas_ok"] else None, "unit": "pair-interactions/s",
+                        "ms_per_step": 1e3 * lit["elapsed"] / args.steps, "steps": args.steps,
+                        "frac_of_fp32_roofline": lval / (roof_pairs * world),
+                        "k1_frac": (FLOPS_PER_PAIR * plan.count * (n - 1) / (lp["force_ms"] * 1e-3) / 1e12 /
+                                    (PEAK_FP32_TFLOPS * (0.5 if args.precision == "f64" else 1.0))) if lp["force_ms"] > 0 else None,
+                        "exchange": lit["exchange"], "per_rank": lit["per_rank"], "shape_check": lit["shape_check"],
+                        "replica_check": lit["replica_check"], "pass": bool(lit["shape_ok"] and lit["replicas_ok"])}]
+        ok = ok and out["also"][0]["pass"]
     if rank == 0 and not args.no_check:
         out["check"] = fixture_check()
         ok = ok and out["check"]["pass"]
@@ -615,6 +687,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(bodies, G, args.cpu_seconds)
     if dist is not None:
+        ok = all_ranks(ok)
         dist.barrier()
         dist.destroy_process_group()
     if not ok:

@@ -280,10 +280,30 @@ int nb_multi_collective_info(nb_multi *m, int *mode, int *nranks, int *rccl_vers
 int nb_enable_timing(nb_sim *s, int on);
 int nb_kernel_times(nb_sim *s, double *force_ms, double *integrate_ms,
                     uint32_t *launches);
-/* Same, plus the average time of the native RCCL all-gather (0 when none ran).  A fused
- * one-launch step reports its whole kernel as force_ms and 0 for integrate_ms. */
+/* Same, plus the average time of the native RCCL collectives of a step (the position all-gather and, for the
+ * rank form of the symmetric pass, the reduce-scatter of the partial accelerations before it; 0 when none ran).
+ * A fused one-launch step reports its whole kernel as force_ms and 0 for integrate_ms. */
 int nb_step_times(nb_sim *s, double *force_ms, double *integrate_ms, double *exchange_ms,
                   uint32_t *launches);
+/* The full breakdown of a step, part by part as the engine stream runs them (averages over the recorded steps,
+ * milliseconds): force pass [rank form: nb_sym_reduce, ncclReduceScatter] integrate [ncclAllGather].  span_ms is
+ * the time from the first event of a step to its last one, so force + sym_reduce + reduce_scatter + integrate +
+ * allgather = span - (idle gaps between the kernels).  An overlapped all-gather (NB_RCCL_OVERLAP) runs on its own
+ * stream and is not timed: allgathers = 0.  Set struct_size = sizeof(nb_step_timing) before the call.
+ * (No reference analogue: TimingHelper times one pass, util.js:297-423; the reference is single-device.) */
+typedef struct nb_step_timing {
+    uint32_t struct_size;
+    uint32_t launches;              /* steps averaged */
+    double force_ms;                /* the force kernel (both launches of an overlapped step) */
+    double sym_reduce_ms;           /* rank form: this rank's sums for every row (nb_sym_reduce) */
+    double reduce_scatter_ms;       /* rank form: in-place ncclReduceScatter of those sums */
+    double integrate_ms;
+    double allgather_ms;            /* in-place ncclAllGather of the new positions on the engine stream */
+    double span_ms;
+    uint32_t reduce_scatters;       /* steps whose reduce-scatter was timed */
+    uint32_t allgathers;            /* steps whose all-gather was timed */
+} nb_step_timing;
+int nb_step_times2(nb_sim *s, nb_step_timing *out);
 /* Runs ONLY the integrate kernel `reps` times back to back on the state as it stands (the
  * force sums are whatever the last force pass left; first zeroed if none ran) and returns
  * the average launch time: the memory-bound kernel measured on its own at sizes where a

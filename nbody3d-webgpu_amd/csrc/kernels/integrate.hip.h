@@ -102,58 +102,128 @@ __global__ __launch_bounds__(kBlock) void nb_frame_pack(const typename vec4<T>::
     }
 }
 
-// Diagnostics (no reference analogue): per-block fp64 partial
-// sums of kinetic energy, momentum, and the shard's share of the softened
-// potential; finished on the host (a few hundred doubles).
+// Diagnostics (no reference analogue; north_star "total-energy drift reported"): per-workgroup fp64
+// partial sums of kinetic energy, momentum and the handle's share of the softened potential; finished on the host in a
+// fixed order (deterministic).
+//   The potential is a scalar, so Newton's third law costs nothing here: workgroup (bi, c) holds kDiagRows i-rows (4 per lane)
+// and sweeps the 256-body tiles of j-chunk c, counting a pair only when j > i -- every UNORDERED pair of the system once
+// (a shard handle: the pairs whose LOWER index lies in its rows, so the shards' shares add up to the whole).  Tiles entirely
+// at or below the block's first row are skipped, tiles entirely above its last row take the unmasked loop, the few that
+// cross the diagonal the masked one.  f32 handles: r^2 and v_rsq_f32 in packed f32 per pair (relative error ~1e-7 per pair,
+// averaging out over the sum), every m_j / r accumulated in fp64 per lane -- 12 v_pk + 2 v_rsq_f32 + 2 v_cvt + 2 v_fma_f64 per
+// two i-rows and j; f64 handles: all fp64, v_rsq_f64 + one correction step.  N = 262,144: ~8 ms (the ordered-pair fp64 loop
+// it replaces: 52 ms; a force step: 10.5 ms).
+constexpr uint32_t kDiagRows = 4 * kBlock;
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void nb_diag(const typename vec4<T>::type* __restrict__ bodies,
                                                  const typename vec4<T>::type* __restrict__ vel, uint32_t n,
-                                                 uint32_t i_begin, uint32_t i_count, double G, double eps2,
-                                                 double* __restrict__ out /* [gridDim.x][5] */)
+                                                 uint32_t i_begin, uint32_t i_count, uint32_t j_chunk, double G, T eps2,
+                                                 double* __restrict__ out /* [gridDim.y][gridDim.x][5] */)
 {
     using V4 = typename vec4<T>::type;
     __shared__ V4 tile[kTile];
     __shared__ double red[5][kBlock / 64];
     const int tid = threadIdx.x;
-    const uint32_t il = blockIdx.x * kBlock + tid;
-    const bool valid = il < i_count;
-    V4 bi = V4{0, 0, 0, 0}, vi = V4{0, 0, 0, 0};
-    if (valid) { bi = bodies[i_begin + il]; vi = vel[il]; }
-    double pot = 0.0;
-    for (uint32_t j0 = 0; j0 < n; j0 += kTile) {
-        const uint32_t j = j0 + tid;
-        tile[tid] = (j < n) ? bodies[j] : V4{0, 0, 0, 0};
-        __syncthreads();
-        double p = 0.0;
-#pragma unroll 4
-        for (int jj = 0; jj < kTile; ++jj) {
-            const V4 b = tile[jj];
-            const double dx = (double)b.x - (double)bi.x, dy = (double)b.y - (double)bi.y, dz = (double)b.z - (double)bi.z;
-            const double r2 = dx * dx + dy * dy + dz * dz;
-            // exclude the self term exactly (j == i), keep everything else
-            const double w = (j0 + jj == i_begin + il) ? 0.0 : (double)b.w;
-            p += w * rsqrt(r2 + eps2);
-        }
-        pot += p;
-        __syncthreads();
+    const uint32_t ib0 = blockIdx.x * kDiagRows;                  // first row of the block, shard-local
+    const uint32_t gi0 = i_begin + ib0;                           // ... and as an index into `bodies`
+    const uint32_t rows = i_count - ib0 < kDiagRows ? i_count - ib0 : kDiagRows;
+    const uint32_t gi_end = gi0 + rows;
+    const uint32_t jc0 = blockIdx.y * j_chunk, jc1 = (jc0 + j_chunk < n) ? jc0 + j_chunk : n;
+
+    T xi[4], yi[4], zi[4];
+    double mi[4], acc[4] = {0.0, 0.0, 0.0, 0.0};
+    uint32_t gi[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t il = (uint32_t)tid + k * kBlock;
+        gi[k] = gi0 + il;
+        const bool valid = il < rows;
+        const V4 b = valid ? ld4(bodies + gi[k]) : V4{0, 0, 0, 0};
+        xi[k] = b.x; yi[k] = b.y; zi[k] = b.z; mi[k] = valid ? (double)b.w : 0.0;     // rows past the block: zero mass
     }
-    double vals[5];
-    const double m = valid ? (double)bi.w : 0.0;
-    vals[0] = 0.5 * m * ((double)vi.x * vi.x + (double)vi.y * vi.y + (double)vi.z * vi.z);
-    vals[1] = valid ? -0.5 * G * m * pot : 0.0;
-    vals[2] = m * vi.x; vals[3] = m * vi.y; vals[4] = m * vi.z;
+
+    for (uint32_t j0 = jc0; j0 < jc1; j0 += kTile) {
+        if (j0 + kTile <= gi0 + 1) continue;                      // every j of the tile <= every i of the block: counted elsewhere
+        const uint32_t j = j0 + tid;
+        __syncthreads();                                          // the previous tile has been read
+        tile[tid] = (j < jc1) ? ld4(bodies + j) : V4{0, 0, 0, 0};  // past the chunk / the system: zero mass
+        __syncthreads();
+        const bool masked = j0 < gi_end;                          // some j <= some i: per-pair test
+        if constexpr (sizeof(T) == 4) {
+            const nb_f2 e2 = nb_f2{eps2, eps2};
+            const nb_f2 xa = nb_f2{xi[0], xi[1]}, ya = nb_f2{yi[0], yi[1]}, za = nb_f2{zi[0], zi[1]};
+            const nb_f2 xb = nb_f2{xi[2], xi[3]}, yb = nb_f2{yi[2], yi[3]}, zb = nb_f2{zi[2], zi[3]};
+            if (!masked) {
+#pragma unroll 4
+                for (int jj = 0; jj < kTile; ++jj) {
+                    const float4 b = tile[jj];
+                    const nb_f2 px = nb_f2{b.x, b.x}, py = nb_f2{b.y, b.y}, pz = nb_f2{b.z, b.z};
+                    const nb_f2 dxa = px - xa, dya = py - ya, dza = pz - za, dxb = px - xb, dyb = py - yb, dzb = pz - zb;
+                    const nb_f2 ra = __builtin_elementwise_fma(dza, dza, __builtin_elementwise_fma(dya, dya, __builtin_elementwise_fma(dxa, dxa, e2)));
+                    const nb_f2 rb = __builtin_elementwise_fma(dzb, dzb, __builtin_elementwise_fma(dyb, dyb, __builtin_elementwise_fma(dxb, dxb, e2)));
+                    const double mj = (double)b.w;
+                    acc[0] = __builtin_fma((double)__builtin_amdgcn_rsqf(ra.x), mj, acc[0]);
+                    acc[1] = __builtin_fma((double)__builtin_amdgcn_rsqf(ra.y), mj, acc[1]);
+                    acc[2] = __builtin_fma((double)__builtin_amdgcn_rsqf(rb.x), mj, acc[2]);
+                    acc[3] = __builtin_fma((double)__builtin_amdgcn_rsqf(rb.y), mj, acc[3]);
+                }
+            } else {
+                for (int jj = 0; jj < kTile; ++jj) {
+                    const float4 b = tile[jj];
+                    const uint32_t jg = j0 + (uint32_t)jj;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float dx = b.x - xi[k], dy = b.y - yi[k], dz = b.z - zi[k];
+                        const float r2 = nb_fma(dz, dz, nb_fma(dy, dy, nb_fma(dx, dx, eps2)));
+                        const double w = jg > gi[k] ? (double)b.w : 0.0;
+                        acc[k] = __builtin_fma((double)__builtin_amdgcn_rsqf(r2), w, acc[k]);
+                    }
+                }
+            }
+        } else {
+            for (int jj = 0; jj < kTile; ++jj) {
+                const double4 b = tile[jj];
+                const uint32_t jg = j0 + (uint32_t)jj;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const double dx = b.x - xi[k], dy = b.y - yi[k], dz = b.z - zi[k];
+                    const double r2 = nb_fma(dz, dz, nb_fma(dy, dy, nb_fma(dx, dx, eps2)));
+                    const double y0 = __builtin_amdgcn_rsq(r2);               // ~2^-26 relative; one correction: y0 (1 + e/2), e = 1 - r2 y0^2
+                    const double e = nb_fma(-(r2 * y0), y0, 1.0);
+                    const double y = nb_fma(0.5 * y0, e, y0);
+                    const double w = (!masked || jg > gi[k]) ? b.w : 0.0;
+                    acc[k] = nb_fma(y, w, acc[k]);
+                }
+            }
+        }
+    }
+
+    double vals[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    vals[1] = -G * (mi[0] * acc[0] + mi[1] * acc[1] + mi[2] * acc[2] + mi[3] * acc[3]);
+    if (blockIdx.y == 0) {                                         // kinetic energy and momentum of the block's rows: once
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t il = ib0 + (uint32_t)tid + k * kBlock;
+            if (il >= i_count) continue;
+            const V4 v = ld4(vel + il);
+            const double vx = (double)v.x, vy = (double)v.y, vz = (double)v.z;
+            vals[0] += 0.5 * mi[k] * (vx * vx + vy * vy + vz * vz);
+            vals[2] += mi[k] * vx; vals[3] += mi[k] * vy; vals[4] += mi[k] * vz;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < 5; ++q) {
         double v = vals[q];
 #pragma unroll
-        for (int s = 32; s >= 1; s >>= 1) v += __shfl_xor(v, s, 64);
+        for (int sft = 32; sft >= 1; sft >>= 1) v += __shfl_xor(v, sft, 64);
         if ((tid & 63) == 0) red[q][tid >> 6] = v;
     }
     __syncthreads();
     if (tid < 5) {
         double v = 0;
         for (int w = 0; w < kBlock / 64; ++w) v += red[tid][w];
-        out[(size_t)blockIdx.x * 5 + tid] = v;
+        out[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 5 + tid] = v;
     }
 }
 

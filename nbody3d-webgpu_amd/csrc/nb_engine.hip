@@ -437,13 +437,13 @@ int get_events(nb_sim* s, nb_events* out)
     if (s->pool_next == s->pool.size()) {
         if (s->pool.size() >= 4096) return 1;   // stop recording, keep running
         nb_events t;
-        t.two = t.xchg = false;
+        t.two = t.xchg = t.rs = false;
         for (auto& e : t.e)
             if (hipEventCreate(&e) != hipSuccess) return 1;
         s->pool.push_back(t);
     }
     *out = s->pool[s->pool_next++];
-    out->two = out->xchg = false;
+    out->two = out->xchg = out->rs = false;
     return 0;
 }
 
@@ -468,10 +468,11 @@ namespace nbi {
 // Rank form of the symmetric pass, first half of a step: the force pass over the chunk lists of the handle's own super-blocks,
 // then this rank's sums for every row of the system into sym_A.
 template <typename T>
-int sym_rank_phase_a_t(nb_sim* s)
+int sym_rank_phase_a_t(nb_sim* s, hipEvent_t after_force)
 {
     using V4 = typename nb::vec4<T>::type;
     launch_force<T>(s);
+    if (after_force) NB_HIP(s, hipEventRecord(after_force, s->stream));
     nb::SymWPlan pl;
     memcpy(&pl, s->sym_plan, sizeof pl);
     const nb::SymRowT<T>* p = (const nb::SymRowT<T>*)s->partial;
@@ -483,11 +484,11 @@ int sym_rank_phase_a_t(nb_sim* s)
     return NB_OK;
 }
 
-int sym_rank_phase_a(nb_sim* s)
+int sym_rank_phase_a(nb_sim* s, void* after_force)
 {
     if (!s->sym_rank) return fail(s, NB_ERR_STATE, "sym_rank_phase_a: not a rank-form handle");
     if (int rc = ensure_gm(s)) return rc;
-    return s->f64 ? sym_rank_phase_a_t<double>(s) : sym_rank_phase_a_t<float>(s);
+    return s->f64 ? sym_rank_phase_a_t<double>(s, (hipEvent_t)after_force) : sym_rank_phase_a_t<float>(s, (hipEvent_t)after_force);
 }
 
 template <typename T>
@@ -648,7 +649,9 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     }
     NB_HIPC(hipMalloc(&s->zero_row, 64));                     // a zero-mass body at the origin: what the LDS-DMA staging
     NB_HIPC(hipMemsetAsync(s->zero_row, 0, 64, s->stream));   // of the packed tile kernels reads for rows past the range (stream-ordered)
-    s->diag_blocks = ceil_div(s->sc, nb::kBlock);
+    // diagnostics: a grid of (row blocks) x (j-chunks); the chunk is sized so that a few thousand workgroups share the pairs
+    s->diag_chunk = nb::kTile * std::min(16u, std::max(1u, s->n / 16384u));
+    s->diag_blocks = ceil_div(s->sc, nb::kDiagRows) * ceil_div(s->n, s->diag_chunk);
     NB_HIPC(hipMalloc((void**)&s->diag, sizeof(double) * 5 * s->diag_blocks));
 #undef NB_HIPC
     *out = s;
@@ -759,8 +762,8 @@ int nb_step(nb_sim* s, uint32_t nsteps)
             nb_events evr;
             const bool recr = s->timing && get_events(s, &evr) == 0;
             if (recr) NB_HIP(s, hipEventRecord(evr.e[0], s->stream));
-            if (int rc = nbi::sym_rank_phase_a(s)) return rc;
-            if (recr) NB_HIP(s, hipEventRecord(evr.e[1], s->stream));
+            if (int rc = nbi::sym_rank_phase_a(s, recr ? evr.e[7] : nullptr)) return rc;
+            if (recr) { NB_HIP(s, hipEventRecord(evr.e[1], s->stream)); evr.rs = true; }
             if (int rc = nbi::rccl_reduce_scatter_A(s)) return rc;
             if (recr) NB_HIP(s, hipEventRecord(evr.e[6], s->stream));
             if (int rc = nbi::sym_rank_phase_b(s)) return rc;
@@ -882,29 +885,68 @@ int nb_enable_timing(nb_sim* s, int on)
     return NB_OK;
 }
 
-int nb_step_times(nb_sim* s, double* force_ms, double* integrate_ms, double* exchange_ms, uint32_t* launches)
+// Averages of the recorded steps since the last call; clears the record.
+static int collect_times(nb_sim* s, nb_step_timing* t)
 {
-    if (!s) return NB_ERR_INVALID;
     NB_HIP(s, hipSetDevice(s->device));
     if (int rc = finish_gather(s)) return rc;
     NB_HIP(s, hipStreamSynchronize(s->stream));
-    double f = 0, g = 0, x = 0;
-    uint32_t nx = 0;
+    double f = 0, red = 0, rs = 0, g = 0, x = 0, span = 0;
+    uint32_t nx = 0, nrs = 0;
     for (auto& ev : s->pending) {
-        float a = 0, b = 0, c = 0, d = 0;
-        NB_HIP(s, hipEventElapsedTime(&a, ev.e[0], ev.e[1]));
-        if (ev.two) NB_HIP(s, hipEventElapsedTime(&c, ev.e[3], ev.e[4]));   // own-row splits, [gather wait], remaining splits
+        float a = 0, b = 0, c = 0, d = 0, r1 = 0, r2 = 0, sp = 0;
+        if (ev.rs) {
+            // rank form: e0 force e7 nb_sym_reduce e1 reduce-scatter e6 integrate e2 [all-gather e5]
+            NB_HIP(s, hipEventElapsedTime(&a, ev.e[0], ev.e[7]));
+            NB_HIP(s, hipEventElapsedTime(&r1, ev.e[7], ev.e[1]));
+            NB_HIP(s, hipEventElapsedTime(&r2, ev.e[1], ev.e[6]));
+            ++nrs;
+        } else {
+            NB_HIP(s, hipEventElapsedTime(&a, ev.e[0], ev.e[1]));
+        }
+        if (ev.two) NB_HIP(s, hipEventElapsedTime(&c, ev.e[3], ev.e[4]));   // own-row work, [gather wait], the rest
         if (!s->fused) NB_HIP(s, hipEventElapsedTime(&b, ev.e[6], ev.e[2]));
         if (ev.xchg) { NB_HIP(s, hipEventElapsedTime(&d, ev.e[2], ev.e[5])); ++nx; }
-        f += a + c; g += b; x += d;
+        NB_HIP(s, hipEventElapsedTime(&sp, ev.e[0], ev.xchg ? ev.e[5] : s->fused ? ev.e[1] : ev.e[2]));
+        f += a + c; red += r1; rs += r2; g += b; x += d; span += sp;
     }
     const uint32_t cnt = (uint32_t)s->pending.size();
-    if (force_ms) *force_ms = cnt ? f / cnt : 0.0;
-    if (integrate_ms) *integrate_ms = cnt ? g / cnt : 0.0;
-    if (exchange_ms) *exchange_ms = nx ? x / nx : 0.0;
-    if (launches) *launches = cnt;
+    t->launches = cnt;
+    t->force_ms = cnt ? f / cnt : 0.0;
+    t->sym_reduce_ms = nrs ? red / nrs : 0.0;
+    t->reduce_scatter_ms = nrs ? rs / nrs : 0.0;
+    t->integrate_ms = cnt ? g / cnt : 0.0;
+    t->allgather_ms = nx ? x / nx : 0.0;
+    t->span_ms = cnt ? span / cnt : 0.0;
+    t->reduce_scatters = nrs;
+    t->allgathers = nx;
     s->pending.clear();
     s->pool_next = 0;
+    return NB_OK;
+}
+
+int nb_step_times2(nb_sim* s, nb_step_timing* out)
+{
+    if (!s) return NB_ERR_INVALID;
+    if (!out || out->struct_size < sizeof(nb_step_timing)) return fail(s, NB_ERR_INVALID, "nb_step_times2: set out->struct_size to sizeof(nb_step_timing)");
+    nb_step_timing t;
+    memset(&t, 0, sizeof t);
+    if (int rc = collect_times(s, &t)) return rc;
+    t.struct_size = out->struct_size;
+    memcpy(out, &t, sizeof t);
+    return NB_OK;
+}
+
+int nb_step_times(nb_sim* s, double* force_ms, double* integrate_ms, double* exchange_ms, uint32_t* launches)
+{
+    if (!s) return NB_ERR_INVALID;
+    nb_step_timing t;
+    memset(&t, 0, sizeof t);
+    if (int rc = collect_times(s, &t)) return rc;
+    if (force_ms) *force_ms = t.force_ms + t.sym_reduce_ms;        // the rank form's nb_sym_reduce counts as force work here
+    if (integrate_ms) *integrate_ms = t.integrate_ms;
+    if (exchange_ms) *exchange_ms = t.reduce_scatter_ms + t.allgather_ms;   // every native collective of a step
+    if (launches) *launches = t.launches;
     return NB_OK;
 }
 
@@ -1004,13 +1046,13 @@ int nb_diagnostics(nb_sim* s, double out[5])
     if (!s->uploaded) return fail(s, NB_ERR_STATE, "nb_diagnostics: nothing uploaded yet");
     NB_HIP(s, hipSetDevice(s->device));
     if (int rc = finish_gather(s)) return rc;
-    dim3 grid(s->diag_blocks), block(nb::kBlock);
+    dim3 grid(ceil_div(s->sc, nb::kDiagRows), ceil_div(s->n, s->diag_chunk)), block(nb::kBlock);
     if (s->f64)
         hipLaunchKernelGGL((nb::nb_diag<double>), grid, block, 0, s->stream, (const double4*)s->bodies[s->cur],
-                           (const double4*)s->vel, s->n, s->sb, s->sc, s->G, s->eps2, s->diag);
+                           (const double4*)s->vel, s->n, s->sb, s->sc, s->diag_chunk, s->G, s->eps2, s->diag);
     else
         hipLaunchKernelGGL((nb::nb_diag<float>), grid, block, 0, s->stream, (const float4*)s->bodies[s->cur],
-                           (const float4*)s->vel, s->n, s->sb, s->sc, s->G, s->eps2, s->diag);
+                           (const float4*)s->vel, s->n, s->sb, s->sc, s->diag_chunk, s->G, (float)s->eps2, s->diag);
     NB_HIP(s, hipGetLastError());
     std::vector<double> h((size_t)5 * s->diag_blocks);
     NB_HIP(s, hipMemcpyAsync(h.data(), s->diag, sizeof(double) * h.size(), hipMemcpyDeviceToHost, s->stream));

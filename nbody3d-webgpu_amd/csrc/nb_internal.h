@@ -16,7 +16,10 @@
 // e[0]..e[1]: force launch issued before a pending gather is waited for (or the only force
 // launch, or the whole fused step); e[3]..e[4]: force launch issued after it; e[6]..e[2]: integrate;
 // e[2]..e[5]: position exchange (RCCL all-gather on the engine stream; e[5] is a plain record).
-struct nb_events { hipEvent_t e[7]; bool two, xchg; };
+// Rank form of the symmetric pass (plain records on the engine stream): e[0] force pass e[7] nb_sym_reduce e[1]
+// ncclReduceScatter e[6] integrate e[2] ncclAllGather e[5]; with the overlapped gather the force pass is two launches,
+// e[0]..e[7] (own-row sweeps, issued before the wait) and e[3]..e[4] (the rest), and `rs` says the e[7]/e[1]/e[6] chain is valid.
+struct nb_events { hipEvent_t e[8]; bool two, xchg, rs; };
 
 struct nb_rccl;   // nb_comm.hip
 
@@ -58,7 +61,7 @@ struct nb_sim {
     void* partial = nullptr;
     double* diag = nullptr;
     void* zero_row = nullptr;      // 64 zero bytes (LDS-DMA source for j past the range)
-    uint32_t diag_blocks = 0;
+    uint32_t diag_blocks = 0, diag_chunk = 256;   // nb_diag: workgroups (row blocks x j-chunks), bodies per j-chunk
     double dt = 0.0, G = 0.0;
     bool params_set = false, uploaded = false;
     uint64_t steps_done = 0;
@@ -141,7 +144,7 @@ int rccl_exchange_begin(nb_sim* s);
 // rank form of the symmetric pass: in-place ncclReduceScatter of sym_A on the engine stream (this rank's rows receive the sum)
 int rccl_reduce_scatter_A(nb_sim* s);
 // the two halves of a rank-form step, for nb_multi (which runs its own reduce-scatter between them)
-int sym_rank_phase_a(nb_sim* s);     // force pass + nb_sym_reduce
+int sym_rank_phase_a(nb_sim* s, void* after_force = nullptr);     // force pass [+ a record of the hipEvent_t `after_force`] + nb_sym_reduce
 int sym_rank_phase_b(nb_sim* s);     // integrate kernel on the handle's rows of sym_A
 int rccl_exchange_wait(nb_sim* s);
 bool rccl_overlapped(const nb_sim* s);

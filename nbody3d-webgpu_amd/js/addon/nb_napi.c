@@ -52,6 +52,7 @@ static int (*p_multi_diagnostics)(nb_multi *, double *);
 static int (*p_multi_set_collective)(nb_multi *, int);
 static int (*p_multi_collective_info)(nb_multi *, int *, int *, int *);
 static int (*p_step_times)(nb_sim *, double *, double *, double *, uint32_t *);
+static int (*p_step_times2)(nb_sim *, nb_step_timing *);
 static int (*p_frame_request)(nb_sim *);
 static int (*p_frame_acquire)(nb_sim *, int, const float **, const float **, uint64_t *);
 static int (*p_plan_query)(const nb_config *, int, double, nb_plan_info *, uint32_t *, uint32_t);
@@ -128,7 +129,7 @@ static napi_value js_load(napi_env env, napi_callback_info info)
         SYM(p_multi_sync, "nb_multi_sync"); SYM(p_multi_last_error, "nb_multi_last_error");
         SYM(p_multi_variant_name, "nb_multi_variant_name"); SYM(p_multi_diagnostics, "nb_multi_diagnostics");
         SYM(p_multi_set_collective, "nb_multi_set_collective"); SYM(p_multi_collective_info, "nb_multi_collective_info");
-        SYM(p_step_times, "nb_step_times"); SYM(p_frame_request, "nb_frame_request"); SYM(p_frame_acquire, "nb_frame_acquire");
+        SYM(p_step_times, "nb_step_times"); SYM(p_step_times2, "nb_step_times2"); SYM(p_frame_request, "nb_frame_request"); SYM(p_frame_acquire, "nb_frame_acquire");
         SYM(p_plan_query, "nb_plan_query");
 #undef SYM
         g_lib = h;
@@ -466,18 +467,27 @@ static napi_value js_diagnostics(napi_env env, napi_callback_info info)
 }
 
 
-/* stepTimes(handle) -> {forceMs, integrateMs, exchangeMs, launches} */
+/* stepTimes(handle) -> {forceMs, integrateMs, exchangeMs, launches, symReduceMs, reduceScatterMs, allgatherMs, spanMs}
+ * (nb_step_times2; forceMs / exchangeMs keep nb_step_times's meaning: force pass + nb_sym_reduce, every native collective) */
 static napi_value js_step_times(napi_env env, napi_callback_info info)
 {
     size_t argc = 1; napi_value argv[1];
     CHECK_NAPI(env, napi_get_cb_info(env, info, &argc, argv, NULL, NULL));
     handle_t *h = argc ? get_handle(env, argv[0]) : NULL; if (!h) return NULL;
     if (h->multi) { napi_throw_error(env, "NB_1", "per-kernel timing is not available on a multi-device handle"); return NULL; }
-    double f, g, x; uint32_t c;
-    int rc = p_step_times(h->sim, &f, &g, &x, &c);
-    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_step_times");
+    nb_step_timing t;
+    memset(&t, 0, sizeof t);
+    t.struct_size = sizeof t;
+    int rc = p_step_times2(h->sim, &t);
+    if (rc != NB_OK) return throw_nb(env, rc, h->sim, "nb_step_times2");
+    const double f = t.force_ms + t.sym_reduce_ms, g = t.integrate_ms, x = t.reduce_scatter_ms + t.allgather_ms;
+    const uint32_t c = t.launches;
     napi_value o, v;
     CHECK_NAPI(env, napi_create_object(env, &o));
+    napi_create_double(env, t.sym_reduce_ms, &v); napi_set_named_property(env, o, "symReduceMs", v);
+    napi_create_double(env, t.reduce_scatter_ms, &v); napi_set_named_property(env, o, "reduceScatterMs", v);
+    napi_create_double(env, t.allgather_ms, &v); napi_set_named_property(env, o, "allgatherMs", v);
+    napi_create_double(env, t.span_ms, &v); napi_set_named_property(env, o, "spanMs", v);
     napi_create_double(env, f, &v); napi_set_named_property(env, o, "forceMs", v);
     napi_create_double(env, g, &v); napi_set_named_property(env, o, "integrateMs", v);
     napi_create_double(env, x, &v); napi_set_named_property(env, o, "exchangeMs", v);

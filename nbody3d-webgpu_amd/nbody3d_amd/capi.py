@@ -58,6 +58,12 @@ class nb_plan_info(C.Structure):
         ("sym_plan", C.c_uint32 * 11), ("tab_len", C.c_uint32), ("variant", C.c_char * 112)]
 
 
+class nb_step_timing(C.Structure):          # include/nbody3d_hip.h
+    _fields_ = [("struct_size", C.c_uint32), ("launches", C.c_uint32), ("force_ms", C.c_double), ("sym_reduce_ms", C.c_double),
+                ("reduce_scatter_ms", C.c_double), ("integrate_ms", C.c_double), ("allgather_ms", C.c_double),
+                ("span_ms", C.c_double), ("reduce_scatters", C.c_uint32), ("allgathers", C.c_uint32)]
+
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
 EXCHANGE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
@@ -70,7 +76,7 @@ SYMBOLS = ["nb_abi_version", "nb_device_count", "nb_create", "nb_destroy", "nb_u
            "nb_multi_download", "nb_multi_sync", "nb_multi_last_error", "nb_multi_variant_name",
            "nb_multi_diagnostics", "nb_multi_set_collective", "nb_multi_collective_info",
            "nb_rccl_unique_id", "nb_rccl_attach", "nb_rccl_detach", "nb_rccl_info",
-           "nb_step_times", "nb_integrate_pass", "nb_frame_request", "nb_frame_acquire", "nb_shape_info", "nb_plan_query"]
+           "nb_step_times", "nb_step_times2", "nb_integrate_pass", "nb_frame_request", "nb_frame_acquire", "nb_shape_info", "nb_plan_query"]
 
 _lib = None
 
@@ -130,6 +136,7 @@ def load_library():
     L.nb_rccl_info.argtypes = [vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.nb_step_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
                                 C.POINTER(C.c_uint32)]
+    L.nb_step_times2.argtypes = [vp, C.POINTER(nb_step_timing)]
     L.nb_integrate_pass.argtypes = [vp, C.c_uint32, C.POINTER(C.c_double)]
     L.nb_shape_info.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
     L.nb_plan_query.argtypes = [C.POINTER(nb_config), C.c_int, C.c_double, C.POINTER(nb_plan_info), C.POINTER(C.c_uint32), C.c_uint32]
@@ -361,6 +368,15 @@ class Simulation:
         f, g, x, c = C.c_double(), C.c_double(), C.c_double(), C.c_uint32()
         self._check(self._L.nb_step_times(self._h, C.byref(f), C.byref(g), C.byref(x), C.byref(c)))
         return f.value, g.value, x.value, c.value
+
+    def step_breakdown(self):
+        """The parts of a step as the engine stream runs them (nb_step_times2; averages in ms since the last call):
+        dict(launches, force_ms, sym_reduce_ms, reduce_scatter_ms, integrate_ms, allgather_ms, span_ms, reduce_scatters,
+        allgathers)."""
+        t = nb_step_timing()
+        t.struct_size = C.sizeof(nb_step_timing)
+        self._check(self._L.nb_step_times2(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in nb_step_timing._fields_ if k != "struct_size"}
 
     def integrate_pass(self, reps):
         """Average ms of the integrate kernel alone over ``reps`` launches (measurement only:

@@ -101,6 +101,15 @@ int main(int argc, char **argv)
     if (nb_enable_timing(sim, 1) != NB_OK || nb_step(sim, 4) != NB_OK || nb_step_times(sim, &f_ms, &i_ms, &x_ms, &launches) != NB_OK ||
         launches != 4 || !(f_ms > 0.0)) { printf("FAIL step times\n"); fails++; }
     else printf("ok step times: %u launches, force %.4f ms, integrate %.4f ms\n", launches, f_ms, i_ms);
+    /* the part-by-part form: on a whole-system handle only the force (and integrate) parts are non-zero */
+    nb_step_timing tm;
+    memset(&tm, 0, sizeof tm);
+    tm.struct_size = sizeof tm;
+    if (nb_step(sim, 2) != NB_OK || nb_step_times2(sim, &tm) != NB_OK || tm.launches != 2 || !(tm.force_ms > 0.0) ||
+        tm.reduce_scatters != 0 || tm.allgathers != 0 || !(tm.span_ms >= tm.force_ms + tm.integrate_ms - 1e-9)) { printf("FAIL step times2\n"); fails++; }
+    else printf("ok step times2: force %.4f + integrate %.4f ms inside a span of %.4f ms\n", tm.force_ms, tm.integrate_ms, tm.span_ms);
+    tm.struct_size = 4;
+    if (nb_step_times2(sim, &tm) != NB_ERR_INVALID) { printf("FAIL step times2 accepts a short struct\n"); fails++; }
     nb_destroy(sim);
 
     /* native RCCL collective with one rank: a shard handle that owns every row */

@@ -36,3 +36,29 @@ def test_bench_emits_one_well_formed_json_line():
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
     assert d["check"]["pass"] is True and d["check"]["max_rel_pos_err_vs_f64_oracle"] < 1e-4
+
+
+def test_force_dist_line_reports_both_protocols_and_a_breakdown_that_adds_up():
+    """The N>1 code path on one rank (--force-dist: the process group, the native RCCL communicator, the in-place
+    ncclReduceScatter and ncclAllGather all really run): the line names the protocol that ran, times BOTH collectives
+    (nb_step_times2), its per-rank parts add up to the step, and the north_star-literal protocol (i-shard + all-gather,
+    NB_FLAG_NO_SYM) is measured by the same launch under `also`."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-dist", "--nbodies", "65536", "--steps", "10", "--warmup", "3",
+                        "--no-cpu-baseline", "--no-check"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["value"] and d["config"]["parallelism"] == "pairshard1+reducescatter+allgather", d["config"]
+    assert "symwrank" in d["config"]["kernel_variant"]
+    x = d["exchange"]
+    assert x["reduce_scatter_ms"] > 0 and x["allgather_ms"] > 0 and abs(x["avg_ms"] - x["reduce_scatter_ms"] - x["allgather_ms"]) < 1e-9
+    assert x["allgather_bytes_sent_per_rank"] == 65536 * 16 and x["reduce_scatter_bytes_sent_per_rank"] == 0      # one rank: nothing leaves it
+    r = d["per_rank"]
+    parts = [r[k] for k in ("force_kernel_avg_ms", "sym_reduce_kernel_avg_ms", "reduce_scatter_avg_ms", "integrate_kernel_avg_ms", "allgather_avg_ms")]
+    assert all(v > 0 for v in parts) and abs(sum(parts) - r["sum_of_parts_ms"]) < 1e-9
+    assert r["sum_of_parts_ms"] <= r["span_ms"] * 1.001
+    assert 0.97 <= r["sum_of_parts_over_ms_per_step"] <= 1.03, r
+    lit = d["also"][0]
+    assert lit["pass"] and lit["value"] > 0 and lit["config"]["parallelism"] == "ishard1+allgather", lit["config"]
+    assert "sym" not in lit["config"]["kernel_variant"]
+    assert lit["exchange"]["allgather_ms"] > 0 and lit["exchange"]["reduce_scatter_ms"] is None
+    assert 0.97 <= lit["per_rank"]["sum_of_parts_over_ms_per_step"] <= 1.03, lit["per_rank"]

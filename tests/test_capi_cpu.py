@@ -13,7 +13,7 @@ from nbody3d_amd import capi
 def header_symbols():
     src = open(os.path.join(ROOT, "include", "nbody3d_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(nb_[a-z_]+)\s*\(", src)) - {"nb_exchange_fn"})
+    return sorted(set(re.findall(r"\b(nb_[a-z0-9_]+)\s*\(", src)) - {"nb_exchange_fn"})
 
 
 def test_library_exports_every_declared_symbol():

@@ -267,9 +267,21 @@ def test_rank_form_with_one_rank_equals_the_whole_system_form():
             sim.rccl_attach(capi.rccl_unique_id(), 1, 0)
             sim.enable_timing(True)
             sim.simulate(steps, 1e-3, G)
-            f_ms, i_ms, x_ms, launches = sim.step_times()
+            t = sim.step_breakdown()                         # nb_step_times2: every part of the rank-form step, the reduce-scatter included
             got = sim.read()
-            assert launches == steps and f_ms > 0 and i_ms > 0 and x_ms > 0
+            assert t["launches"] == steps and t["reduce_scatters"] == steps and t["allgathers"] == steps, t
+            parts = [t[k] for k in ("force_ms", "sym_reduce_ms", "reduce_scatter_ms", "integrate_ms", "allgather_ms")]
+            assert all(p > 0 for p in parts), t
+            assert 0.6 * t["span_ms"] < sum(parts) <= 1.001 * t["span_ms"], t      # the parts are back to back on the engine stream
+            sim.simulate(2, 1e-3, G)
+            f_ms, i_ms, x_ms, launches = sim.step_times()    # the four-number form folds them: force + sym_reduce, both collectives
+            assert launches == 2 and f_ms > 0 and i_ms > 0 and x_ms > 0
+            sim.enable_timing(False)
+        with Simulation(n, shard=(0, n), jsplit=1, flags=capi.NB_FLAG_SYM_SHARD) as sim:       # the state the comparisons below use: `steps` steps
+            sim.init(b, v)
+            sim.rccl_attach(capi.rccl_unique_id(), 1, 0)
+            sim.simulate(steps, 1e-3, G)
+            got = sim.read()
         assert rel_pos_err(got[0], ref[0], 1.0) < 1e-6, G
         assert np.abs(got[2][:, :3] - ref[2][:, :3]).max() < 2e-6 * np.abs(ref[2][:, :3]).max(), G
         rb, _, ra = oracle.run_f64(b, v, None, 1e-3, G, steps)
