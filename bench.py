@@ -108,7 +108,7 @@ def _k2_bytes_per_body(variant_name):
     """Bytes the integrate kernel moves per body: the algorithmic 96 plus the partial sums it adds up --
     16 B per j-split of the ordered-pair kernels, 12 B per resident / traveler layer of the symmetric pass."""
     import re
-    m = re.search(r"_r(\d+)t(\d+)$", variant_name)
+    m = re.search(r"_r(\d+)t(\d+)(?:_u\d+)?$", variant_name)
     if "sym" in variant_name and m:
         return 96.0 + 12.0 * (int(m.group(1)) + int(m.group(2)))
     js = _jsplit(variant_name)

@@ -82,6 +82,10 @@ typedef enum nb_precision { NB_F32 = 0, NB_F64 = 1 } nb_precision;
                                   handle until a communicator is attached.  Needs shard rows that are whole super-blocks
                                   (shard_begin, shard_count and n multiples of 1,024, or of 512); ignored otherwise */
 
+#define NB_FLAG_WHOLE_SWEEPS 256u /* tuning/A-B: the symmetric pass cuts its wave ranges at whole chunk-sweeps (64 rotation steps), as in
+                                   ABI 2.0; by default systems with few sweeps per wave cut them in quarter sweeps (variant suffix
+                                   "_u4"), which evens out the SIMDs' work (N = 16,384: the longest SIMD runs 4.25 sweeps instead of 5) */
+
 /* nb_array: selector for nb_device_ptr */
 typedef enum nb_array { NB_BODIES = 0, NB_VEL = 1, NB_ACCEL = 2 } nb_array;
 
@@ -127,7 +131,8 @@ typedef struct nb_config {
                                splits j over workgroups too (reduced in the same launch).
                                K = 7: the symmetric force pass (whole-system f32 handles): every unordered pair is
                                evaluated once and both accelerations accumulated; II = resident bodies per lane (08
-                               or 16), LL = 01, X = 3 / 1: wave-granular form with 1 / 2 traveling bodies per lane
+                               or 16), LL = 01 (02 / 04 / 08: wave ranges cut in half / quarter / eighth sweeps whatever the size),
+                               X = 3 / 1: wave-granular form with 1 / 2 traveling bodies per lane
                                (jsplit = waves per SIMD), X = 4: workgroup form (II = 08; jsplit = segments per
                                super-block).  E.g. 716013.
                                See nb_variant_name().                              */
@@ -336,7 +341,9 @@ int nb_shape_info(nb_sim *s, uint32_t *jsplit, uint32_t *j_per_split, uint32_t *
  *                      plan words the kernels receive (nb::SymWPlan: np, nsb, W, total_hi, total_lo, n_hi, H, r_layer0,
  *                      t_layer0, L, p0; workgroup form nb::SymPlan: np, nsb, q, total_hi, total_lo, n_hi, H, r_layer0, t_layer0)
  *   tab                (caller's array of tab_cap words, may be NULL) first wave and wave count of every super-block's
- *                      list, 2 * nsb words; tab_len reports how many there are */
+ *                      list, 2 * nsb words; with sym_ups > 1 followed by the spill lists -- {offset, count} per traveler
+ *                      chunk (2 * sym_np / 64 words), then the wave numbers; tab_len reports how many words there are
+ *   sym_ups            work units per chunk-sweep: the wave ranges are floor/ceil-equal in units of 64 / sym_ups rotation steps */
 typedef struct nb_plan_info {
   uint32_t struct_size; /* sizeof(nb_plan_info), set by the caller */
   uint32_t kind, ipl, ls, x;
@@ -345,6 +352,8 @@ typedef struct nb_plan_info {
   uint32_t sym_plan[11];
   uint32_t tab_len;
   char variant[112];
+  uint32_t sym_ups;        /* wave-granular symmetric pass: work units per chunk-sweep (1: whole sweeps; 4: quarter sweeps) */
+  uint32_t sym_spill_rows; /* rows of the spill buffer (one row set per wave; 0 with whole sweeps) */
 } nb_plan_info;
 int nb_plan_query(const nb_config *cfg, int n_cu, double clock_hz, nb_plan_info *out, uint32_t *tab,
                   uint32_t tab_cap);

@@ -66,6 +66,14 @@ __device__ __forceinline__ double4 ld4(const double4* p)
 typedef float nb_v3f __attribute__((ext_vector_type(3)));
 __device__ __forceinline__ nb_v3f ld3(const float4* p) { return *reinterpret_cast<const nb_v3f*>(p); }
 
+// v_rsq_f32 in its 64-bit (VOP3) encoding.  On gfx950 a 64-bit instruction that does not start on an 8-byte boundary issues more
+// slowly (profiles/r04/README.md "instruction alignment": the symmetric pass's loop +12 % at one wave per SIMD, +5 % at two), the
+// hot loops are all packed-f32 / DPP instructions (64-bit encodings), and a 32-bit v_rsq_f32_e32 among them flips the parity of
+// everything behind it.  An |x| source modifier needs the VOP3 form, so the compiler emits v_rsq_f32_e64 -- still ITS instruction
+// (it keeps the wait state gfx950 wants between a transcendental and a reader of its result; an asm statement would not get it).
+// The argument is a cube of r^2 + eps2 > 0: |x| = x, the value is bit for bit v_rsq_f32(x).
+__device__ __forceinline__ float nb_rsq(float x) { return __builtin_amdgcn_rsqf(__builtin_fabsf(x)); }
+
 __device__ __forceinline__ float nb_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 __device__ __forceinline__ double nb_fma(double a, double b, double c) { return __builtin_fma(a, b, c); }
 

@@ -198,7 +198,7 @@ void nb_step_jpk(const float4* __restrict__ bodies_in, const float4* __restrict_
 #pragma unroll
         for (int c = 0; c < 4; ++c) r[c] = r[c] * d2[c];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+        for (int c = 0; c < 4; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
 #pragma unroll
         for (int c = 0; c < 4; ++c) r[c] = nb_f2{p[c][6], p[c][7]} * r[c];
         // ascending pairs; the even- and odd-j sums of the lane are added after the loop

@@ -240,7 +240,7 @@ struct PkCore {
 #pragma unroll
             for (int c = 0; c < NC; ++c) {
                 if constexpr (NG == 1) r[c] = rsq_ordered(r[c]);
-                else r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+                else r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
             }
             // m_j * inv.  One i-pair per lane: the explicit high-half broadcast (no v_mov for the mass; -2..-3.4 % per
             // step from N = 3,000 to 10,000).  More pairs per lane: the plain product -- the v_mov is 1 instruction in
@@ -500,7 +500,7 @@ void nb_step_direct(const float4* __restrict__ bodies_in, const float4* __restri
 #pragma unroll
             for (int c = 0; c < 4; ++c) r[c] = r[c] * d2[c];
 #pragma unroll
-            for (int c = 0; c < 4; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+            for (int c = 0; c < 4; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
 #pragma unroll
             for (int c = 0; c < 4; ++c) r[c] = bm[c] * r[c];
 #pragma unroll
@@ -628,7 +628,7 @@ void nb_force_pk_sgpr(const float4* __restrict__ bodies, float4* __restrict__ pa
 #pragma unroll
             for (int c = 0; c < NG; ++c) r[c] = r[c] * d2[c];
 #pragma unroll
-            for (int c = 0; c < NG; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+            for (int c = 0; c < NG; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
 #pragma unroll
             for (int c = 0; c < NG; ++c) r[c] = bm * r[c];
 #pragma unroll

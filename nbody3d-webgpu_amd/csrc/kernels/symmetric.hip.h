@@ -113,7 +113,7 @@ void nb_force_sym(const float4* __restrict__ bodies, SymRow* __restrict__ partia
 #pragma unroll
                     for (int c = 0; c < 4; ++c) r[c] = r[c] * d2[c];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+                    for (int c = 0; c < 4; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
 #pragma unroll
                     for (int c = 0; c < 4; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
 #pragma unroll
@@ -190,7 +190,7 @@ void nb_force_sym(const float4* __restrict__ bodies, SymRow* __restrict__ partia
 template <int NG, int J>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : (NG < 4 ? 8 : 4))))
 void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ partial, const uint32_t* __restrict__ gtab, const SymWPlan pl,
-                   const uint32_t n, const float eps2)
+                   const uint32_t n, const float eps2, SymRow* __restrict__ spill)
 {
     constexpr uint32_t S = 128u * NG;          // rows per super-block = one wave's residents
     constexpr int GW = NG < 4 ? NG : 4;        // packed groups evaluated stage-major together
@@ -199,20 +199,26 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));     // the four waves of a workgroup are independent
     if (w >= pl.W) return;
-    uint32_t p = pl.p0 + (uint32_t)(((uint64_t)w * pl.L) / pl.W);
-    const uint32_t pend = pl.p0 + (uint32_t)(((uint64_t)(w + 1) * pl.L) / pl.W);
+    // The wave's range, in UNITS of 64 / ups rotation steps (ups units per chunk-sweep), relative to the handle's part of the list.
+    // With ups > 1 a sweep may be shared by consecutive waves: each runs its own rotation steps [s0, s1) of it, starting from
+    // travelers loaded s0 lanes ahead (wave_ror:1 moves a traveler from lane l to lane l + 1, so after s steps lane l holds the
+    // traveler that started in lane l - s).
+    const uint32_t ups = pl.ups, ustep = 64u / ups;
+    const uint64_t Lu = (uint64_t)pl.L * ups;
+    uint32_t u = (uint32_t)(((uint64_t)w * Lu) / pl.W);
+    const uint32_t uend = (uint32_t)(((uint64_t)(w + 1) * Lu) / pl.W);
     const nb_f2 e2 = nb_f2{eps2, eps2};
     const uint32_t first_lo = pl.n_hi * pl.total_hi;
 
-    while (p < pend) {
-        // which super-block's list p lies in, and where
+    while (u < uend) {
+        // which super-block's list the unit lies in, and where
+        const uint32_t ps = u / ups, p = pl.p0 + ps;                 // the sweep: relative to the handle's range / in the global list
         uint32_t g, k, total;
         if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
         else { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
         const uint32_t ring = total - CPS;                           // symmetric chunks of g; CPS resident-only chunks follow
-        uint32_t kend = k + (pend - p);
-        if (kend > total) kend = total;
-        p += kend - k;
+        uint32_t ug_end = (ps - k + total) * ups;                    // end of g's list, in units
+        if (ug_end > uend) ug_end = uend;
 
         nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
         {
@@ -224,25 +230,35 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
                 ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
             }
         }
-        for (; k < kend; ++k) {
+        while (u < ug_end) {
+            // the wave's steps [s0, s1) of sweep k
+            const uint32_t q0 = u % ups;
+            uint32_t nun = ups - q0;
+            if (nun > ug_end - u) nun = ug_end - u;
+            const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
+            u += nun;
             const bool sym = k < ring;
             const uint32_t d = k / CPS;                              // ring distance - 1 (symmetric chunks)
             uint32_t tb = g + 1 + d;
             if (tb >= pl.nsb) tb -= pl.nsb;
             const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
+            ++k;
             if (tstart >= n) continue;   // a chunk of padding rows only (zero mass): exerts nothing, and nobody reads its sums
             float tx[J], ty[J], tz[J], tm[J];
             nb_f2 bx[J], by[J], bz[J];
+            const uint32_t src = ((uint32_t)lane - s0) & 63u;        // the traveler this lane holds after s0 rotation steps
 #pragma unroll
-            for (int u = 0; u < J; ++u) {
-                const float4 t = ld4(bodies + tstart + u * 64 + lane);
-                tx[u] = t.x; ty[u] = t.y; tz[u] = t.z; tm[u] = t.w;
-                bx[u] = nb_f2{0, 0}; by[u] = nb_f2{0, 0}; bz[u] = nb_f2{0, 0};
+            for (int uu = 0; uu < J; ++uu) {
+                const float4 t = ld4(bodies + tstart + uu * 64 + src);
+                tx[uu] = t.x; ty[uu] = t.y; tz[uu] = t.z; tm[uu] = t.w;
+                bx[uu] = nb_f2{0, 0}; by[uu] = nb_f2{0, 0}; bz[uu] = nb_f2{0, 0};
             }
-            for (int st = 0; st < 64; ++st) {
+            // (the loop head is 8-byte aligned by -falign-loops=8: a packed instruction that straddles an 8-byte boundary issues
+            // more slowly -- 12 % on this loop at one wave per SIMD, profiles/r04/README.md)
+            for (uint32_t st = s0; st < s1; ++st) {
 #pragma unroll
-                for (int u = 0; u < J; ++u) {
-                    const nb_f2 px = nb_f2{tx[u], tx[u]}, py = nb_f2{ty[u], ty[u]}, pz = nb_f2{tz[u], tz[u]}, pm = nb_f2{tm[u], tm[u]};
+                for (int uu = 0; uu < J; ++uu) {
+                    const nb_f2 px = nb_f2{tx[uu], tx[uu]}, py = nb_f2{ty[uu], ty[uu]}, pz = nb_f2{tz[uu], tz[uu]}, pm = nb_f2{tm[uu], tm[uu]};
 #pragma unroll
                     for (int c0g = 0; c0g < NG; c0g += GW) {         // stage-major over groups of (up to) four
                         nb_f2 dx[GW], dy[GW], dz[GW], d2[GW], r[GW], si[GW], sj[GW];
@@ -263,7 +279,7 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
 #pragma unroll
                         for (int c = 0; c < GW; ++c) r[c] = r[c] * d2[c];
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) r[c] = nb_f2{__builtin_amdgcn_rsqf(r[c].x), __builtin_amdgcn_rsqf(r[c].y)};
+                        for (int c = 0; c < GW; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
 #pragma unroll
                         for (int c = 0; c < GW; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
 #pragma unroll
@@ -275,25 +291,27 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
 #pragma unroll
                         for (int c = 0; c < GW; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) bx[u] = __builtin_elementwise_fma(-sj[c], dx[c], bx[u]);   // x_i - x_t = -(x_t - x_i), exactly
+                        for (int c = 0; c < GW; ++c) bx[uu] = __builtin_elementwise_fma(-sj[c], dx[c], bx[uu]);   // x_i - x_t = -(x_t - x_i), exactly
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) by[u] = __builtin_elementwise_fma(-sj[c], dy[c], by[u]);
+                        for (int c = 0; c < GW; ++c) by[uu] = __builtin_elementwise_fma(-sj[c], dy[c], by[uu]);
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) bz[u] = __builtin_elementwise_fma(-sj[c], dz[c], bz[u]);
+                        for (int c = 0; c < GW; ++c) bz[uu] = __builtin_elementwise_fma(-sj[c], dz[c], bz[uu]);
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < J; ++u) {                        // the travelers and their sums move on by one lane
-                    tx[u] = wave_rot1(tx[u]); ty[u] = wave_rot1(ty[u]); tz[u] = wave_rot1(tz[u]); tm[u] = wave_rot1(tm[u]);
-                    bx[u] = nb_f2{wave_rot1(bx[u].x), wave_rot1(bx[u].y)};
-                    by[u] = nb_f2{wave_rot1(by[u].x), wave_rot1(by[u].y)};
-                    bz[u] = nb_f2{wave_rot1(bz[u].x), wave_rot1(bz[u].y)};
+                for (int uu = 0; uu < J; ++uu) {                     // the travelers and their sums move on by one lane
+                    tx[uu] = wave_rot1(tx[uu]); ty[uu] = wave_rot1(ty[uu]); tz[uu] = wave_rot1(tz[uu]); tm[uu] = wave_rot1(tm[uu]);
+                    bx[uu] = nb_f2{wave_rot1(bx[uu].x), wave_rot1(bx[uu].y)};
+                    by[uu] = nb_f2{wave_rot1(by[uu].x), wave_rot1(by[uu].y)};
+                    bz[uu] = nb_f2{wave_rot1(bz[uu].x), wave_rot1(bz[uu].y)};
                 }
             }
             if (sym) {
-                SymRow* out = partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart + lane;
+                // the sums of steps [s0, s1) sit s1 lanes past their travelers' home lanes.  The part that starts the sweep owns the
+                // sweep's traveler layer; any later part goes to the wave's own spill row (K2 adds it: the chunk's spill list)
+                SymRow* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)w * CH) + (((uint32_t)lane - s1) & 63u);
 #pragma unroll
-                for (int u = 0; u < J; ++u) out[u * 64] = SymRow{bx[u].x + bx[u].y, by[u].x + by[u].y, bz[u].x + bz[u].y};
+                for (int uu = 0; uu < J; ++uu) out[uu * 64] = SymRow{bx[uu].x + bx[uu].y, by[uu].x + by[uu].y, bz[uu].x + bz[uu].y};
             }
         }
         // resident sums of this wave's part of g's list
@@ -322,24 +340,26 @@ __device__ __forceinline__ double wave_rot1(double v)
 template <int IPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __restrict__ partial, const uint32_t* __restrict__ gtab,
-                     const SymWPlan pl, const uint32_t n, const double G, const double eps2)
+                     const SymWPlan pl, const uint32_t n, const double G, const double eps2, SymRowT<double>* __restrict__ spill)
 {
     constexpr uint32_t S = 64u * IPL, CH = 64u, CPS = S / CH;
     constexpr int GW = 4;                      // residents evaluated stage-major together
     const int lane = threadIdx.x & 63;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
     if (w >= pl.W) return;
-    uint32_t p = pl.p0 + (uint32_t)(((uint64_t)w * pl.L) / pl.W);
-    const uint32_t pend = pl.p0 + (uint32_t)(((uint64_t)(w + 1) * pl.L) / pl.W);
+    const uint32_t ups = pl.ups, ustep = 64u / ups;          // wave ranges in units of 64 / ups rotation steps: see nb_force_symw
+    const uint64_t Lu = (uint64_t)pl.L * ups;
+    uint32_t u = (uint32_t)(((uint64_t)w * Lu) / pl.W);
+    const uint32_t uend = (uint32_t)(((uint64_t)(w + 1) * Lu) / pl.W);
     const uint32_t first_lo = pl.n_hi * pl.total_hi;
-    while (p < pend) {
+    while (u < uend) {
+        const uint32_t ps = u / ups, p = pl.p0 + ps;
         uint32_t g, k, total;
         if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
         else { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
         const uint32_t ring = total - CPS;
-        uint32_t kend = k + (pend - p);
-        if (kend > total) kend = total;
-        p += kend - k;
+        uint32_t ug_end = (ps - k + total) * ups;
+        if (ug_end > uend) ug_end = uend;
         double xi[IPL], yi[IPL], zi[IPL], mi[IPL], ax[IPL], ay[IPL], az[IPL];
 #pragma unroll
         for (int c = 0; c < IPL; ++c) {
@@ -347,19 +367,25 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
             xi[c] = b.x; yi[c] = b.y; zi[c] = b.z; mi[c] = b.w * G;
             ax[c] = 0; ay[c] = 0; az[c] = 0;
         }
-        for (; k < kend; ++k) {
+        while (u < ug_end) {
+            const uint32_t q0 = u % ups;
+            uint32_t nun = ups - q0;
+            if (nun > ug_end - u) nun = ug_end - u;
+            const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
+            u += nun;
             const bool sym = k < ring;
             const uint32_t d = k / CPS;
             uint32_t tb = g + 1 + d;
             if (tb >= pl.nsb) tb -= pl.nsb;
             const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
+            ++k;
             if (tstart >= n) continue;
-            const double4 t = ld4(bodies + tstart + lane);
+            const double4 t = ld4(bodies + tstart + (((uint32_t)lane - s0) & 63u));
             double tx = t.x, ty = t.y, tz = t.z, tm = t.w * G, bx = 0, by = 0, bz = 0;
-            for (int st = 0; st < 64; ++st) {
+            for (uint32_t st = s0; st < s1; ++st) {
 #pragma unroll
                 for (int c0g = 0; c0g < IPL; c0g += GW) {            // stage-major over four residents
-                    double dx[GW], dy[GW], dz[GW], d2[GW], y[GW], u[GW];
+                    double dx[GW], dy[GW], dz[GW], d2[GW], y[GW], uu[GW];
 #pragma unroll
                     for (int c = 0; c < GW; ++c) dx[c] = tx - xi[c0g + c];
 #pragma unroll
@@ -375,11 +401,11 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
                         const double y2 = y[c] * y[c];
                         const double e = nb_fma(-d2[c], y2, 1.0);
                         const double t3 = y[c] * y2;
-                        u[c] = nb_fma(t3 * e, 1.5, t3);
+                        uu[c] = nb_fma(t3 * e, 1.5, t3);
                     }
 #pragma unroll
                     for (int c = 0; c < GW; ++c) {
-                        const double si = tm * u[c], sj = mi[c0g + c] * u[c];
+                        const double si = tm * uu[c], sj = mi[c0g + c] * uu[c];
                         ax[c0g + c] = nb_fma(si, dx[c], ax[c0g + c]); ay[c0g + c] = nb_fma(si, dy[c], ay[c0g + c]); az[c0g + c] = nb_fma(si, dz[c], az[c0g + c]);
                         bx = nb_fma(-sj, dx[c], bx); by = nb_fma(-sj, dy[c], by); bz = nb_fma(-sj, dz[c], bz);
                     }
@@ -387,7 +413,10 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
                 tx = wave_rot1(tx); ty = wave_rot1(ty); tz = wave_rot1(tz); tm = wave_rot1(tm);
                 bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz);
             }
-            if (sym) partial[(size_t)(pl.t_layer0 + d) * pl.np + tstart + lane] = SymRowT<double>{bx, by, bz};
+            if (sym) {
+                SymRowT<double>* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)w * CH) + (((uint32_t)lane - s1) & 63u);
+                *out = SymRowT<double>{bx, by, bz};
+            }
         }
         SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + (w - gtab[2 * g])) * pl.np + (size_t)g * S + lane;
 #pragma unroll
@@ -481,12 +510,15 @@ __global__ __launch_bounds__(kBlock) void nb_peer_gather(const PeerPtrs src, typ
     dst[idx] = ld4((const V4*)src.p[d] + idx);
 }
 
-// K2 for the wave-granular form: resident layers gtab[2g+1] (waves that worked on g's list), then the traveler layers.
+// K2 for the wave-granular form: resident layers gtab[2g+1] (waves that worked on g's list), then the traveler layers, then (wave
+// ranges cut inside sweeps, pl.ups > 1) the spill rows of the waves that ran a later part of a sweep over the body's chunk:
+// {offset, count} per chunk of CH rows at gtab[2 nsb + 2 chunk], wave numbers from gtab[2 nsb + 2 np / CH] on.  Fixed order.
 template <typename T, int R>
 __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::type* __restrict__ bodies, typename vec4<T>::type* __restrict__ vel,
                                                            typename vec4<T>::type* __restrict__ acc, const SymRowT<T>* __restrict__ partial,
                                                            const uint32_t* __restrict__ gtab, uint32_t n, const SymWPlan pl, uint32_t S, T dt,
-                                                           typename vec4<T>::type* __restrict__ gout, T G)
+                                                           typename vec4<T>::type* __restrict__ gout, T G, const SymRowT<T>* __restrict__ spill,
+                                                           uint32_t ch_shift /* log2 of the travelers per chunk */)
 {
     using V4 = typename vec4<T>::type;
     const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
@@ -497,8 +529,20 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::ty
         const uint32_t b = il / S;
         const uint32_t nr = gtab[2 * b + 1];
         const uint32_t nt = pl.H + ((pl.n_hi && b >= pl.n_hi) ? 1u : 0u);
-        const uint32_t total = nr + nt;
-        auto row = [&](uint32_t e) { return partial + (size_t)(e < nr ? pl.r_layer0 + e : pl.t_layer0 + (e - nr)) * pl.np + il; };
+        uint32_t ns = 0;
+        const uint32_t* ids = nullptr;
+        const uint32_t ci = il >> ch_shift;
+        if (pl.ups > 1) {
+            const uint32_t* ent = gtab + 2 * pl.nsb + 2 * ci;
+            ns = ent[1];
+            ids = gtab + 2 * pl.nsb + 2 * (pl.np >> ch_shift) + ent[0];
+        }
+        const uint32_t total = nr + nt + ns;
+        auto row = [&](uint32_t e) {
+            if (e < nr) return partial + (size_t)(pl.r_layer0 + e) * pl.np + il;
+            if (e < nr + nt) return partial + (size_t)(pl.t_layer0 + (e - nr)) * pl.np + il;
+            return spill + (((size_t)ids[e - nr - nt] << ch_shift) + (il - (ci << ch_shift)));
+        };
         uint32_t e = r;
         for (; e + 3 * R < total; e += 4 * R) {
             const SymRowT<T> p0 = *row(e), p1 = *row(e + R), p2 = *row(e + 2 * R), p3 = *row(e + 3 * R);

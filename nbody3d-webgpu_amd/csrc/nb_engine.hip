@@ -174,6 +174,7 @@ void plan_handle(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz, dou
     static_assert(sizeof(s->sym_plan) == sizeof(p.sym_plan), "nb_sim::sym_plan mirrors LaunchPlan::sym_plan");
     memcpy(s->sym_plan, p.sym_plan, sizeof s->sym_plan);
     s->sym_tab_host = std::move(p.sym_tab_host);
+    s->sym_spill_rows = p.sym_spill_rows;
     s->variant = std::move(p.variant);
 }
 
@@ -236,13 +237,14 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
         void* p = s->partial;
         const uint32_t* tab = s->sym_tab;
         uint32_t n = s->n;
+        void* sp = s->sym_spill;                           // one row set per wave (wave ranges cut inside sweeps); null with whole sweeps
         if (s->f64) {
             double G = s->G, e2 = s->eps2;
-            void* args[] = {&b, &p, &tab, &pl, &n, &G, &e2};
+            void* args[] = {&b, &p, &tab, &pl, &n, &G, &e2, &sp};
             launch_kernel(kernel_of(true, sh), dim3(ceil_div(pl.W, 4u)), dim3(256), args, s->stream, t0, t1);
         } else {
             float e2 = (float)s->eps2;
-            void* args[] = {&b, &p, &tab, &pl, &n, &e2};
+            void* args[] = {&b, &p, &tab, &pl, &n, &e2, &sp};
             launch_kernel(kernel_of(false, sh), dim3(ceil_div(pl.W, 4u)), dim3(256), args, s->stream, t0, t1);
         }
         return;
@@ -335,8 +337,9 @@ void launch_integrate(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullpt
         V4* aa = (V4*)s->acc;
         const nb::SymRowT<T>* pp = (const nb::SymRowT<T>*)s->partial;
         const uint32_t* tab = s->sym_tab;
-        uint32_t n = s->n, S = ipb_of(shape_of(s));
-        void* args[] = {&b, &v, &aa, &pp, &tab, &n, &pl, &S, &dt, &gout, &G};
+        uint32_t n = s->n, S = ipb_of(shape_of(s)), ch_shift = s->ws == 3 ? 6u : 7u;      // travelers per chunk: X = 3 one per lane (64), X = 1 two (128)
+        const void* sp = s->sym_spill;
+        void* args[] = {&b, &v, &aa, &pp, &tab, &n, &pl, &S, &dt, &gout, &G, &sp, &ch_shift};
         launch_kernel((const void*)&nb::nb_integrate_symw<T, 8>, dim3(ceil_div(n * 8u, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
         return;
     }
@@ -621,16 +624,31 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     }
     NB_HIPC(hipMalloc(&s->vel, row * s->sc));
     NB_HIPC(hipMalloc(&s->acc, row * s->sc));
+    // `partial` is allocated exactly ONCE, with the size the handle's own kernels index (round 3's memory fault: an if / else-if
+    // split allocated it a second time with the ordered-pair size -- 16 n q = 8.4 MB at N = 32,768, q = 16 -- under a
+    // symmetric handle that needed 12 np (q + H + 1) = 9.4 MB; profiles/r03/README.md)
+    auto alloc_partial = [&](size_t bytes) -> hipError_t {
+        if (s->partial) return hipErrorInvalidValue;
+        s->partial_bytes = bytes;
+        return hipMalloc(&s->partial, bytes);
+    };
     if (s->sym) {
-        NB_HIPC(hipMalloc(&s->partial, (size_t)3 * s->esz * s->sym_np * s->sym_layers));       // layers of (x, y, z) rows: 12 bytes (24 in f64)
+        NB_HIPC(alloc_partial((size_t)3 * s->esz * s->sym_np * s->sym_layers));       // layers of (x, y, z) rows: 12 bytes (24 in f64)
         if (s->sym_rank) NB_HIPC(hipMalloc(&s->sym_A, 4 * s->esz * s->sym_np));
+        if (s->sym_spill_rows) {
+            // zeroed once: a wave that never spills (its range starts at a sweep boundary) leaves its row alone, and nobody reads it
+            NB_HIPC(hipMalloc(&s->sym_spill, (size_t)3 * s->esz * s->sym_spill_rows));
+            NB_HIPC(hipMemset(s->sym_spill, 0, (size_t)3 * s->esz * s->sym_spill_rows));
+        }
         if (s->symw) {
             NB_HIPC(hipMalloc((void**)&s->sym_tab, sizeof(uint32_t) * s->sym_tab_host.size()));
             NB_HIPC(hipMemcpy(s->sym_tab, s->sym_tab_host.data(), sizeof(uint32_t) * s->sym_tab_host.size(), hipMemcpyHostToDevice));
         }
     } else if (!s->fused) {
-        NB_HIPC(hipMalloc(&s->partial, row * s->sc * s->jsplit));
+        NB_HIPC(alloc_partial(row * s->sc * s->jsplit));
     }
+    if (s->partial_bytes != (s->sym ? (size_t)3 * s->esz * s->sym_np * s->sym_layers : s->fused ? (size_t)0 : row * s->sc * s->jsplit))
+        return bail(NB_ERR_STATE, "nb_create: the partial-sum buffer does not have the size this handle's kernels index");
     if (s->jpk) {
         // pairs: whole 4-pair units (128 B) plus one spare the loop's last request may touch; everything past the
         // system stays zero (zero-mass bodies at the origin).  Partials: 64 rows per (split, i-block).
@@ -681,6 +699,7 @@ void nb_destroy(nb_sim* s)
     if (s->jpartial) (void)hipFree(s->jpartial);
     if (s->tickets) (void)hipFree(s->tickets);
     if (s->sym_tab) (void)hipFree(s->sym_tab);
+    if (s->sym_spill) (void)hipFree(s->sym_spill);
     if (s->sym_A) (void)hipFree(s->sym_A);
     if (s->diag) (void)hipFree(s->diag);
     if (s->zero_row) (void)hipFree(s->zero_row);
@@ -1032,8 +1051,10 @@ int nb_plan_query(const nb_config* cfg_in, int n_cu, double clock_hz, nb_plan_in
     out->jsplit = tmp.jsplit; out->j_per_split = tmp.j_per_split; out->own_split0 = tmp.own_split0; out->own_splits = tmp.own_splits;
     out->sym = tmp.sym; out->symw = tmp.symw; out->sym_rank = tmp.sym_rank;
     out->sym_np = tmp.sym_np; out->sym_layers = tmp.sym_layers; out->sym_g0 = tmp.sym_g0; out->sym_g1 = tmp.sym_g1;
-    static_assert(sizeof(out->sym_plan) == sizeof(tmp.sym_plan), "nb_plan_info::sym_plan mirrors nb_sim::sym_plan");
+    static_assert(sizeof(out->sym_plan) == sizeof(tmp.sym_plan) - sizeof(uint32_t), "nb_plan_info::sym_plan holds the first eleven words of nb_sim::sym_plan; the twelfth (ups) is sym_ups");
     memcpy(out->sym_plan, tmp.sym_plan, sizeof out->sym_plan);
+    out->sym_ups = tmp.symw ? tmp.sym_plan[11] : 0;
+    out->sym_spill_rows = tmp.sym_spill_rows;
     out->tab_len = (uint32_t)tmp.sym_tab_host.size();
     snprintf(out->variant, sizeof out->variant, "%s", tmp.variant.c_str());
     if (tab) memcpy(tab, tmp.sym_tab_host.data(), sizeof(uint32_t) * (out->tab_len < tab_cap ? out->tab_len : tab_cap));

@@ -59,6 +59,7 @@ struct nb_sim {
     void* vel = nullptr;
     void* acc = nullptr;
     void* partial = nullptr;
+    size_t partial_bytes = 0;      // what `partial` was allocated with (nb_create checks it against the handle's form)
     double* diag = nullptr;
     void* zero_row = nullptr;      // 64 zero bytes (LDS-DMA source for j past the range)
     uint32_t diag_blocks = 0, diag_chunk = 256;   // nb_diag: workgroups (row blocks x j-chunks), bodies per j-chunk
@@ -92,10 +93,12 @@ struct nb_sim {
     // bodies / gm are allocated with sym_np >= n rows (zero-mass padding); `partial` holds sym_layers x sym_np rows.
     bool sym = false;
     uint32_t sym_np = 0, sym_layers = 0;
-    uint32_t sym_plan[11] = {0};   // nb::SymPlan / nb::SymWPlan, kept as plain words here (nb_comm.hip does not see the kernels' types)
+    uint32_t sym_plan[12] = {0};   // nb::SymPlan / nb::SymWPlan, kept as plain words here (nb_comm.hip does not see the kernels' types)
     bool symw = false;             // wave-granular form (nb_force_symw): sym_plan holds a SymWPlan, sym_tab the per-super-block table
     uint32_t* sym_tab = nullptr;   // device: {first wave, wave count} per super-block
     std::vector<uint32_t> sym_tab_host;
+    void* sym_spill = nullptr;     // ups > 1: one spill row set per wave (traveler sums of the sweep a wave's range starts inside)
+    uint32_t sym_spill_rows = 0;
     // rank form (NB_FLAG_SYM_SHARD: a shard handle whose cross-rank reduction the engine's native exchange provides): the
     // handle's own rows are the resident super-blocks [sym_g0, sym_g1); sym_A[np] = this rank's sums for EVERY row, reduce-
     // scattered across the ranks before the integrate kernel reads the rank's own rows of it

@@ -83,8 +83,12 @@ static void name_variant(LaunchPlan* s, bool f64, const Shape& sh)
     else if (sh.kind == kJpk)
         snprintf(buf, sizeof buf, "f32pk_fused_jpairs_ws%d_js%u", jpk_ws(sh.x), s->jsplit);
     else if (sh.kind == kSym)
-        snprintf(buf, sizeof buf, f64 ? (s->sym_rank ? "f64_symwrank_ipl%d_j%d_w%u_r%ut%u" : "f64_symw_ipl%d_j%d_w%u_r%ut%u") : s->sym_rank ? "f32pk_symwrank_ipl%d_j%d_w%u_r%ut%u" : s->symw ? "f32pk_symw_ipl%d_j%d_w%u_r%ut%u" : "f32pk_sym_ipl%d_ws%d_q%u_r%ut%u", sh.ipl, s->symw ? (sh.x == 3 ? 1 : 2) : sh.x,
+    {
+        // "_u4": wave ranges cut in quarter sweeps (SymWPlan::ups, word 11); whole sweeps carry no suffix
+        const int len = snprintf(buf, sizeof buf, f64 ? (s->sym_rank ? "f64_symwrank_ipl%d_j%d_w%u_r%ut%u" : "f64_symw_ipl%d_j%d_w%u_r%ut%u") : s->sym_rank ? "f32pk_symwrank_ipl%d_j%d_w%u_r%ut%u" : s->symw ? "f32pk_symw_ipl%d_j%d_w%u_r%ut%u" : "f32pk_sym_ipl%d_ws%d_q%u_r%ut%u", sh.ipl, s->symw ? (sh.x == 3 ? 1 : 2) : sh.x,
                  s->sym_plan[2], s->sym_plan[8] - s->sym_plan[7], s->sym_layers - (s->sym_plan[8] - s->sym_plan[7]));     // words 7, 8: r_layer0, t_layer0 in both plans
+        if (s->symw && s->sym_plan[11] > 1 && len > 0 && (size_t)len < sizeof buf) snprintf(buf + len, sizeof buf - (size_t)len, "_u%u", s->sym_plan[11]);
+    }
     else
         snprintf(buf, sizeof buf, "%s%s_lds%d_ipl%d_ls%d_js%u", f64 ? "f64" : "f32", sh.kind == kPkLds ? "pk" : "",
                  nb::kTile * (sh.kind == kPkLds ? sh.x : 1), sh.ipl, sh.ls, s->jsplit);
@@ -146,7 +150,7 @@ inline ModelKnobs model_knobs() { return ModelKnobs(); }       // release build:
 // Fitted on profiles/r03/sym_variants_scan_wave_granular*.txt (N = 12,000 .. 262,144, both resident counts: within 2 %);
 // 4 residents per lane (half the chunk-sweep of 8: finer rounding) win from N ~ 14,000 to 18,000 (sym_4_residents_per_lane.txt);
 // k = 3 measured behind k = 2 (N = 131,072: 2,682 vs 2,615 us).
-struct SymChoice { int ipl; uint32_t k; double t; };
+struct SymChoice { int ipl; uint32_t k; uint32_t ups; double t; };
 
 // Bytes of partial-sum layers a symmetric handle allocates: one traveler layer per ring distance, i.e. ~ 3 * esz * N^2 / (2 S)
 // (N = 1,048,576 with 1,024-row super-blocks: 6.4 GB, N = 4 M: 103 GB; it grows with N^2, so very large systems fall back to the
@@ -164,9 +168,19 @@ double sym_layer_budget(const nb_config& cfg, double device_mem)
     return std::min(device_mem / 3.0, 96.0 * 1073741824.0);
 }
 
-SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64, double layer_budget)
+// Work units per chunk-sweep for a handle of L sweeps cut into W wave ranges.  With whole sweeps a wave gets floor or ceil(L / W)
+// of them and the launch lasts as long as its longest SIMD: at N = 16,384 (4.1 sweeps per SIMD) some SIMDs run 5 -- 56 us against
+// 44 us of pair work (profiles/r04/step_parts_base.txt).  Quarter sweeps (16 rotation steps) bring that to 4.25.  A system with
+// dozens of sweeps per wave does not need them.
+uint32_t sym_units(uint64_t L, uint32_t W, bool whole_only)
 {
-    SymChoice best{0, 0, 1e300};
+    if (whole_only || W == 0) return 1;
+    return L < (uint64_t)48 * W ? 4u : 1u;
+}
+
+SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64, double layer_budget, bool whole_only)
+{
+    SymChoice best{0, 0, 1, 1e300};
     for (int ipl : {4, 8, 16}) {
         if (f64 && ipl != 8) continue;              // nb_force_symw64<8>: 8 residents per lane, 19 DP instructions + v_rsq_f64 per pair
         const uint32_t NG = (uint32_t)ipl / 2, S = 64u * (uint32_t)ipl, cps = S / 64u;
@@ -181,12 +195,16 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
         if (per_simd < 1.0) continue;
         for (uint32_t k = 1; k <= 2; ++k) {
-            const double pw = per_simd / 2.0, fl = std::floor(pw);
-            const double sweeps = k == 1 ? std::ceil(per_simd) * 1.019 : (2.0 * fl + 2.0 * std::min(1.0, 2.0 * (pw - fl))) * 1.01;
+            const uint32_t ups = sym_units(L, (uint32_t)simds * k, whole_only);
+            // in units of 1 / ups sweep: a wave gets floor or ceil of its share; two waves of a SIMD both round up about min(1, 2p) of the time
+            const double pu = per_simd * ups, pw = pu / 2.0, fl = std::floor(pw);
+            const double units = k == 1 ? std::ceil(pu) * 1.019 : (2.0 * fl + 2.0 * std::min(1.0, 2.0 * (pw - fl))) * 1.01;
+            const double sweeps = units / ups;
             const double segs = per_simd / k / (double)total_lo + 1.0;             // super-blocks a wave's range touches
-            const double layers = (double)(H + 1) + (double)total_hi * k / per_simd + 1.0;     // traveler + resident layers K2 reads per body
-            const double t = sweeps * t_chunk + 3.5e-6 + segs * 1.5e-6 + boundary + layers * n * (f64 ? 24.0 : 12.0) / 5.0e12;
-            if (t < best.t) best = {ipl, k, t};
+            const double spill = ups > 1 ? simds * k * 64.0 / n : 0.0;             // spill rows K2 adds per body (one 64-row spill per wave)
+            const double layers = (double)(H + 1) + (double)total_hi * k / per_simd + 1.0 + spill;     // traveler + resident layers K2 reads per body
+            const double t = sweeps * t_chunk + 3.5e-6 + segs * 1.5e-6 + (ups > 1 ? 0.6e-6 : 0.0) + boundary + layers * n * (f64 ? 24.0 : 12.0) / 5.0e12;
+            if (t < best.t) best = {ipl, k, ups, t};
         }
     }
     return best;
@@ -197,11 +215,11 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
 //   rank_ipl != 0: rank form -- only the lists of the handle's own super-blocks [sb / S, (sb + sc) / S)
 //   sym_k: waves per SIMD the cost model asked for (0: cfg.jsplit, else 1; rank form 2 when there is enough work)
 static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, uint32_t sb, uint32_t sc, const nb_config& cfg, int n_cu,
-                         int rank_ipl, uint32_t sym_k)
+                         int rank_ipl, uint32_t sym_k, uint32_t sym_ups)
 {
     // wave-granular form: super-block = one wave's residents; the chunk lists of all super-blocks laid end to end are cut
     // into W equal ranges, W = cfg.jsplit (default 1) waves per SIMD of the chip.
-    const uint32_t S = ipb_of(sh), J = sh.x == 3 ? 1u : 2u, cps = S / (64u * J);
+    const uint32_t S = ipb_of(sh), J = sh.x == 3 ? 1u : 2u, CH = 64u * J, cps = S / CH;
     const uint32_t nsb = ceil_div(n, S), H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
     nb::SymWPlan pl;
     pl.np = nsb * S; pl.nsb = nsb;
@@ -214,23 +232,63 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, u
     pl.L = offset_of(g1) - pl.p0;
     const uint32_t kw = sym_k ? sym_k : (cfg.jsplit ? cfg.jsplit : (rank_ipl && pl.L >= 16u * (uint32_t)n_cu ? 2u : 1u));
     uint32_t W = 4u * (uint32_t)n_cu * kw;
-    if (W > pl.L) W = (pl.L + 3u) & ~3u;
+    // work units per sweep: the rank form's reduction kernels know nothing of spill rows, so a rank keeps whole sweeps
+    const bool whole_only = rank_ipl != 0 || (cfg.flags & NB_FLAG_WHOLE_SWEEPS);
+    const uint32_t ups = whole_only ? 1u : (sym_ups ? sym_ups : sym_units(pl.L, W, false));
+    pl.ups = ups;
+    const uint64_t Lu = (uint64_t)pl.L * ups;                  // the handle's work in units
+    if (W > Lu) W = (uint32_t)Lu;                               // never more waves than units: every wave has work, so every resident layer the table
+                                                               // counts is written (the kernel's `w >= W` guard idles the rest of the last workgroup)
     pl.W = W;
-    auto start_of = [&](uint32_t w) { return (uint32_t)(((uint64_t)w * pl.L) / pl.W); };
-    auto wave_of = [&](uint32_t p) {              // p: position inside this handle's range
-        uint32_t w = (uint32_t)(((uint64_t)p * pl.W) / pl.L);
-        while (w + 1 < pl.W && start_of(w + 1) <= p) ++w;
-        while (w > 0 && start_of(w) > p) --w;
+    auto start_of = [&](uint32_t w) { return (uint64_t)w * Lu / pl.W; };          // first unit of wave w (relative to the handle's range)
+    auto wave_of = [&](uint64_t u) {              // u: unit inside this handle's range
+        uint32_t w = (uint32_t)(u * pl.W / Lu);
+        while (w + 1 < pl.W && start_of(w + 1) <= u) ++w;
+        while (w > 0 && start_of(w) > u) --w;
         return w;
     };
-    s->sym_tab_host.assign(2 * (size_t)nsb, 0);
+    const uint32_t nch = pl.np / CH;
+    s->sym_tab_host.assign(2 * (size_t)nsb + (ups > 1 ? 2 * (size_t)nch : 0), 0);
     uint32_t max_r = 1;
     for (uint32_t g = g0; g < g1; ++g) {
         const uint32_t total = g < n_hi ? pl.total_hi : pl.total_lo;
-        const uint32_t off = offset_of(g) - pl.p0;
-        const uint32_t first = wave_of(off), last = wave_of(off + total - 1);
+        const uint64_t off = (uint64_t)(offset_of(g) - pl.p0) * ups;
+        const uint32_t first = wave_of(off), last = wave_of(off + (uint64_t)total * ups - 1);
         s->sym_tab_host[2 * g] = first; s->sym_tab_host[2 * g + 1] = last - first + 1;
         if (last - first + 1 > max_r) max_r = last - first + 1;
+    }
+    s->sym_spill_rows = 0;
+    if (ups > 1) {
+        // spill lists: a wave whose range starts inside a sweep keeps that sweep's traveler sums in its own spill row; K2 adds
+        // them to the rows of the sweep's traveler chunk.  Per chunk {offset, count}, then the wave numbers in ascending order.
+        struct Spill { uint32_t chunk, wave; };
+        std::vector<Spill> sp;
+        for (uint32_t w = 0; w < pl.W; ++w) {
+            const uint64_t u = start_of(w);
+            if (u % ups == 0 || start_of(w + 1) == u) continue;               // starts a sweep, or has no work
+            const uint32_t p = pl.p0 + (uint32_t)(u / ups);
+            const uint32_t first_lo = n_hi * pl.total_hi;
+            uint32_t g, k, total;
+            if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
+            else { const uint32_t r = p - first_lo; g = n_hi + r / pl.total_lo; k = r - (g - n_hi) * pl.total_lo; total = pl.total_lo; }
+            const uint32_t ring = total - cps;
+            if (k >= ring) continue;                                            // resident-only sweep: no traveler sums
+            uint32_t tb = g + 1 + k / cps;
+            if (tb >= nsb) tb -= nsb;
+            const uint32_t tstart = tb * S + (k % cps) * CH;
+            if (tstart >= n) continue;                                          // a chunk of padding rows: skipped by the kernel
+            sp.push_back({tstart / CH, w});
+        }
+        std::stable_sort(sp.begin(), sp.end(), [](const Spill& a, const Spill& b) { return a.chunk < b.chunk; });      // waves stay ascending inside a chunk
+        const size_t base = 2 * (size_t)nsb, ids0 = base + 2 * (size_t)nch;
+        s->sym_tab_host.resize(ids0 + sp.size(), 0);
+        for (size_t e = 0; e < sp.size(); ++e) {
+            uint32_t* ent = &s->sym_tab_host[base + 2 * (size_t)sp[e].chunk];
+            if (ent[1] == 0) ent[0] = (uint32_t)e;
+            ++ent[1];
+            s->sym_tab_host[ids0 + e] = sp[e].wave;
+        }
+        s->sym_spill_rows = pl.W * CH;
     }
     s->sym_rank = rank_ipl != 0; s->sym_g0 = g0; s->sym_g1 = g1;
     pl.r_layer0 = 0; pl.t_layer0 = max_r;
@@ -239,7 +297,7 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, u
     s->sym = true; s->symw = true; s->sym_np = pl.np; s->sym_layers = max_r + H + (n_hi ? 1u : 0u);
     s->ipl = sh.ipl; s->ls = 1; s->packed = !f64; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
     s->ws = sh.x; s->tl = 1;
-    s->jsplit = max_r; s->j_per_split = ceil_div(pl.L, pl.W) * 64u * J; s->swap_acc = false; s->own_split0 = 0; s->own_splits = 0;
+    s->jsplit = max_r; s->j_per_split = (uint32_t)ceil_div((uint32_t)((Lu + pl.W - 1) / pl.W), ups) * 64u * J; s->swap_acc = false; s->own_split0 = 0; s->own_splits = 0;
     name_variant(s, f64, sh);
 }
 
@@ -328,7 +386,7 @@ LaunchPlan plan_launch(const PlanInput& in)
     }
 
     Shape sh{f64 ? kScalar : kPkLds, 2, 1, 1};
-    uint32_t js = cfg.jsplit, sym_k = 0;
+    uint32_t js = cfg.jsplit, sym_k = 0, sym_ups = 0;
     // NB_FLAG_SYM_SHARD: a rank's shard whose cross-rank reduction the engine's native exchange provides takes the RANK form of the
     // symmetric pass when its rows are whole super-blocks (1,024 rows, or 512); otherwise the flag is ignored
     int rank_ipl = 0;
@@ -346,6 +404,7 @@ LaunchPlan plan_launch(const PlanInput& in)
             if ((want.kind == kFused || want.kind == kDirect) && !may_fuse && !f64) want = {kPkLds, want.ipl, want.ls, 1};   // same loop, two kernels
             if (want.kind == kDirect && n > 1024u * (uint32_t)want.x) want = {kFused, 2, 64, 4};
             if (want.kind == kJpk && !may_fuse) want = {kPkSgpr, 4, 1, 4};      // whole-system f32 handles only
+            if (want.kind == kSym && want.ls > 1) { sym_ups = (uint32_t)want.ls <= 8u ? (uint32_t)want.ls : 0u; want.ls = 1; }      // K = 7: LL = 02 / 04 / 08 pins the units per sweep
             if (want.kind == kSym && (!whole || cfg.ext_bodies || !shape_exists(f64, want) || n <= ipb_of(want) ||       // likewise; >= 2 super-blocks,
                                       sym_layer_bytes(n, ipb_of(want), esz) > std::max(layer_budget, 0.6 * in.device_mem)))    // and layers that fit (pinned: up to 60 % of the memory)
                 want = f64 ? Shape{kScalar, 4, 1, 1} : Shape{kPkSgpr, 8, 1, 4};
@@ -469,8 +528,8 @@ LaunchPlan plan_launch(const PlanInput& in)
         // the symmetric pass (whole-system f32 handles; every unordered pair once): from N ~ 14,000 up it beats every
         // ordered-pair shape above (N = 16,384: 61.7 vs 65.7 us, 40,002: 270 vs 357 us, 262,144: 10.5 vs 14.6 ms)
         if (!pinned && whole && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
-            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, f64, layer_budget);
-            if (sc2.ipl && sc2.t < 0.98 * (pick ? pick->t : best_t)) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; }     // a clear win only: both estimates are good to ~3 %
+            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, f64, layer_budget, (cfg.flags & NB_FLAG_WHOLE_SWEEPS) != 0);
+            if (sc2.ipl && sc2.t < 0.98 * (pick ? pick->t : best_t)) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; sym_ups = sc2.ups; }     // a clear win only: both estimates are good to ~3 %
         }
     }
     if (js < 1) {   // pinned shape outside the model's candidate list: fill ~4096 workgroups
@@ -480,7 +539,7 @@ LaunchPlan plan_launch(const PlanInput& in)
         if (js < 1) js = 1;
     }
     if (sh.kind == kFused || sh.kind == kDirect) js = 1;
-    if (sh.kind == kSym && sh.x != 4) { lay_out_symw(s, sh, f64, n, sb, sc, cfg, n_cu, rank_ipl, sym_k); return plan; }
+    if (sh.kind == kSym && sh.x != 4) { lay_out_symw(s, sh, f64, n, sb, sc, cfg, n_cu, rank_ipl, sym_k, sym_ups); return plan; }
     if (sh.kind == kSym) { lay_out_sym_wg(s, sh, f64, n, cfg, n_cu); return plan; }
     s->ipl = sh.ipl; s->ls = sh.ls;
     s->packed = sh.kind != kScalar; s->sgpr = sh.kind == kPkSgpr;

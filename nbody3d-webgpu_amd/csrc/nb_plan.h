@@ -33,6 +33,12 @@ struct SymWPlan {
     uint32_t L;                 // chunk-sweeps of this handle: n_hi * total_hi + (nsb - n_hi) * total_lo for a whole system
     uint32_t p0;                // where this handle's range starts in the global list (0 for a whole system; a RANK that owns
                                 // the resident super-blocks [g0, g1) works on the lists of those super-blocks only)
+    uint32_t ups;               // work units per chunk-sweep (1, 2, 4 or 8): the W wave ranges are floor/ceil-equal in UNITS of
+                                // 64 / ups rotation steps, so a sweep may be shared by consecutive waves.  The wave that runs a
+                                // sweep's steps from 0 stores its traveler sums in the sweep's traveler layer; a wave that starts
+                                // mid-sweep stores them in its own SPILL row (one per wave), which K2 adds through the per-chunk
+                                // spill lists that follow the {first wave, count} table: {offset, count} per traveler chunk, then
+                                // the wave numbers
 };
 }  // namespace nb
 
@@ -70,8 +76,10 @@ struct LaunchPlan {
     uint32_t jsplit = 1, j_per_split = 0, junits = 0, own_split0 = 0, own_splits = 0;
     bool sym = false, symw = false, sym_rank = false;
     uint32_t sym_np = 0, sym_layers = 0, sym_g0 = 0, sym_g1 = 0;
-    uint32_t sym_plan[11] = {0};         // nb::SymWPlan (symw) or nb::SymPlan, as plain words
-    std::vector<uint32_t> sym_tab_host;  // wave-granular form: {first wave, wave count} per super-block
+    uint32_t sym_plan[12] = {0};         // nb::SymWPlan (symw) or nb::SymPlan, as plain words
+    uint32_t sym_spill_rows = 0;         // wave-granular form with ups > 1: rows of the spill buffer (W x travelers per chunk)
+    std::vector<uint32_t> sym_tab_host;  // wave-granular form: {first wave, wave count} per super-block [2 nsb words]; with ups > 1
+                                         // followed by {offset, count} per traveler chunk [2 np / CH words] and the spill lists' wave numbers
     std::string variant;
 };
 

@@ -26,6 +26,7 @@ NB_FLAG_POISON = 16
 NB_FLAG_JPK_FENCED = 32
 NB_FLAG_NO_SYM = 64
 NB_FLAG_SYM_SHARD = 128
+NB_FLAG_WHOLE_SWEEPS = 256
 NB_RCCL_ID_BYTES = 128
 NB_RCCL_OVERLAP = 1
 NB_MULTI_PEER, NB_MULTI_RCCL = 0, 1
@@ -55,7 +56,8 @@ class nb_plan_info(C.Structure):
     _fields_ = [("struct_size", C.c_uint32)] + [(k, C.c_uint32) for k in (
         "kind", "ipl", "ls", "x", "jsplit", "j_per_split", "own_split0", "own_splits",
         "sym", "symw", "sym_rank", "sym_np", "sym_layers", "sym_g0", "sym_g1")] + [
-        ("sym_plan", C.c_uint32 * 11), ("tab_len", C.c_uint32), ("variant", C.c_char * 112)]
+        ("sym_plan", C.c_uint32 * 11), ("tab_len", C.c_uint32), ("variant", C.c_char * 112),
+        ("sym_ups", C.c_uint32), ("sym_spill_rows", C.c_uint32)]
 
 
 class nb_step_timing(C.Structure):          # include/nbody3d_hip.h
@@ -202,7 +204,17 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
     out["variant"] = info.variant.decode()
     if info.sym:
         out["plan"] = dict(zip(SYMW_PLAN_WORDS if info.symw else SYM_PLAN_WORDS, (int(w) for w in info.sym_plan)))
-        out["tab"] = tab.reshape(-1, 2)
+        nsb = out["plan"]["nsb"]
+        out["tab"] = tab[:2 * nsb].reshape(-1, 2)
+        out["ups"], out["spill_rows"] = int(info.sym_ups), int(info.sym_spill_rows)
+        if info.symw:
+            out["plan"]["ups"] = int(info.sym_ups)
+        if info.sym_ups > 1:
+            # the spill lists (wave ranges cut inside sweeps): {offset, count} per traveler chunk, then the wave numbers
+            ch = 128 if info.x == 1 else 64
+            nch = out["plan"]["np"] // ch
+            out["spill_tab"] = tab[2 * nsb:2 * nsb + 2 * nch].reshape(-1, 2)
+            out["spill_ids"] = tab[2 * nsb + 2 * nch:]
     return out
 
 

@@ -12,16 +12,18 @@ import pytest
 
 from nbody3d_amd import capi
 
-NB_FLAG_NO_SYM, NB_FLAG_SYM_SHARD = 64, 128
+NB_FLAG_NO_SYM, NB_FLAG_SYM_SHARD, NB_FLAG_WHOLE_SWEEPS = 64, 128, 256
 
 
 def walk_symw(q, n, rank=False):
-    """Every chunk-sweep of a wave-granular plan as arrays (one entry per list position of this handle)."""
+    """Every chunk-sweep of a wave-granular plan as arrays (one entry per list position of this handle), and the waves that
+    share it: the plan cuts the handle's L sweeps into W ranges of UNITS (ups units = 64 rotation steps per sweep)."""
     pl, tab = q["plan"], q["tab"]
     J = 2 if q["x"] == 1 else 1
     S, CH = 64 * q["ipl"], 64 * J
     cps = S // CH
-    nsb, W, L, p0 = pl["nsb"], pl["W"], pl["L"], pl["p0"]
+    nsb, W, L, p0, ups = pl["nsb"], pl["W"], pl["L"], pl["p0"], pl["ups"]
+    assert ups in (1, 2, 4, 8) and q["ups"] == ups
     assert pl["np"] == nsb * S and nsb == -(-n // S)
     H, n_hi = pl["H"], pl["n_hi"]
     assert H == (nsb - 1) // 2 and n_hi == (0 if nsb % 2 else nsb // 2)
@@ -38,13 +40,46 @@ def walk_symw(q, n, rank=False):
     tb = np.where(sym, (g + 1 + d) % nsb, g)
     c = np.where(sym, k % cps, k - ring)
     tstart = tb * S + c * CH
-    # the wave that sweeps each position: W floor/ceil-equal ranges of the handle's L positions
-    starts = p0 + (np.arange(W + 1, dtype=np.int64) * L) // W
-    assert np.all(np.diff(starts) >= 0) and starts[0] == p0 and starts[-1] == p0 + L
-    assert np.diff(starts).max() - np.diff(starts).min() <= 1                    # balanced to one chunk-sweep
-    w = np.searchsorted(starts, p, side="right") - 1
-    assert np.all((w >= 0) & (w < W))
-    return dict(S=S, CH=CH, cps=cps, nsb=nsb, H=H, n_hi=n_hi, g=g, k=k, sym=sym, d=d, tb=tb, c=c, tstart=tstart, w=w, pl=pl, tab=tab)
+    # the waves: W floor/ceil-equal ranges of the handle's L * ups units, none of them empty
+    Lu = L * ups
+    starts = (np.arange(W + 1, dtype=np.int64) * Lu) // W
+    assert starts[0] == 0 and starts[-1] == Lu and W <= Lu
+    assert np.diff(starts).min() >= 1 and np.diff(starts).max() - np.diff(starts).min() <= 1      # balanced to one unit, every wave has work
+    wu = np.searchsorted(starts, np.arange(Lu, dtype=np.int64), side="right") - 1               # the wave of every unit
+    assert np.all((wu >= 0) & (wu < W))
+    w = wu[::ups]                                # the wave that starts each sweep (steps from 0): it owns the sweep's traveler layer
+    w_last = wu[ups - 1::ups]                    # ... and the one that ends it
+    return dict(S=S, CH=CH, cps=cps, nsb=nsb, H=H, n_hi=n_hi, g=g, k=k, sym=sym, d=d, tb=tb, c=c, tstart=tstart, w=w, w_last=w_last, wu=wu,
+                starts=starts, ups=ups, pl=pl, tab=tab)
+
+
+def check_spill_lists(q, n, wk):
+    """ups > 1: a wave whose range starts INSIDE a sweep keeps that sweep's traveler sums in its own spill row; the plan lists,
+    per traveler chunk, the waves K2 has to add -- exactly those, in ascending order."""
+    ups, W, CH, starts = wk["ups"], wk["pl"]["W"], wk["CH"], wk["starts"]
+    if ups == 1:
+        assert q["spill_rows"] == 0 and "spill_tab" not in q
+        return
+    assert q["spill_rows"] == W * CH
+    st, ids = q["spill_tab"], q["spill_ids"]
+    assert st.shape[0] == wk["pl"]["np"] // CH
+    want = {}
+    for wv in range(W):
+        u0 = int(starts[wv])
+        if u0 % ups == 0:
+            continue
+        sw = u0 // ups
+        if wk["sym"][sw] and wk["tstart"][sw] < n:
+            want.setdefault(int(wk["tstart"][sw]) // CH, []).append(wv)
+    got = {}
+    for ci in range(st.shape[0]):
+        off, cnt = int(st[ci, 0]), int(st[ci, 1])
+        if cnt:
+            got[ci] = [int(x) for x in ids[off:off + cnt]]
+    assert got == want
+    assert sum(len(v) for v in want.values()) == len(ids)
+    # a sweep is shared by consecutive waves: the first owns the layer, each of the others spills exactly once
+    assert all(v == sorted(v) for v in got.values())
 
 
 def check_whole_plan(q, n):
@@ -69,9 +104,11 @@ def check_whole_plan(q, n):
     assert np.all(own == 1) and np.all(tb[~sym] == g[~sym])
     # (3) ring distances stay inside the traveler layers
     assert np.all(d[sym] < H + (g[sym] < n_hi)) and pl["t_layer0"] + H + (1 if n_hi else 0) == q["sym_layers"]
-    # (4) resident layers: wave w writes layer r_layer0 + (w - first wave of g); the table is what the traversal does
+    # (4) resident layers: wave w writes layer r_layer0 + (w - first wave of g) for every super-block it has a unit of; the
+    #     table is what the traversal does
+    gu = np.repeat(g, wk["ups"])
     for b in range(nsb):
-        ws = np.unique(w[g == b])
+        ws = np.unique(wk["wu"][gu == b])
         assert ws[0] == tab[b, 0] and len(ws) == tab[b, 1] and ws[-1] - ws[0] + 1 == len(ws), b
     assert pl["r_layer0"] == 0 and tab[:, 1].max() == pl["t_layer0"] == q["jsplit"]
     # (5) traveler layers: K2 (nb_integrate_symw) reads layers t_layer0 + [0, H + (n_hi and b >= n_hi)) of every row of b --
@@ -81,6 +118,8 @@ def check_whole_plan(q, n):
     for b in range(nsb):
         nt = H + (1 if (n_hi and b >= n_hi) else 0)
         assert np.all(tl[b, :, :nt] == 1) and np.all(tl[b, :, nt:] == 0), b
+    # (6) sweeps shared by several waves: the later parts go through the spill lists
+    check_spill_lists(q, n, wk)
     return wk
 
 
@@ -106,7 +145,10 @@ def test_pinned_wave_granular_plans(variant, n, jsplit):
         return
     assert q["symw"] and q["ipl"] == variant // 1000 % 100 and q["x"] == variant % 10
     wk = check_whole_plan(q, n)
-    assert wk["pl"]["W"] % 4 == 0 and wk["pl"]["W"] <= max(4, wk["pl"]["L"] + 3)
+    assert wk["pl"]["W"] <= wk["pl"]["L"] * wk["pl"]["ups"]              # never more waves than units: no wave without work
+    whole = capi.plan_query(n, force_variant=variant, jsplit=jsplit, flags=NB_FLAG_WHOLE_SWEEPS)       # the A/B arm: whole sweeps per wave
+    assert whole["ups"] == 1 and "_u" not in whole["variant"].rsplit("_r", 1)[1]
+    check_whole_plan(whole, n)
 
 
 @pytest.mark.parametrize("n", [40002, 262144])
@@ -168,6 +210,7 @@ def test_rank_form_plans_tile_the_pair_list(n, g, prec):
         S = 64 * q["ipl"]
         assert q["sym_g0"] == b // S and q["sym_g1"] == (b + cnt) // S
         wk = walk_symw(q, n, rank=True)
+        assert wk["ups"] == 1 and q["spill_rows"] == 0                                     # a rank keeps whole sweeps (nb_sym_reduce knows no spill rows)
         assert wk["g"].min() == q["sym_g0"] and wk["g"].max() == q["sym_g1"] - 1         # only its own super-blocks are resident
         for sb in range(q["sym_g0"], q["sym_g1"]):
             ws = np.unique(wk["w"][wk["g"] == sb])
@@ -213,7 +256,7 @@ def test_shard_own_splits_lie_inside_the_shard(n, g):
 
 def test_model_choice_table():
     """The automatic choice at the sizes DESIGN.md quotes (256 CUs, 2.4 GHz): a change of the cost model shows up here."""
-    want = {1024: "f32pk_fused_regs1024", 10000: "f32pk_fused_jpairs", 16384: "f32pk_symw_ipl8_j1_w2048", 40002: "f32pk_symw_ipl16_j1_w1024",
+    want = {1024: "f32pk_fused_regs1024", 10000: "f32pk_fused_jpairs", 16384: "f32pk_symw_ipl8_j1_w1024_r34t16_u4", 40002: "f32pk_symw_ipl16_j1_w1024_r28t20_u4",
             65536: "f32pk_symw_ipl16_j1_w2048", 262144: "f32pk_symw_ipl16_j1_w2048_r10t128", 1048576: "f32pk_symw_ipl16_j1_w2048"}
     for n, prefix in want.items():
         assert capi.plan_query(n)["variant"].startswith(prefix), (n, capi.plan_query(n)["variant"])

@@ -49,6 +49,58 @@ def test_single_step_matches_the_fp64_oracle(variant, jsplit, n):
     assert rel_pos_err(bb, b2, 1.0) < 1e-6, name
 
 
+# the wave ranges are cut in UNITS of a chunk-sweep (64 rotation steps): whole sweeps (NB_FLAG_WHOLE_SWEEPS, the ABI 2.0 form), or
+# half / quarter / eighth sweeps (LL = 02 / 04 / 08; LL = 01: the planner's choice, quarters at these sizes) -- a sweep shared by
+# two waves leaves its later part in the second wave's spill row, which the integrate kernel adds through the chunk's spill list
+UNIT_ARMS = [(716013, 0, capi.NB_FLAG_WHOLE_SWEEPS, ""), (708013, 2, capi.NB_FLAG_WHOLE_SWEEPS, ""), (708011, 1, capi.NB_FLAG_WHOLE_SWEEPS, ""),
+             (716023, 1, 0, "_u2"), (716083, 2, 0, "_u8"), (708081, 1, 0, "_u8"), (704043, 3, 0, "_u4"), (708043, 0, 0, "_u4"), (716041, 2, 0, "_u4")]
+
+
+@pytest.mark.parametrize("variant,jsplit,flags,suffix", UNIT_ARMS)
+@pytest.mark.parametrize("n", [2049, 8192, 12289, 20001])
+def test_sweep_unit_arms_match_the_oracle_and_each_other(variant, jsplit, flags, suffix, n):
+    b, v = (ic.plummer(n, seed=91) if n % 2 == 0 else ic.uniform_cube(n, seed=91))
+    if n <= 64 * (variant // 1000 % 100):
+        return
+    bb, vv, aa, name = run(b, v, 1, force_variant=variant, jsplit=jsplit, flags=flags)
+    assert "symw" in name and (name.endswith(suffix) if suffix else "_u" not in name.rsplit("_r", 1)[1]), name
+    ref = oracle.accel_f64(b, 1.0)
+    assert np.abs(aa[:, :3] - ref[:, :3]).max() < TOL_ACC * np.abs(ref[:, :3]).max(), name
+    b2, _, a2, name2 = run(b, v, 1, force_variant=variant // 100 * 100 + 10 + variant % 10, jsplit=jsplit)      # the planner's units
+    assert np.abs(aa[:, :3] - a2[:, :3]).max() < 2e-6 * np.abs(ref[:, :3]).max(), (name, name2)                # same pairs, another order of additions
+    again = run(b, v, 1, force_variant=variant, jsplit=jsplit, flags=flags)
+    assert again[2].tobytes() == aa.tobytes() and again[0].tobytes() == bb.tobytes(), name                      # deterministic
+
+
+@pytest.mark.parametrize("n,precision", [(16384, "f32"), (20000, "f32"), (40002, "f32"), (16384, "f64"), (40002, "f64")])
+def test_default_plan_cuts_mid_sizes_in_sub_sweep_units(n, precision):
+    """The sizes the reference's UI offers (1,001 .. 500,010, default 40,002: index.html:68-74) have a handful of sweeps per SIMD:
+    the default plan cuts them in quarter sweeps.  Multi-step agreement with the fp64 oracle and with the whole-sweep arm."""
+    b, v = ic.plummer(n, seed=92)
+    dt = np.float64 if precision == "f64" else np.float32
+    bb, vv, aa, name = run(b.astype(dt), v.astype(dt), 3, precision=precision)
+    assert "symw" in name and "_u" in name.rsplit("_r", 1)[1], name
+    wb, wv, wa, wname = run(b.astype(dt), v.astype(dt), 3, precision=precision, flags=capi.NB_FLAG_WHOLE_SWEEPS)
+    assert "symw" in wname and "_u" not in wname.rsplit("_r", 1)[1], wname
+    tol = 1e-12 if precision == "f64" else 1e-6
+    assert rel_pos_err(bb, wb, 1.0) < tol and np.abs(aa[:, :3] - wa[:, :3]).max() < (1e-11 if precision == "f64" else 4e-6) * np.abs(wa[:, :3]).max()
+    rb, _, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 3)
+    assert rel_pos_err(bb, rb, 1.0) < (1e-12 if precision == "f64" else TOL_TIGHT), name
+    assert np.abs(aa[:, :3] - ra[:, :3]).max() < (1e-11 if precision == "f64" else TOL_ACC) * np.abs(ra[:, :3]).max(), name
+
+
+def test_workgroup_form_at_the_size_that_faulted_in_round_3():
+    """N = 32,768, q = 16 segments: the partial-sum buffer this handle indexes is 12 np (q + H + 1) = 9.4 MB; round 3 once
+    allocated it a second time with the ordered-pair size 16 n q = 8.4 MB (profiles/r03/README.md).  nb_create now allocates it
+    in one place and checks its size against the handle's form; this runs the configuration once."""
+    n = 32768
+    b, v = ic.plummer(n, seed=93)
+    bb, vv, aa, name = run(b, v, 2, force_variant=708014, jsplit=16)
+    assert name.startswith("f32pk_sym_ipl8_ws4_q16"), name
+    rb, _, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 2)
+    assert rel_pos_err(bb, rb, 1.0) < TOL_TIGHT and np.abs(aa[:, :3] - ra[:, :3]).max() < TOL_ACC * np.abs(ra[:, :3]).max()
+
+
 @pytest.mark.parametrize("name,steps", [("plummer1024", 100), ("cube1000", 20), ("disk771", 50), ("galaxy_ref", 30)])
 @pytest.mark.parametrize("variant,jsplit", [(708013, 0), (708011, 2)])
 def test_golden_trajectories(manifest, name, steps, variant, jsplit):
