@@ -325,6 +325,27 @@ def also_measurements(Simulation, ic, device):
     mb, mv = ic.plummer(1048576, seed=1)
     run("config 4's system on ONE GPU: N=1048576 Plummer sphere, fp32 (the 8-GPU run shards this)", mb, mv, 1e-3, 1.0, "f32", 0, 1, 3, 3)
     del mb, mv
+    # config 5's second half: "long-horizon energy conservation vs fp32" -- the same system through both engines, energy sampled on
+    # the device (nb_diagnostics: KE after call n with PE before it)
+    try:
+        hn, hsteps, hevery = 65536, 400, 50
+        hb, hv = ic.plummer(hn, seed=1)
+        drift, final = {}, {}
+        for prec, dt_np in (("f32", np.float32), ("f64", np.float64)):
+            with Simulation(hn, precision=prec, device=device) as sim:
+                sim.init(hb.astype(dt_np), hv.astype(dt_np))
+                sim.set_params(1e-3, 1.0)
+                drift[prec] = max(sim.energy_drift(hsteps, hevery))
+                final[prec] = sim.read(vel=False, accel=False)[0]
+        dpos = np.abs(final["f32"][:, :3].astype(np.float64) - final["f64"][:, :3]).max(1)
+        rel = float((dpos / np.maximum(np.sqrt((final["f64"][:, :3] ** 2).sum(1)), 1.0)).max())
+        ok = bool(drift["f32"] < 1e-6 and drift["f64"] < 1e-6 and 0.5 * drift["f64"] < drift["f32"] < 2.0 * drift["f64"] and rel < 2e-5)
+        out.append({"workload": "config 5 energy horizon: N=65536 Plummer sphere, dt=1e-3, f32 and f64 engines from the same initial conditions",
+                    "n": hn, "steps": hsteps, "sampled_every": hevery, "max_dE_rel_f32": drift["f32"], "max_dE_rel_f64": drift["f64"],
+                    "max_rel_pos_diff_f32_vs_f64": rel, "tolerance": "both drifts < 1e-6 and within 2x of each other; positions < 2e-5",
+                    "pass": ok, "frac": None})
+    except Exception as e:
+        out.append({"workload": "config 5 energy horizon", "error": str(e), "pass": False, "frac": None})
     try:
         gb, gv, gp = ic.reference_galaxies(os.path.join(ROOT, "tests", "golden", "galaxy40002_params.json"))
         run("reference default: N=40002, 2 galaxies x 20000 + central masses 1e7, G=dt=1e-4 (index.html:68-74), fp32",

@@ -197,7 +197,7 @@ static void read_config(napi_env env, napi_value opts, nb_config *cfg)
     if (get_u32_prop(env, opts, "layerBudgetMiB", &u)) cfg->layer_budget_mib = u;
 }
 
-/* planQuery(options) -> {variant, kind, ipl, ls, x, jsplit, jPerSplit, sym, symRows, symLayers, layerBytes}: nb_plan_query -- the launch
+/* planQuery(options) -> {variant, kind, ipl, ls, x, jsplit, jPerSplit, sym, symRows, symLayers, symUnitsPerSweep, symSpillRows, layerBytes}: nb_plan_query -- the launch
  * plan nb_create would build, from host arithmetic alone (options.nCU + options.clockHz given: no GPU needed) */
 static napi_value js_plan_query(napi_env env, napi_callback_info info)
 {
@@ -219,6 +219,7 @@ static napi_value js_plan_query(napi_env env, napi_callback_info info)
     PUT_U32("kind", pi.kind); PUT_U32("ipl", pi.ipl); PUT_U32("ls", pi.ls); PUT_U32("x", pi.x);
     PUT_U32("jsplit", pi.jsplit); PUT_U32("jPerSplit", pi.j_per_split);
     PUT_U32("sym", pi.sym); PUT_U32("symRows", pi.sym_np); PUT_U32("symLayers", pi.sym_layers);
+    PUT_U32("symUnitsPerSweep", pi.sym_ups); PUT_U32("symSpillRows", pi.sym_spill_rows);
 #undef PUT_U32
     napi_create_double(env, 3.0 * (cfg.precision == NB_F64 ? 8.0 : 4.0) * (double)pi.sym_np * (double)pi.sym_layers, &v);
     napi_set_named_property(env, o, "layerBytes", v);

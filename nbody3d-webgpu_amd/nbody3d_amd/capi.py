@@ -448,6 +448,24 @@ class Simulation:
         self._check(self._L.nb_diagnostics(self._h, out))
         return out[0], out[1], np.array(out[2:5])
 
+    def energy_drift(self, steps, every):
+        """Runs ``steps`` steps (parameters as set) and samples the total energy every ``every`` steps with the bookkeeping of
+        SURVEY.md §8(c): the stored velocity lags the positions by one call (nbody3d.js:278-283), so KE(vel after call n) pairs
+        with PE(positions BEFORE call n); E0 pairs the uploaded state.  Returns [|E_n - E0| / |E0|] at the sampled steps."""
+        ke0, pe0, _ = self.diagnostics()
+        e0 = ke0 + pe0
+        out, done = [], 0
+        while done < steps:
+            k = min(int(every), steps - done)
+            if k > 1:
+                self.simulate(k - 1)
+            _, pe_prev, _ = self.diagnostics()
+            self.step()
+            ke, _, _ = self.diagnostics()
+            done += k
+            out.append(abs((ke + pe_prev - e0) / e0))
+        return out
+
 
 class MultiSimulation:
     """Single-process multi-device handle (nb_multi_*): n_shards i-shards, one per

@@ -437,3 +437,25 @@ def test_f64_multi_handle_takes_the_rank_form(n, g):
         one.init(b, v)
         one.simulate(4, 1e-3, 1.0)
         assert rel_pos_err(got[0], one.read()[0], 1.0) < 1e-12
+
+
+def test_energy_horizon_f32_against_f64():
+    """BASELINE config 5 ("long-horizon energy conservation vs fp32") where the driver sees it: the same N = 65,536 Plummer sphere
+    through the f32 and the f64 engine, 400 steps at dt = 1e-3, energy sampled on the device every 50 steps (KE after call n with
+    PE before it).  The leapfrog's own truncation dominates both: the drifts stay below 1e-6, agree within 2x,
+    and the f32 positions stay within 2e-5 of the f64 ones.  (2,000 steps at N = 262,144: profiles/r03/energy_horizon_*.json,
+    1.575e-7 vs 1.569e-7.)"""
+    n, steps, every = 65536, 400, 50
+    b, v = ic.plummer(n, seed=1)
+    drift, final = {}, {}
+    for prec, dt_np in (("f32", np.float32), ("f64", np.float64)):
+        with Simulation(n, precision=prec) as sim:
+            sim.init(b.astype(dt_np), v.astype(dt_np))
+            sim.set_params(1e-3, 1.0)
+            drift[prec] = sim.energy_drift(steps, every)
+            final[prec] = sim.read(vel=False, accel=False)[0]
+            assert "symw" in sim.variant, sim.variant
+    m32, m64 = max(drift["f32"]), max(drift["f64"])
+    assert len(drift["f32"]) == steps // every and m32 < 1e-6 and m64 < 1e-6, (m32, m64)
+    assert 0.5 * m64 < m32 < 2.0 * m64, (m32, m64)
+    assert rel_pos_err(final["f32"], final["f64"], 1.0) < 2e-5
