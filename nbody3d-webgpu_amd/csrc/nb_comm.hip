@@ -340,25 +340,20 @@ int nb_multi_create(const nb_config* cfg_in, uint32_t n_shards, const int32_t* d
         if (rc != NB_OK) { std::string e = nbi::create_error(); nb_multi_destroy(m); return mfail(nullptr, rc, "nb_multi_create: shard " + std::to_string(k) + ": " + e); }
         m->shard.push_back(s);
     }
-    // peer access between every pair of distinct devices (ignore "already enabled")
+    // Peer access between every pair of distinct devices.  The pull kernels (nb_peer_sum / nb_peer_gather) dereference the other
+    // shards' arrays directly, so they are only used when EVERY ordered pair of devices is accessible AND was enabled (success or
+    // "already enabled"); any other outcome keeps the hipMemcpyAsync / staging path, which needs no mapping.
+    m->pull = n_shards <= 16;
     for (uint32_t a = 0; a < n_shards; ++a)
         for (uint32_t b = 0; b < n_shards; ++b) {
             const int da = m->shard[a]->device, db = m->shard[b]->device;
             if (da == db) continue;
             int can = 0;
-            if (hipDeviceCanAccessPeer(&can, da, db) == hipSuccess && can) {
-                (void)hipSetDevice(da);
-                hipError_t e = hipDeviceEnablePeerAccess(db, 0);
-                if (e != hipSuccess) (void)hipGetLastError();   // hipErrorPeerAccessAlreadyEnabled is fine
-            }
-        }
-    // pull kernels need every shard's memory mapped on every other shard's device
-    m->pull = n_shards <= 16;
-    for (uint32_t a = 0; a < n_shards && m->pull; ++a)
-        for (uint32_t b = 0; b < n_shards; ++b) {
-            const int da = m->shard[a]->device, db = m->shard[b]->device;
-            int can = 1;
-            if (da != db && (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can)) { m->pull = false; break; }
+            if (hipDeviceCanAccessPeer(&can, da, db) != hipSuccess || !can) { (void)hipGetLastError(); m->pull = false; continue; }
+            hipError_t e = hipSetDevice(da);
+            if (e == hipSuccess) e = hipDeviceEnablePeerAccess(db, 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); e = hipSuccess; }
+            if (e != hipSuccess) { (void)hipGetLastError(); m->pull = false; }
         }
     m->ev_k2.resize(n_shards); m->ev_copied.resize(n_shards);
     m->sym = want_sym;

@@ -6,8 +6,13 @@
 # no further GPU step is started after a kill.
 set -u
 mkdir -p gpurun_out
+# A leg that times out (124 / 137) or dies on a signal (rc >= 128: 134 / 139 is how a GPU memory fault or an abort surfaces) ends the
+# pass at once -- no further GPU leg is started after a kill or a fault -- and any failing leg makes the script exit non-zero.
+FAILED=0
 step() { local name=$1 to=$2; shift 2; echo "== $name: $*"; timeout -k 10 "$to" "$@" > "gpurun_out/$name.txt" 2>&1; local rc=$?
-         echo "== $name rc=$rc"; if [ $rc -eq 124 ] || [ $rc -eq 137 ]; then echo "TIMEOUT in $name"; tail -5 "gpurun_out/$name.txt"; exit 1; fi; return 0; }
+         echo "== $name rc=$rc"
+         if [ $rc -ge 124 ]; then echo "TIMEOUT / SIGNAL in $name (rc=$rc): stopping the pass"; tail -5 "gpurun_out/$name.txt"; exit 1; fi
+         if [ $rc -ne 0 ]; then FAILED=1; fi; return 0; }
 while [ $# -gt 0 ]; do
   leg=$1; shift
   case $leg in
@@ -24,3 +29,4 @@ while [ $# -gt 0 ]; do
     *) echo "unknown leg $leg"; exit 2 ;;
   esac
 done
+exit $FAILED
