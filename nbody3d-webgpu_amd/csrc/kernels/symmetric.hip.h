@@ -243,7 +243,7 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             if (tb >= pl.nsb) tb -= pl.nsb;
             const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
             ++k;
-            if (tstart >= n) continue;   // a chunk of padding rows only (zero mass): exerts nothing, and nobody reads its sums
+            if (tstart >= n) continue;   // a chunk of padding rows only (zero mass): exerts nothing, and nobody reads its sums 
             float tx[J], ty[J], tz[J], tm[J];
             nb_f2 bx[J], by[J], bz[J];
             const uint32_t src = ((uint32_t)lane - s0) & 63u;        // the traveler this lane holds after s0 rotation steps
