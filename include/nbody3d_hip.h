@@ -354,6 +354,11 @@ typedef struct nb_plan_info {
   char variant[112];
   uint32_t sym_ups;        /* wave-granular symmetric pass: work units per chunk-sweep (1: whole sweeps; 4: quarter sweeps) */
   uint32_t sym_spill_rows; /* rows of the spill buffer (one row set per wave; 0 with whole sweeps) */
+  uint32_t sym_rank_plan[15]; /* rank form (sym_rank): np, nsb, total_hi, total_lo, n_hi, H, r_layer0, rb_layer0, t_layer0, g0, g1, LA, LB,
+                                 WA, WB -- phase A = the sweeps whose travelers are the rank's own rows (LA sweeps, waves [0, WA):
+                                 what an overlapped step issues before it waits for the all-gather), phase B the rest.  `tab` then
+                                 holds {first A wave, A waves, first B wave, B waves} per super-block (4 * nsb words) and the two
+                                 phases' prefix tables (g1 - g0 + 1 words each) */
 } nb_plan_info;
 int nb_plan_query(const nb_config *cfg, int n_cu, double clock_hz, nb_plan_info *out, uint32_t *tab,
                   uint32_t tab_cap);

@@ -424,6 +424,210 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
     }
 }
 
+// ---- the rank form's force kernels (nb::SymRankPlan, nb_plan.h): whole sweeps, one traveler per lane, two phases -------------
+// Waves [0, WA) sweep phase A (travelers = the rank's own rows), waves [WA, WA + WB) phase B; `wave0` / `wave_end` select the part
+// of them a launch runs (everything, or A before the wait for the all-gather and B after it).  A phase's sweeps are laid end to
+// end; prefix[gi] is where own super-block g0 + gi begins.
+__device__ __forceinline__ uint32_t rank_find(const uint32_t* __restrict__ prefix, uint32_t ng, uint32_t p)
+{
+    uint32_t lo = 0, hi = ng;                         // largest gi with prefix[gi] <= p  (prefix[ng] > p)
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (prefix[mid] <= p) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <int NG>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : 4)))
+void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ partial, const uint32_t* __restrict__ tab, const SymRankPlan pl,
+                        const uint32_t n, const float eps2, const uint32_t wave0, const uint32_t wave_end)
+{
+    constexpr uint32_t S = 128u * NG, CPS = S / 64u;
+    constexpr int GW = NG < 4 ? NG : 4;
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = wave0 + __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (w >= wave_end) return;
+    const bool phase_b = w >= pl.WA;
+    const uint32_t wl = phase_b ? w - pl.WA : w, Lp = phase_b ? pl.LB : pl.LA, Wp = phase_b ? pl.WB : pl.WA;
+    const uint32_t ng = pl.g1 - pl.g0;
+    const uint32_t* __restrict__ prefix = tab + 4 * pl.nsb + (phase_b ? ng + 1 : 0);
+    uint32_t p = (uint32_t)(((uint64_t)wl * Lp) / Wp);
+    const uint32_t pend = (uint32_t)(((uint64_t)(wl + 1) * Lp) / Wp);
+    const nb_f2 e2 = nb_f2{eps2, eps2};
+    while (p < pend) {
+        const uint32_t gi = rank_find(prefix, ng, p), g = pl.g0 + gi;
+        uint32_t j = p - prefix[gi];
+        const uint32_t len = prefix[gi + 1] - prefix[gi];
+        uint32_t jend = j + (pend - p);
+        if (jend > len) jend = len;
+        p += jend - j;
+        const uint32_t total = g < pl.n_hi ? pl.total_hi : pl.total_lo, ring = total - CPS;
+        uint32_t a = (pl.g1 - 1 - g) * CPS;                          // sweeps of g whose travelers are own rows
+        if (a > ring) a = ring;
+
+        nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
+        {
+            const float4* rb = bodies + (size_t)g * S + lane;
+#pragma unroll
+            for (int c = 0; c < NG; ++c) {
+                const float4 b0 = ld4(rb + (2 * c) * 64), b1 = ld4(rb + (2 * c + 1) * 64);
+                xi[c] = nb_f2{b0.x, b1.x}; yi[c] = nb_f2{b0.y, b1.y}; zi[c] = nb_f2{b0.z, b1.z}; mi[c] = nb_f2{b0.w, b1.w};
+                ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
+            }
+        }
+        for (; j < jend; ++j) {
+            const uint32_t k = phase_b ? a + j : (j < a ? j : ring + (j - a));       // position in g's list
+            const bool sym = k < ring;
+            const uint32_t d = k / CPS;
+            uint32_t tb = g + 1 + d;
+            if (tb >= pl.nsb) tb -= pl.nsb;
+            const uint32_t tstart = sym ? tb * S + (k % CPS) * 64u : g * S + (k - ring) * 64u;
+            if (tstart >= n) continue;
+            const float4 t = ld4(bodies + tstart + lane);
+            float tx = t.x, ty = t.y, tz = t.z, tm = t.w;
+            nb_f2 bx = nb_f2{0, 0}, by = nb_f2{0, 0}, bz = nb_f2{0, 0};
+            for (int st = 0; st < 64; ++st) {
+                const nb_f2 px = nb_f2{tx, tx}, py = nb_f2{ty, ty}, pz = nb_f2{tz, tz}, pm = nb_f2{tm, tm};
+#pragma unroll
+                for (int c0g = 0; c0g < NG; c0g += GW) {
+                    nb_f2 dx[GW], dy[GW], dz[GW], d2[GW], r[GW], si[GW], sj[GW];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) dx[c] = px - xi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) dy[c] = py - yi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) dz[c] = pz - zi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) r[c] = d2[c] * d2[c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) si[c] = pm * r[c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) sj[c] = mi[c0g + c] * r[c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) bx = __builtin_elementwise_fma(-sj[c], dx[c], bx);
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) by = __builtin_elementwise_fma(-sj[c], dy[c], by);
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) bz = __builtin_elementwise_fma(-sj[c], dz[c], bz);
+                }
+                tx = wave_rot1(tx); ty = wave_rot1(ty); tz = wave_rot1(tz); tm = wave_rot1(tm);
+                bx = nb_f2{wave_rot1(bx.x), wave_rot1(bx.y)};
+                by = nb_f2{wave_rot1(by.x), wave_rot1(by.y)};
+                bz = nb_f2{wave_rot1(bz.x), wave_rot1(bz.y)};
+            }
+            if (sym) partial[(size_t)(pl.t_layer0 + d) * pl.np + tstart + lane] = SymRow{bx.x + bx.y, by.x + by.y, bz.x + bz.y};
+        }
+        // resident sums of this wave's part of g's list in this phase
+        const uint32_t* gt = tab + 4 * g;
+        SymRow* out = partial + (size_t)(phase_b ? pl.rb_layer0 + (wl - gt[2]) : pl.r_layer0 + (wl - gt[0])) * pl.np + (size_t)g * S + lane;
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+            out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
+            out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
+        }
+    }
+}
+
+template <int IPL>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* __restrict__ partial, const uint32_t* __restrict__ tab,
+                          const SymRankPlan pl, const uint32_t n, const double G, const double eps2, const uint32_t wave0, const uint32_t wave_end)
+{
+    constexpr uint32_t S = 64u * IPL, CPS = S / 64u;
+    constexpr int GW = 4;
+    const int lane = threadIdx.x & 63;
+    const uint32_t w = wave0 + __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
+    if (w >= wave_end) return;
+    const bool phase_b = w >= pl.WA;
+    const uint32_t wl = phase_b ? w - pl.WA : w, Lp = phase_b ? pl.LB : pl.LA, Wp = phase_b ? pl.WB : pl.WA;
+    const uint32_t ng = pl.g1 - pl.g0;
+    const uint32_t* __restrict__ prefix = tab + 4 * pl.nsb + (phase_b ? ng + 1 : 0);
+    uint32_t p = (uint32_t)(((uint64_t)wl * Lp) / Wp);
+    const uint32_t pend = (uint32_t)(((uint64_t)(wl + 1) * Lp) / Wp);
+    while (p < pend) {
+        const uint32_t gi = rank_find(prefix, ng, p), g = pl.g0 + gi;
+        uint32_t j = p - prefix[gi];
+        const uint32_t len = prefix[gi + 1] - prefix[gi];
+        uint32_t jend = j + (pend - p);
+        if (jend > len) jend = len;
+        p += jend - j;
+        const uint32_t total = g < pl.n_hi ? pl.total_hi : pl.total_lo, ring = total - CPS;
+        uint32_t a = (pl.g1 - 1 - g) * CPS;
+        if (a > ring) a = ring;
+        double xi[IPL], yi[IPL], zi[IPL], mi[IPL], ax[IPL], ay[IPL], az[IPL];
+#pragma unroll
+        for (int c = 0; c < IPL; ++c) {
+            const double4 b = ld4(bodies + (size_t)g * S + c * 64 + lane);
+            xi[c] = b.x; yi[c] = b.y; zi[c] = b.z; mi[c] = b.w * G;
+            ax[c] = 0; ay[c] = 0; az[c] = 0;
+        }
+        for (; j < jend; ++j) {
+            const uint32_t k = phase_b ? a + j : (j < a ? j : ring + (j - a));
+            const bool sym = k < ring;
+            const uint32_t d = k / CPS;
+            uint32_t tb = g + 1 + d;
+            if (tb >= pl.nsb) tb -= pl.nsb;
+            const uint32_t tstart = sym ? tb * S + (k % CPS) * 64u : g * S + (k - ring) * 64u;
+            if (tstart >= n) continue;
+            const double4 t = ld4(bodies + tstart + lane);
+            double tx = t.x, ty = t.y, tz = t.z, tm = t.w * G, bx = 0, by = 0, bz = 0;
+            for (int st = 0; st < 64; ++st) {
+#pragma unroll
+                for (int c0g = 0; c0g < IPL; c0g += GW) {
+                    double dx[GW], dy[GW], dz[GW], d2[GW], y[GW], uu[GW];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) dx[c] = tx - xi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) dy[c] = ty - yi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) dz[c] = tz - zi[c0g + c];
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) d2[c] = nb_fma(dz[c], dz[c], nb_fma(dy[c], dy[c], nb_fma(dx[c], dx[c], eps2)));
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) y[c] = __builtin_amdgcn_rsq(d2[c]);
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) {
+                        const double y2 = y[c] * y[c];
+                        const double e = nb_fma(-d2[c], y2, 1.0);
+                        const double t3 = y[c] * y2;
+                        uu[c] = nb_fma(t3 * e, 1.5, t3);
+                    }
+#pragma unroll
+                    for (int c = 0; c < GW; ++c) {
+                        const double si = tm * uu[c], sj = mi[c0g + c] * uu[c];
+                        ax[c0g + c] = nb_fma(si, dx[c], ax[c0g + c]); ay[c0g + c] = nb_fma(si, dy[c], ay[c0g + c]); az[c0g + c] = nb_fma(si, dz[c], az[c0g + c]);
+                        bx = nb_fma(-sj, dx[c], bx); by = nb_fma(-sj, dy[c], by); bz = nb_fma(-sj, dz[c], bz);
+                    }
+                }
+                tx = wave_rot1(tx); ty = wave_rot1(ty); tz = wave_rot1(tz); tm = wave_rot1(tm);
+                bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz);
+            }
+            if (sym) partial[(size_t)(pl.t_layer0 + d) * pl.np + tstart + lane] = SymRowT<double>{bx, by, bz};
+        }
+        const uint32_t* gt = tab + 4 * g;
+        SymRowT<double>* out = partial + (size_t)(phase_b ? pl.rb_layer0 + (wl - gt[2]) : pl.r_layer0 + (wl - gt[0])) * pl.np + (size_t)g * S + lane;
+#pragma unroll
+        for (int c = 0; c < IPL; ++c) out[c * 64] = SymRowT<double>{ax[c], ay[c], az[c]};
+    }
+}
+
 // The RANK form of the pass (multi-GPU: rank r keeps the super-blocks [g0, g1) of its own rows resident and sweeps THEIR chunk
 // lists, so every unordered pair of the system is evaluated by exactly one rank): the traveler sums a rank produces belong
 // to bodies of other ranks as well.  This kernel adds up, for EVERY row of the system, what this rank has for it -- its
@@ -431,18 +635,19 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
 // nb_integrate_symw uses -- into one array A[np]; the ranks then reduce-scatter A (ncclReduceScatter, or peer copies + a
 // fixed-order sum in the single-process handle) and the plain integrate kernel reads the rank's rows of the result.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __restrict__ partial, const uint32_t* __restrict__ gtab,
-                                                       typename vec4<T>::type* __restrict__ A, const SymWPlan pl, uint32_t S, uint32_t g0, uint32_t g1)
+__global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __restrict__ partial, const uint32_t* __restrict__ tab,
+                                                       typename vec4<T>::type* __restrict__ A, const SymRankPlan pl, uint32_t S)
 {
     using SymRow = SymRowT<T>;
     using V4 = typename vec4<T>::type;
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= pl.np) return;
-    const uint32_t b = j / S;
+    const uint32_t b = j / S, g0 = pl.g0, g1 = pl.g1;
     T sx = 0, sy = 0, sz = 0;
-    if (b >= g0 && b < g1) {
-        const uint32_t nr = gtab[2 * b + 1];
-        for (uint32_t e = 0; e < nr; ++e) { const SymRow r = partial[(size_t)(pl.r_layer0 + e) * pl.np + j]; sx += r.x; sy += r.y; sz += r.z; }
+    if (b >= g0 && b < g1) {                                     // resident layers: phase A's waves, then phase B's
+        const uint32_t na = tab[4 * b + 1], nb_ = tab[4 * b + 3];
+        for (uint32_t e = 0; e < na; ++e) { const SymRow r = partial[(size_t)(pl.r_layer0 + e) * pl.np + j]; sx += r.x; sy += r.y; sz += r.z; }
+        for (uint32_t e = 0; e < nb_; ++e) { const SymRow r = partial[(size_t)(pl.rb_layer0 + e) * pl.np + j]; sx += r.x; sy += r.y; sz += r.z; }
     }
     if (g1 - g0 > pl.H) {
         for (uint32_t d = 0; d <= pl.H; ++d) {                   // few ring distances, many own super-blocks: ascending distance

@@ -124,6 +124,13 @@ const void* sgpr_kernel(int ipl, int ws)
     return nullptr;
 }
 
+// The rank form's force kernel (two phases: nb::SymRankPlan); ipl = residents per lane.
+const void* rank_kernel_of(bool f64, int ipl)
+{
+    if (f64) return ipl == 8 ? (const void*)&nb::nb_force_symw64_rank<8> : nullptr;
+    return ipl == 16 ? (const void*)&nb::nb_force_symw_rank<8> : ipl == 8 ? (const void*)&nb::nb_force_symw_rank<4> : nullptr;
+}
+
 // The kernel a shape launches (nullptr: no such instantiation).
 const void* kernel_of(bool f64, const Shape& sh)
 {
@@ -173,6 +180,8 @@ void plan_handle(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz, dou
     s->sym_np = p.sym_np; s->sym_layers = p.sym_layers; s->sym_g0 = p.sym_g0; s->sym_g1 = p.sym_g1;
     static_assert(sizeof(s->sym_plan) == sizeof(p.sym_plan), "nb_sim::sym_plan mirrors LaunchPlan::sym_plan");
     memcpy(s->sym_plan, p.sym_plan, sizeof s->sym_plan);
+    static_assert(sizeof(s->sym_rank_plan) == sizeof(p.sym_rank_plan), "nb_sim::sym_rank_plan mirrors LaunchPlan::sym_rank_plan");
+    memcpy(s->sym_rank_plan, p.sym_rank_plan, sizeof s->sym_rank_plan);
     s->sym_tab_host = std::move(p.sym_tab_host);
     s->sym_spill_rows = p.sym_spill_rows;
     s->variant = std::move(p.variant);
@@ -230,6 +239,27 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
 {
     using V4 = typename nb::vec4<T>::type;
     const Shape sh = shape_of(s);
+    if (s->sym_rank) {
+        // part 0: every wave; 1: phase A (travelers = own rows; nothing of the other ranks is read); 2: phase B
+        nb::SymRankPlan rp;
+        memcpy(&rp, s->sym_rank_plan, sizeof rp);
+        uint32_t w0 = part == 2 ? rp.WA : 0u, w1 = part == 1 ? rp.WA : rp.WA + rp.WB;
+        if (w1 <= w0) return;
+        const void* b = jstream(s, s->cur);
+        void* p = s->partial;
+        const uint32_t* tab = s->sym_tab;
+        uint32_t n = s->n;
+        if (s->f64) {
+            double G = s->G, e2 = s->eps2;
+            void* args[] = {&b, &p, &tab, &rp, &n, &G, &e2, &w0, &w1};
+            launch_kernel(rank_kernel_of(true, sh.ipl), dim3(ceil_div(w1 - w0, 4u)), dim3(256), args, s->stream, t0, t1);
+        } else {
+            float e2 = (float)s->eps2;
+            void* args[] = {&b, &p, &tab, &rp, &n, &e2, &w0, &w1};
+            launch_kernel(rank_kernel_of(false, sh.ipl), dim3(ceil_div(w1 - w0, 4u)), dim3(256), args, s->stream, t0, t1);
+        }
+        return;
+    }
     if (s->symw) {
         nb::SymWPlan pl;
         memcpy(&pl, s->sym_plan, sizeof pl);
@@ -471,27 +501,33 @@ namespace nbi {
 // Rank form of the symmetric pass, first half of a step: the force pass over the chunk lists of the handle's own super-blocks,
 // then this rank's sums for every row of the system into sym_A.
 template <typename T>
-int sym_rank_phase_a_t(nb_sim* s, hipEvent_t after_force)
+int sym_rank_phase_a_t(nb_sim* s, hipEvent_t after_force, bool split_at_gather)
 {
     using V4 = typename nb::vec4<T>::type;
-    launch_force<T>(s);
+    if (split_at_gather) {
+        launch_force<T>(s, 1);                        // own-row travelers: needs nothing from the other ranks
+        if (int rc = finish_gather(s)) return rc;     // the engine stream waits for their rows here
+        launch_force<T>(s, 2);
+    } else {
+        launch_force<T>(s);
+    }
     if (after_force) NB_HIP(s, hipEventRecord(after_force, s->stream));
-    nb::SymWPlan pl;
-    memcpy(&pl, s->sym_plan, sizeof pl);
+    nb::SymRankPlan rp;
+    memcpy(&rp, s->sym_rank_plan, sizeof rp);
     const nb::SymRowT<T>* p = (const nb::SymRowT<T>*)s->partial;
     const uint32_t* tab = s->sym_tab;
     V4* A = (V4*)s->sym_A;
-    uint32_t S = ipb_of(shape_of(s)), g0 = s->sym_g0, g1 = s->sym_g1;
-    void* args[] = {&p, &tab, &A, &pl, &S, &g0, &g1};
-    NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_sym_reduce<T>, dim3(ceil_div(pl.np, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
+    uint32_t S = ipb_of(shape_of(s));
+    void* args[] = {&p, &tab, &A, &rp, &S};
+    NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_sym_reduce<T>, dim3(ceil_div(rp.np, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
     return NB_OK;
 }
 
-int sym_rank_phase_a(nb_sim* s, void* after_force)
+int sym_rank_phase_a(nb_sim* s, void* after_force, bool split_at_gather)
 {
     if (!s->sym_rank) return fail(s, NB_ERR_STATE, "sym_rank_phase_a: not a rank-form handle");
     if (int rc = ensure_gm(s)) return rc;
-    return s->f64 ? sym_rank_phase_a_t<double>(s, (hipEvent_t)after_force) : sym_rank_phase_a_t<float>(s, (hipEvent_t)after_force);
+    return s->f64 ? sym_rank_phase_a_t<double>(s, (hipEvent_t)after_force, split_at_gather) : sym_rank_phase_a_t<float>(s, (hipEvent_t)after_force, split_at_gather);
 }
 
 template <typename T>
@@ -777,11 +813,14 @@ int nb_step(nb_sim* s, uint32_t nsteps)
             // rank form of the symmetric pass: force pass -> this rank's sums for every row -> reduce-scatter across the ranks
             // -> integrate own rows -> all-gather of the new positions
             if (!s->rccl) return fail(s, NB_ERR_STATE, "nb_step: an NB_FLAG_SYM_SHARD handle needs nb_rccl_attach (or nb_multi) for its reduce-scatter");
-            if (int rc = finish_gather(s)) return rc;
+            // an overlapped all-gather of the previous step still in flight: the sweeps whose travelers are this rank's own rows
+            // (phase A, ~1 / ranks of the work) are issued before the engine stream waits for it
+            const bool split = s->gather_pending;
+            if (!split) { if (int rc = finish_gather(s)) return rc; }
             nb_events evr;
             const bool recr = s->timing && get_events(s, &evr) == 0;
             if (recr) NB_HIP(s, hipEventRecord(evr.e[0], s->stream));
-            if (int rc = nbi::sym_rank_phase_a(s, recr ? evr.e[7] : nullptr)) return rc;
+            if (int rc = nbi::sym_rank_phase_a(s, recr ? evr.e[7] : nullptr, split)) return rc;
             if (recr) { NB_HIP(s, hipEventRecord(evr.e[1], s->stream)); evr.rs = true; }
             if (int rc = nbi::rccl_reduce_scatter_A(s)) return rc;
             if (recr) NB_HIP(s, hipEventRecord(evr.e[6], s->stream));
@@ -789,7 +828,7 @@ int nb_step(nb_sim* s, uint32_t nsteps)
             if (recr) NB_HIP(s, hipEventRecord(evr.e[2], s->stream));
             NB_HIP(s, hipGetLastError());
             if (int rc = nbi::rccl_exchange_begin(s)) return rc;
-            if (nbi::rccl_overlapped(s)) { s->gather_pending = true; if (int rc2 = finish_gather(s)) return rc2; }
+            if (nbi::rccl_overlapped(s)) s->gather_pending = true;        // waited for inside the next force pass (or by whoever reads the positions first)
             else if (recr) { NB_HIP(s, hipEventRecord(evr.e[5], s->stream)); evr.xchg = true; }
             if (recr) s->pending.push_back(evr);
             continue;
@@ -1055,6 +1094,8 @@ int nb_plan_query(const nb_config* cfg_in, int n_cu, double clock_hz, nb_plan_in
     memcpy(out->sym_plan, tmp.sym_plan, sizeof out->sym_plan);
     out->sym_ups = tmp.symw ? tmp.sym_plan[11] : 0;
     out->sym_spill_rows = tmp.sym_spill_rows;
+    static_assert(sizeof(out->sym_rank_plan) == sizeof(tmp.sym_rank_plan), "nb_plan_info::sym_rank_plan mirrors nb_sim::sym_rank_plan");
+    memcpy(out->sym_rank_plan, tmp.sym_rank_plan, sizeof out->sym_rank_plan);
     out->tab_len = (uint32_t)tmp.sym_tab_host.size();
     snprintf(out->variant, sizeof out->variant, "%s", tmp.variant.c_str());
     if (tab) memcpy(tab, tmp.sym_tab_host.data(), sizeof(uint32_t) * (out->tab_len < tab_cap ? out->tab_len : tab_cap));

@@ -104,6 +104,7 @@ struct nb_sim {
     // scattered across the ranks before the integrate kernel reads the rank's own rows of it
     bool sym_rank = false;
     uint32_t sym_g0 = 0, sym_g1 = 0;
+    uint32_t sym_rank_plan[15] = {0};   // nb::SymRankPlan: the two phases (own-row travelers first), their wave counts and layer bases
     void* sym_A = nullptr;
     std::string variant, err;
     nb_exchange_fn xfn = nullptr;
@@ -147,7 +148,9 @@ int rccl_exchange_begin(nb_sim* s);
 // rank form of the symmetric pass: in-place ncclReduceScatter of sym_A on the engine stream (this rank's rows receive the sum)
 int rccl_reduce_scatter_A(nb_sim* s);
 // the two halves of a rank-form step, for nb_multi (which runs its own reduce-scatter between them)
-int sym_rank_phase_a(nb_sim* s, void* after_force = nullptr);     // force pass [+ a record of the hipEvent_t `after_force`] + nb_sym_reduce
+// force pass [+ a record of the hipEvent_t `after_force`] + nb_sym_reduce.  split_at_gather: the sweeps whose travelers are the rank's
+// own rows are launched first, then the engine stream waits for the pending all-gather, then the rest (bit-identical to one launch)
+int sym_rank_phase_a(nb_sim* s, void* after_force = nullptr, bool split_at_gather = false);
 int sym_rank_phase_b(nb_sim* s);     // integrate kernel on the handle's rows of sym_A
 int rccl_exchange_wait(nb_sim* s);
 bool rccl_overlapped(const nb_sim* s);

@@ -301,6 +301,73 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, u
     name_variant(s, f64, sh);
 }
 
+// Rank form (NB_FLAG_SYM_SHARD): the handle's own super-blocks [sb / S, (sb + sc) / S), their lists split into the sweeps whose
+// travelers are own rows (phase A) and the rest (phase B); see nb::SymRankPlan.
+static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, uint32_t sb, uint32_t sc, const nb_config& cfg, int n_cu)
+{
+    const uint32_t S = ipb_of(sh), cps = S / 64u;                    // one traveler per lane
+    const uint32_t nsb = ceil_div(n, S), H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
+    nb::SymRankPlan rp;
+    rp.np = nsb * S; rp.nsb = nsb;
+    rp.total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps; rp.total_lo = (H + 1) * cps;
+    rp.n_hi = n_hi; rp.H = H;
+    rp.g0 = sb / S; rp.g1 = (sb + sc) / S;
+    const uint32_t ng = rp.g1 - rp.g0;
+    std::vector<uint32_t> preA(ng + 1, 0), preB(ng + 1, 0);
+    for (uint32_t gi = 0; gi < ng; ++gi) {
+        const uint32_t g = rp.g0 + gi;
+        const uint32_t total = g < n_hi ? rp.total_hi : rp.total_lo, ring = total - cps;
+        const uint32_t a = std::min(ring, (rp.g1 - 1 - g) * cps);       // ring distances d with g + 1 + d < g1: travelers inside the own rows
+        preA[gi + 1] = preA[gi] + a + cps;                               // ... and the super-block's own chunks (resident-only)
+        preB[gi + 1] = preB[gi] + (ring - a);
+    }
+    rp.LA = preA[ng]; rp.LB = preB[ng];
+    const uint32_t L = rp.LA + rp.LB;
+    const uint32_t kw = cfg.jsplit ? cfg.jsplit : (L >= 16u * (uint32_t)n_cu ? 2u : 1u);
+    const uint32_t Wfull = 4u * (uint32_t)n_cu * kw;
+    rp.WA = std::min(Wfull, rp.LA);                                      // never more waves than sweeps: every wave has work
+    rp.WB = std::min(Wfull, rp.LB);
+    // {first wave, waves} of every own super-block in each phase; B waves counted from 0 (the kernel adds WA)
+    s->sym_tab_host.assign(4 * (size_t)nsb + 2 * ((size_t)ng + 1), 0);
+    uint32_t max_ra = 1, max_rb = 0;
+    auto wave_of = [](uint64_t p, uint32_t Lp, uint32_t Wp) {
+        uint32_t w = (uint32_t)(p * Wp / Lp);
+        while (w + 1 < Wp && (uint64_t)(w + 1) * Lp / Wp <= p) ++w;
+        while (w > 0 && (uint64_t)w * Lp / Wp > p) --w;
+        return w;
+    };
+    for (uint32_t gi = 0; gi < ng; ++gi) {
+        uint32_t* t = &s->sym_tab_host[4 * (size_t)(rp.g0 + gi)];
+        const uint32_t fa = wave_of(preA[gi], rp.LA, rp.WA), la = wave_of(preA[gi + 1] - 1, rp.LA, rp.WA);
+        t[0] = fa; t[1] = la - fa + 1;
+        max_ra = std::max(max_ra, t[1]);
+        if (preB[gi + 1] > preB[gi]) {
+            const uint32_t fb = wave_of(preB[gi], rp.LB, rp.WB), lb = wave_of(preB[gi + 1] - 1, rp.LB, rp.WB);
+            t[2] = fb; t[3] = lb - fb + 1;
+            max_rb = std::max(max_rb, t[3]);
+        }
+    }
+    std::copy(preA.begin(), preA.end(), s->sym_tab_host.begin() + 4 * (size_t)nsb);
+    std::copy(preB.begin(), preB.end(), s->sym_tab_host.begin() + 4 * (size_t)nsb + ng + 1);
+    rp.r_layer0 = 0; rp.rb_layer0 = max_ra; rp.t_layer0 = max_ra + max_rb;
+    static_assert(sizeof(rp) == sizeof(s->sym_rank_plan), "LaunchPlan::sym_rank_plan holds a SymRankPlan");
+    memcpy(s->sym_rank_plan, &rp, sizeof rp);
+    // the SymWPlan summary the reduction kernel and the reports read
+    nb::SymWPlan pl;
+    pl.np = rp.np; pl.nsb = nsb; pl.W = rp.WA + rp.WB; pl.total_hi = rp.total_hi; pl.total_lo = rp.total_lo; pl.n_hi = n_hi; pl.H = H;
+    pl.r_layer0 = 0; pl.t_layer0 = rp.t_layer0; pl.L = L; pl.ups = 1;
+    pl.p0 = (rp.g0 <= n_hi ? rp.g0 * rp.total_hi : n_hi * rp.total_hi + (rp.g0 - n_hi) * rp.total_lo);
+    memcpy(s->sym_plan, &pl, sizeof pl);
+    s->sym_spill_rows = 0;
+    s->sym_rank = true; s->sym_g0 = rp.g0; s->sym_g1 = rp.g1;
+    s->sym = true; s->symw = true; s->sym_np = rp.np; s->sym_layers = rp.t_layer0 + H + (n_hi ? 1u : 0u);
+    s->ipl = sh.ipl; s->ls = 1; s->packed = !f64; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
+    s->ws = sh.x; s->tl = 1;
+    s->jsplit = rp.WA + rp.WB; s->j_per_split = ceil_div(L, std::max(1u, rp.WA + rp.WB)) * 64u; s->swap_acc = false;
+    s->own_split0 = 0; s->own_splits = rp.WA;          // the waves whose sweeps read the rank's own rows only: issued before the wait for the gather
+    name_variant(s, f64, sh);
+}
+
 // Workgroup form (nb_force_sym<4,4,2>, the A/B arm): Q segments per super-block's chunk list.
 static void lay_out_sym_wg(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, const nb_config& cfg, int n_cu)
 {
@@ -539,7 +606,8 @@ LaunchPlan plan_launch(const PlanInput& in)
         if (js < 1) js = 1;
     }
     if (sh.kind == kFused || sh.kind == kDirect) js = 1;
-    if (sh.kind == kSym && sh.x != 4) { lay_out_symw(s, sh, f64, n, sb, sc, cfg, n_cu, rank_ipl, sym_k, sym_ups); return plan; }
+    if (sh.kind == kSym && rank_ipl) { lay_out_symw_rank(s, sh, f64, n, sb, sc, cfg, n_cu); return plan; }
+    if (sh.kind == kSym && sh.x != 4) { lay_out_symw(s, sh, f64, n, sb, sc, cfg, n_cu, 0, sym_k, sym_ups); return plan; }
     if (sh.kind == kSym) { lay_out_sym_wg(s, sh, f64, n, cfg, n_cu); return plan; }
     s->ipl = sh.ipl; s->ls = sh.ls;
     s->packed = sh.kind != kScalar; s->sgpr = sh.kind == kPkSgpr;

@@ -40,6 +40,24 @@ struct SymWPlan {
                                 // spill lists that follow the {first wave, count} table: {offset, count} per traveler chunk, then
                                 // the wave numbers
 };
+// The rank form of the pass (NB_FLAG_SYM_SHARD: the handle keeps the super-blocks [g0, g1) of its own rows resident and sweeps THEIR
+// chunk lists), in TWO phases so that the part that needs nothing from the other ranks can run while their rows are still on the
+// wire (NB_RCCL_OVERLAP):
+//   phase A  the sweeps whose travelers are the rank's OWN rows: ring targets g + 1 + d < g1, and the resident-only sweeps of
+//            each super-block's own chunks -- about 1 / ranks of the work;
+//   phase B  the rest: travelers from the other ranks' rows.
+// Each phase lays its sweeps end to end (prefixA / prefixB: first position of every own super-block's part) and cuts them into its
+// own WA / WB floor/ceil-equal wave ranges; waves [0, WA) run phase A, [WA, WA + WB) phase B -- in ONE launch, or in two with the
+// wait for the all-gather between them: the same waves do the same sweeps either way, so the results are bit-identical.
+// A wave's resident sums of super-block g go to layer r_layer0 + (wave - first A wave of g) or rb_layer0 + (wave - first B wave of g);
+// table: {first A wave, A waves, first B wave (counted from WA), B waves} per super-block, then prefixA[g1 - g0 + 1], prefixB[g1 - g0 + 1].
+struct SymRankPlan {
+    uint32_t np, nsb;
+    uint32_t total_hi, total_lo, n_hi, H;
+    uint32_t r_layer0, rb_layer0, t_layer0;
+    uint32_t g0, g1;
+    uint32_t LA, LB, WA, WB;
+};
 }  // namespace nb
 
 namespace nbp {
@@ -78,6 +96,7 @@ struct LaunchPlan {
     uint32_t sym_np = 0, sym_layers = 0, sym_g0 = 0, sym_g1 = 0;
     uint32_t sym_plan[12] = {0};         // nb::SymWPlan (symw) or nb::SymPlan, as plain words
     uint32_t sym_spill_rows = 0;         // wave-granular form with ups > 1: rows of the spill buffer (W x travelers per chunk)
+    uint32_t sym_rank_plan[15] = {0};    // rank form: nb::SymRankPlan as plain words (sym_plan then holds the SymWPlan summary: W = WA + WB, L = LA + LB)
     std::vector<uint32_t> sym_tab_host;  // wave-granular form: {first wave, wave count} per super-block [2 nsb words]; with ups > 1
                                          // followed by {offset, count} per traveler chunk [2 np / CH words] and the spill lists' wave numbers
     std::string variant;

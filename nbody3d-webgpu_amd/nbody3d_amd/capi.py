@@ -57,7 +57,7 @@ class nb_plan_info(C.Structure):
         "kind", "ipl", "ls", "x", "jsplit", "j_per_split", "own_split0", "own_splits",
         "sym", "symw", "sym_rank", "sym_np", "sym_layers", "sym_g0", "sym_g1")] + [
         ("sym_plan", C.c_uint32 * 11), ("tab_len", C.c_uint32), ("variant", C.c_char * 112),
-        ("sym_ups", C.c_uint32), ("sym_spill_rows", C.c_uint32)]
+        ("sym_ups", C.c_uint32), ("sym_spill_rows", C.c_uint32), ("sym_rank_plan", C.c_uint32 * 15)]
 
 
 class nb_step_timing(C.Structure):          # include/nbody3d_hip.h
@@ -172,6 +172,7 @@ def _ptr(a):
 
 
 SYMW_PLAN_WORDS = ("np", "nsb", "W", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "t_layer0", "L", "p0")
+SYM_RANK_PLAN_WORDS = ("np", "nsb", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "rb_layer0", "t_layer0", "g0", "g1", "LA", "LB", "WA", "WB")
 SYM_PLAN_WORDS = ("np", "nsb", "q", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "t_layer0")
 
 
@@ -205,7 +206,17 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
     if info.sym:
         out["plan"] = dict(zip(SYMW_PLAN_WORDS if info.symw else SYM_PLAN_WORDS, (int(w) for w in info.sym_plan)))
         nsb = out["plan"]["nsb"]
-        out["tab"] = tab[:2 * nsb].reshape(-1, 2)
+        if info.sym_rank:
+            # the rank form: two phases (own-row travelers first), {first A wave, A waves, first B wave, B waves} per super-block
+            rp = dict(zip(SYM_RANK_PLAN_WORDS, (int(w) for w in info.sym_rank_plan)))
+            ng = rp["g1"] - rp["g0"]
+            out["rank_plan"] = rp
+            out["rank_tab"] = tab[:4 * nsb].reshape(-1, 4)
+            out["prefix_a"] = tab[4 * nsb:4 * nsb + ng + 1]
+            out["prefix_b"] = tab[4 * nsb + ng + 1:4 * nsb + 2 * (ng + 1)]
+            out["tab"] = out["rank_tab"][:, :2]
+        else:
+            out["tab"] = tab[:2 * nsb].reshape(-1, 2)
         out["ups"], out["spill_rows"] = int(info.sym_ups), int(info.sym_spill_rows)
         if info.symw:
             out["plan"]["ups"] = int(info.sym_ups)

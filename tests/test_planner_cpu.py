@@ -186,16 +186,48 @@ def test_workgroup_form_plan(n, jsplit):
     assert pl["t_layer0"] == Q and q["sym_layers"] == Q + H + (1 if n_hi else 0)
 
 
+def walk_rank(q, n):
+    """The two phases of a rank-form plan as the kernel walks them: {phase: (g, k, wave)} arrays over the phase's positions."""
+    rp, S = q["rank_plan"], 64 * q["ipl"]
+    cps = S // 64
+    g0, g1, ng = rp["g0"], rp["g1"], rp["g1"] - rp["g0"]
+    out = {}
+    for phase, L, W, pre in (("A", rp["LA"], rp["WA"], q["prefix_a"]), ("B", rp["LB"], rp["WB"], q["prefix_b"])):
+        assert len(pre) == ng + 1 and pre[0] == 0 and pre[-1] == L and np.all(np.diff(pre.astype(np.int64)) >= 0)
+        if L == 0:
+            assert W == 0
+            out[phase] = (np.zeros(0, np.int64),) * 3
+            continue
+        assert 1 <= W <= L
+        p = np.arange(L, dtype=np.int64)
+        gi = np.searchsorted(pre.astype(np.int64), p, side="right") - 1
+        g = g0 + gi
+        j = p - pre[gi]
+        total = np.where(g < rp["n_hi"], rp["total_hi"], rp["total_lo"])
+        ring = total - cps
+        a = np.minimum(ring, (g1 - 1 - g) * cps)
+        k = (a + j) if phase == "B" else np.where(j < a, j, ring + (j - a))
+        assert np.all(k < total)
+        starts = (np.arange(W + 1, dtype=np.int64) * L) // W
+        assert np.diff(starts).min() >= 1 and np.diff(starts).max() - np.diff(starts).min() <= 1
+        w = np.searchsorted(starts, p, side="right") - 1
+        out[phase] = (g, k, w)
+    return out
+
+
 @pytest.mark.parametrize("n,g,prec", [(8192, 2, "f32"), (65536, 8, "f32"), (262144, 8, "f32"), (262144, 3, "f32"), (1048576, 8, "f32"),
                                      (16384, 4, "f64"), (262144, 8, "f64")])
 def test_rank_form_plans_tile_the_pair_list(n, g, prec):
-    """NB_FLAG_SYM_SHARD: rank r sweeps the chunk lists of its own super-blocks only; the ranks' ranges follow one another
-    and together are the whole system's list -- so the union evaluates every unordered pair exactly once."""
+    """NB_FLAG_SYM_SHARD: rank r sweeps the chunk lists of its own super-blocks only -- the ranks together evaluate every unordered
+    pair exactly once -- in two phases: A = the sweeps whose travelers are the rank's OWN rows (what an overlapped step issues before
+    it waits for the all-gather), B = the rest."""
     align = 512 if prec == "f64" else 1024
     rows = -(-(-(-n // g)) // align) * align
-    whole = capi.plan_query(n, precision=prec, force_variant=(708013 if prec == "f64" else 716013), jsplit=1)
+    whole = capi.plan_query(n, precision=prec, force_variant=(708013 if prec == "f64" else 716013), jsplit=1, flags=NB_FLAG_WHOLE_SWEEPS)
     assert whole["symw"]
-    end = 0
+    wpl = whole["plan"]
+    seen = np.zeros(wpl["L"], np.int32)                      # every position of the whole system's list, by (g, k)
+    off = lambda gg: np.where(gg <= wpl["n_hi"], gg * wpl["total_hi"], wpl["n_hi"] * wpl["total_hi"] + (gg - wpl["n_hi"]) * wpl["total_lo"])
     for r in range(g):
         b = min(r * rows, n)
         cnt = min(rows, n - b)
@@ -203,20 +235,40 @@ def test_rank_form_plans_tile_the_pair_list(n, g, prec):
             continue
         q = capi.plan_query(n, precision=prec, shard=(b, cnt), flags=NB_FLAG_SYM_SHARD)
         assert q["sym_rank"] and "symwrank" in q["variant"], q["variant"]
-        pl = q["plan"]
-        assert {k: pl[k] for k in ("np", "nsb", "total_hi", "total_lo", "n_hi", "H")} == {k: whole["plan"][k] for k in ("np", "nsb", "total_hi", "total_lo", "n_hi", "H")}
-        assert pl["p0"] == end
-        end = pl["p0"] + pl["L"]
+        rp, pl = q["rank_plan"], q["plan"]
+        assert {k: rp[k] for k in ("np", "nsb", "total_hi", "total_lo", "n_hi", "H")} == {k: wpl[k] for k in ("np", "nsb", "total_hi", "total_lo", "n_hi", "H")}
         S = 64 * q["ipl"]
-        assert q["sym_g0"] == b // S and q["sym_g1"] == (b + cnt) // S
-        wk = walk_symw(q, n, rank=True)
-        assert wk["ups"] == 1 and q["spill_rows"] == 0                                     # a rank keeps whole sweeps (nb_sym_reduce knows no spill rows)
-        assert wk["g"].min() == q["sym_g0"] and wk["g"].max() == q["sym_g1"] - 1         # only its own super-blocks are resident
-        for sb in range(q["sym_g0"], q["sym_g1"]):
-            ws = np.unique(wk["w"][wk["g"] == sb])
-            assert ws[0] == q["tab"][sb, 0] and len(ws) == q["tab"][sb, 1]
-        assert q["tab"][:, 1].max() == pl["t_layer0"]
-    assert end == whole["plan"]["L"]
+        cps = S // 64
+        assert rp["g0"] == q["sym_g0"] == b // S and rp["g1"] == q["sym_g1"] == (b + cnt) // S
+        assert pl["L"] == rp["LA"] + rp["LB"] and pl["W"] == rp["WA"] + rp["WB"] and pl["ups"] == 1 and q["spill_rows"] == 0
+        assert q["own_splits"] == rp["WA"] and q["own_split0"] == 0          # what nb_shape_info reports: the waves issued before the wait
+        wk = walk_rank(q, n)
+        for phase in "AB":
+            gg, kk, ww = wk[phase]
+            if len(gg) == 0:
+                continue
+            np.add.at(seen, off(gg) + kk, 1)
+            total = np.where(gg < rp["n_hi"], rp["total_hi"], rp["total_lo"])
+            sym = kk < total - cps
+            tb = np.where(sym, (gg + 1 + kk // cps) % rp["nsb"], gg)
+            own = (tb >= rp["g0"]) & (tb < rp["g1"])
+            if phase == "A":
+                assert np.all(own)                            # residents AND travelers are the rank's own rows: nothing of the gather is read
+            elif g > 1:
+                assert not np.any(own & (tb > gg))            # an own target ahead on the ring would have been phase A's
+            # the table: first wave and wave count of every own super-block in this phase
+            col = 0 if phase == "A" else 2
+            for sb in range(rp["g0"], rp["g1"]):
+                ws = np.unique(ww[gg == sb])
+                if len(ws):
+                    assert ws[0] == q["rank_tab"][sb, col] and len(ws) == q["rank_tab"][sb, col + 1] and ws[-1] - ws[0] + 1 == len(ws)
+                else:
+                    assert q["rank_tab"][sb, col + 1] == 0
+        assert rp["r_layer0"] == 0 and rp["rb_layer0"] == q["rank_tab"][:, 1].max() and rp["t_layer0"] == rp["rb_layer0"] + q["rank_tab"][:, 3].max()
+        assert q["sym_layers"] == rp["t_layer0"] + rp["H"] + (1 if rp["n_hi"] else 0)
+        if g > 1:
+            assert 0.5 / g < rp["LA"] / pl["L"] < 2.0 / g       # about 1 / ranks of the work runs before the wait
+    assert np.all(seen == 1)                                     # the ranks' phases tile the system's pair list
 
 
 def test_rank_form_needs_whole_super_blocks():

@@ -346,6 +346,35 @@ def test_rank_form_with_one_rank_equals_the_whole_system_form():
                 assert x.tobytes() == y.tobytes(), G
 
 
+@pytest.mark.parametrize("n,precision", [(16384, "f32"), (40960, "f32"), (8192, "f64")])
+def test_rank_form_overlapped_gather_is_bit_identical(n, precision):
+    """NB_RCCL_OVERLAP on a rank-form handle: the sweeps whose travelers are the rank's own rows (phase A of nb::SymRankPlan) are
+    issued BEFORE the engine stream waits for the previous step's all-gather, the rest after it -- the same waves do the same
+    sweeps as in the single launch, so the trajectories agree bit for bit.  One rank (the collectives really run; the second
+    stream, the events and the split launches are the ones N ranks use); nb_shape_info reports the share issued before the wait."""
+    dt_np = np.float64 if precision == "f64" else np.float32
+    b, v = ic.plummer(n, seed=94)
+    b, v = b.astype(dt_np), v.astype(dt_np)
+    out = {}
+    for overlap in (False, True):
+        with Simulation(n, shard=(0, n), precision=precision, flags=capi.NB_FLAG_SYM_SHARD) as sim:
+            assert "symwrank" in sim.variant, sim.variant
+            shp = sim.shape_info()
+            assert 0 < shp["own_splits"] <= shp["jsplit"], shp          # waves of phase A / all waves
+            sim.init(b, v)
+            sim.rccl_attach(capi.rccl_unique_id(), 1, 0, overlap=overlap)
+            sim.simulate(1, 1e-3, 1.0)
+            sim.simulate(7)                                   # steps 2.. run their phase A under the pending gather
+            mid = sim.read()                                  # a read in between waits for the gather
+            sim.simulate(5)
+            out[overlap] = (mid, sim.read())
+    for x, y in zip(out[False][0] + out[False][1], out[True][0] + out[True][1]):
+        assert x.tobytes() == y.tobytes()
+    rb, _, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 13)
+    tol = 1e-12 if precision == "f64" else TOL_TIGHT
+    assert rel_pos_err(out[True][1][0], rb, 1.0) < tol
+
+
 def test_rank_form_is_not_taken_when_the_rows_are_not_whole_super_blocks_or_without_the_flag():
     n = 16384
     with Simulation(n, shard=(256, 8192), flags=capi.NB_FLAG_SYM_SHARD) as s:       # begin not on a 512-row boundary
