@@ -315,6 +315,11 @@ int nb_step_times2(nb_sim *s, nb_step_timing *out);
  * full O(N^2) step would take minutes (N >= 4M: state no longer cache-resident).  The
  * particle state is garbage afterwards -- measurement only; not available on a fused handle. */
 int nb_integrate_pass(nb_sim *s, uint32_t reps, double *avg_ms);
+/* Runs ONLY the force pass `reps` times back to back on the positions as they stand and returns the average time per pass
+ * (a rank-form handle: both phases of the force kernel + nb_sym_reduce).  The state is left untouched (the pass writes partial
+ * sums only).  Measurement: what ONE rank of an N-rank partition spends in its force pass can be timed on a single GPU
+ * without a communicator -- create the shard handle (shard_begin / shard_count, NB_FLAG_SYM_SHARD), upload, call this. */
+int nb_force_pass(nb_sim *s, uint32_t reps, double *avg_ms);
 
 /* Name of the force-kernel variant a handle resolved to (for reports), e.g.
  * "f32pk_fused_lds1024_ipl2_ls64" or "f32pk_sgpr_ipl8_ws4_js8".  Valid until nb_destroy. */
@@ -354,11 +359,12 @@ typedef struct nb_plan_info {
   char variant[112];
   uint32_t sym_ups;        /* wave-granular symmetric pass: work units per chunk-sweep (1: whole sweeps; 4: quarter sweeps) */
   uint32_t sym_spill_rows; /* rows of the spill buffer (one row set per wave; 0 with whole sweeps) */
-  uint32_t sym_rank_plan[15]; /* rank form (sym_rank): np, nsb, total_hi, total_lo, n_hi, H, r_layer0, rb_layer0, t_layer0, g0, g1, LA, LB,
-                                 WA, WB -- phase A = the sweeps whose travelers are the rank's own rows (LA sweeps, waves [0, WA):
+  uint32_t sym_rank_plan[16]; /* rank form (sym_rank): np, nsb, total_hi, total_lo, n_hi, H, r_layer0, rb_layer0, t_layer0, g0, g1, LA, LB,
+                                 WA, WB, ups -- phase A = the sweeps whose travelers are the rank's own rows (LA sweeps, waves [0, WA):
                                  what an overlapped step issues before it waits for the all-gather), phase B the rest.  `tab` then
-                                 holds {first A wave, A waves, first B wave, B waves} per super-block (4 * nsb words) and the two
-                                 phases' prefix tables (g1 - g0 + 1 words each) */
+                                 holds {first A wave, A waves, first B wave, B waves} per super-block (4 * nsb words), the two
+                                 phases' prefix tables (g1 - g0 + 1 words each) and, with ups > 1, the spill lists ({offset, count}
+                                 per 64-row chunk, then the wave numbers) */
 } nb_plan_info;
 int nb_plan_query(const nb_config *cfg, int n_cu, double clock_hz, nb_plan_info *out, uint32_t *tab,
                   uint32_t tab_cap);

@@ -441,7 +441,7 @@ __device__ __forceinline__ uint32_t rank_find(const uint32_t* __restrict__ prefi
 template <int NG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : 4)))
 void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ partial, const uint32_t* __restrict__ tab, const SymRankPlan pl,
-                        const uint32_t n, const float eps2, const uint32_t wave0, const uint32_t wave_end)
+                        const uint32_t n, const float eps2, const uint32_t wave0, const uint32_t wave_end, SymRow* __restrict__ spill)
 {
     constexpr uint32_t S = 128u * NG, CPS = S / 64u;
     constexpr int GW = NG < 4 ? NG : 4;
@@ -452,16 +452,18 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
     const uint32_t wl = phase_b ? w - pl.WA : w, Lp = phase_b ? pl.LB : pl.LA, Wp = phase_b ? pl.WB : pl.WA;
     const uint32_t ng = pl.g1 - pl.g0;
     const uint32_t* __restrict__ prefix = tab + 4 * pl.nsb + (phase_b ? ng + 1 : 0);
-    uint32_t p = (uint32_t)(((uint64_t)wl * Lp) / Wp);
-    const uint32_t pend = (uint32_t)(((uint64_t)(wl + 1) * Lp) / Wp);
+    // the wave's range in units of 64 / ups rotation steps of its phase (see nb_force_symw)
+    const uint32_t ups = pl.ups, ustep = 64u / ups;
+    const uint64_t Lu = (uint64_t)Lp * ups;
+    uint32_t u = (uint32_t)(((uint64_t)wl * Lu) / Wp);
+    const uint32_t uend = (uint32_t)(((uint64_t)(wl + 1) * Lu) / Wp);
     const nb_f2 e2 = nb_f2{eps2, eps2};
-    while (p < pend) {
-        const uint32_t gi = rank_find(prefix, ng, p), g = pl.g0 + gi;
-        uint32_t j = p - prefix[gi];
-        const uint32_t len = prefix[gi + 1] - prefix[gi];
-        uint32_t jend = j + (pend - p);
-        if (jend > len) jend = len;
-        p += jend - j;
+    while (u < uend) {
+        const uint32_t ps = u / ups;
+        const uint32_t gi = rank_find(prefix, ng, ps), g = pl.g0 + gi;
+        uint32_t j = ps - prefix[gi];
+        uint32_t ug_end = prefix[gi + 1] * ups;                      // end of g's part of the phase, in units
+        if (ug_end > uend) ug_end = uend;
         const uint32_t total = g < pl.n_hi ? pl.total_hi : pl.total_lo, ring = total - CPS;
         uint32_t a = (pl.g1 - 1 - g) * CPS;                          // sweeps of g whose travelers are own rows
         if (a > ring) a = ring;
@@ -476,18 +478,24 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
                 ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
             }
         }
-        for (; j < jend; ++j) {
+        while (u < ug_end) {
+            const uint32_t q0 = u % ups;                             // the wave's steps [s0, s1) of this sweep
+            uint32_t nun = ups - q0;
+            if (nun > ug_end - u) nun = ug_end - u;
+            const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
+            u += nun;
             const uint32_t k = phase_b ? a + j : (j < a ? j : ring + (j - a));       // position in g's list
+            ++j;
             const bool sym = k < ring;
             const uint32_t d = k / CPS;
             uint32_t tb = g + 1 + d;
             if (tb >= pl.nsb) tb -= pl.nsb;
             const uint32_t tstart = sym ? tb * S + (k % CPS) * 64u : g * S + (k - ring) * 64u;
             if (tstart >= n) continue;
-            const float4 t = ld4(bodies + tstart + lane);
+            const float4 t = ld4(bodies + tstart + (((uint32_t)lane - s0) & 63u));
             float tx = t.x, ty = t.y, tz = t.z, tm = t.w;
             nb_f2 bx = nb_f2{0, 0}, by = nb_f2{0, 0}, bz = nb_f2{0, 0};
-            for (int st = 0; st < 64; ++st) {
+            for (uint32_t st = s0; st < s1; ++st) {
                 const nb_f2 px = nb_f2{tx, tx}, py = nb_f2{ty, ty}, pz = nb_f2{tz, tz}, pm = nb_f2{tm, tm};
 #pragma unroll
                 for (int c0g = 0; c0g < NG; c0g += GW) {
@@ -532,7 +540,10 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
                 by = nb_f2{wave_rot1(by.x), wave_rot1(by.y)};
                 bz = nb_f2{wave_rot1(bz.x), wave_rot1(bz.y)};
             }
-            if (sym) partial[(size_t)(pl.t_layer0 + d) * pl.np + tstart + lane] = SymRow{bx.x + bx.y, by.x + by.y, bz.x + bz.y};
+            if (sym) {
+                SymRow* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)w * 64u) + (((uint32_t)lane - s1) & 63u);
+                *out = SymRow{bx.x + bx.y, by.x + by.y, bz.x + bz.y};
+            }
         }
         // resident sums of this wave's part of g's list in this phase
         const uint32_t* gt = tab + 4 * g;
@@ -548,7 +559,8 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
 template <int IPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* __restrict__ partial, const uint32_t* __restrict__ tab,
-                          const SymRankPlan pl, const uint32_t n, const double G, const double eps2, const uint32_t wave0, const uint32_t wave_end)
+                          const SymRankPlan pl, const uint32_t n, const double G, const double eps2, const uint32_t wave0, const uint32_t wave_end,
+                          SymRowT<double>* __restrict__ spill)
 {
     constexpr uint32_t S = 64u * IPL, CPS = S / 64u;
     constexpr int GW = 4;
@@ -559,15 +571,16 @@ void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* _
     const uint32_t wl = phase_b ? w - pl.WA : w, Lp = phase_b ? pl.LB : pl.LA, Wp = phase_b ? pl.WB : pl.WA;
     const uint32_t ng = pl.g1 - pl.g0;
     const uint32_t* __restrict__ prefix = tab + 4 * pl.nsb + (phase_b ? ng + 1 : 0);
-    uint32_t p = (uint32_t)(((uint64_t)wl * Lp) / Wp);
-    const uint32_t pend = (uint32_t)(((uint64_t)(wl + 1) * Lp) / Wp);
-    while (p < pend) {
-        const uint32_t gi = rank_find(prefix, ng, p), g = pl.g0 + gi;
-        uint32_t j = p - prefix[gi];
-        const uint32_t len = prefix[gi + 1] - prefix[gi];
-        uint32_t jend = j + (pend - p);
-        if (jend > len) jend = len;
-        p += jend - j;
+    const uint32_t ups = pl.ups, ustep = 64u / ups;
+    const uint64_t Lu = (uint64_t)Lp * ups;
+    uint32_t u = (uint32_t)(((uint64_t)wl * Lu) / Wp);
+    const uint32_t uend = (uint32_t)(((uint64_t)(wl + 1) * Lu) / Wp);
+    while (u < uend) {
+        const uint32_t ps = u / ups;
+        const uint32_t gi = rank_find(prefix, ng, ps), g = pl.g0 + gi;
+        uint32_t j = ps - prefix[gi];
+        uint32_t ug_end = prefix[gi + 1] * ups;
+        if (ug_end > uend) ug_end = uend;
         const uint32_t total = g < pl.n_hi ? pl.total_hi : pl.total_lo, ring = total - CPS;
         uint32_t a = (pl.g1 - 1 - g) * CPS;
         if (a > ring) a = ring;
@@ -578,17 +591,23 @@ void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* _
             xi[c] = b.x; yi[c] = b.y; zi[c] = b.z; mi[c] = b.w * G;
             ax[c] = 0; ay[c] = 0; az[c] = 0;
         }
-        for (; j < jend; ++j) {
+        while (u < ug_end) {
+            const uint32_t q0 = u % ups;
+            uint32_t nun = ups - q0;
+            if (nun > ug_end - u) nun = ug_end - u;
+            const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
+            u += nun;
             const uint32_t k = phase_b ? a + j : (j < a ? j : ring + (j - a));
+            ++j;
             const bool sym = k < ring;
             const uint32_t d = k / CPS;
             uint32_t tb = g + 1 + d;
             if (tb >= pl.nsb) tb -= pl.nsb;
             const uint32_t tstart = sym ? tb * S + (k % CPS) * 64u : g * S + (k - ring) * 64u;
             if (tstart >= n) continue;
-            const double4 t = ld4(bodies + tstart + lane);
+            const double4 t = ld4(bodies + tstart + (((uint32_t)lane - s0) & 63u));
             double tx = t.x, ty = t.y, tz = t.z, tm = t.w * G, bx = 0, by = 0, bz = 0;
-            for (int st = 0; st < 64; ++st) {
+            for (uint32_t st = s0; st < s1; ++st) {
 #pragma unroll
                 for (int c0g = 0; c0g < IPL; c0g += GW) {
                     double dx[GW], dy[GW], dz[GW], d2[GW], y[GW], uu[GW];
@@ -619,7 +638,10 @@ void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* _
                 tx = wave_rot1(tx); ty = wave_rot1(ty); tz = wave_rot1(tz); tm = wave_rot1(tm);
                 bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz);
             }
-            if (sym) partial[(size_t)(pl.t_layer0 + d) * pl.np + tstart + lane] = SymRowT<double>{bx, by, bz};
+            if (sym) {
+                SymRowT<double>* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)w * 64u) + (((uint32_t)lane - s1) & 63u);
+                *out = SymRowT<double>{bx, by, bz};
+            }
         }
         const uint32_t* gt = tab + 4 * g;
         SymRowT<double>* out = partial + (size_t)(phase_b ? pl.rb_layer0 + (wl - gt[2]) : pl.r_layer0 + (wl - gt[0])) * pl.np + (size_t)g * S + lane;
@@ -636,7 +658,8 @@ void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* _
 // fixed-order sum in the single-process handle) and the plain integrate kernel reads the rank's rows of the result.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __restrict__ partial, const uint32_t* __restrict__ tab,
-                                                       typename vec4<T>::type* __restrict__ A, const SymRankPlan pl, uint32_t S)
+                                                       typename vec4<T>::type* __restrict__ A, const SymRankPlan pl, uint32_t S,
+                                                       const SymRowT<T>* __restrict__ spill)
 {
     using SymRow = SymRowT<T>;
     using V4 = typename vec4<T>::type;
@@ -665,6 +688,12 @@ __global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __rest
             const SymRow r = partial[(size_t)(pl.t_layer0 + d) * pl.np + j];
             sx += r.x; sy += r.y; sz += r.z;
         }
+    }
+    if (pl.ups > 1) {                                            // later parts of sweeps shared by two waves: the chunk's spill list
+        const uint32_t base = 4 * pl.nsb + 2 * (g1 - g0 + 1), ci = j >> 6;
+        const uint32_t so = tab[base + 2 * ci], ns = tab[base + 2 * ci + 1];
+        const uint32_t* ids = tab + base + 2 * (pl.np >> 6) + so;
+        for (uint32_t e = 0; e < ns; ++e) { const SymRow r = spill[(size_t)ids[e] * 64u + (j & 63u)]; sx += r.x; sy += r.y; sz += r.z; }
     }
     A[j] = V4{sx, sy, sz, 0};
 }

@@ -249,13 +249,14 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
         void* p = s->partial;
         const uint32_t* tab = s->sym_tab;
         uint32_t n = s->n;
+        void* sp = s->sym_spill;
         if (s->f64) {
             double G = s->G, e2 = s->eps2;
-            void* args[] = {&b, &p, &tab, &rp, &n, &G, &e2, &w0, &w1};
+            void* args[] = {&b, &p, &tab, &rp, &n, &G, &e2, &w0, &w1, &sp};
             launch_kernel(rank_kernel_of(true, sh.ipl), dim3(ceil_div(w1 - w0, 4u)), dim3(256), args, s->stream, t0, t1);
         } else {
             float e2 = (float)s->eps2;
-            void* args[] = {&b, &p, &tab, &rp, &n, &e2, &w0, &w1};
+            void* args[] = {&b, &p, &tab, &rp, &n, &e2, &w0, &w1, &sp};
             launch_kernel(rank_kernel_of(false, sh.ipl), dim3(ceil_div(w1 - w0, 4u)), dim3(256), args, s->stream, t0, t1);
         }
         return;
@@ -518,7 +519,8 @@ int sym_rank_phase_a_t(nb_sim* s, hipEvent_t after_force, bool split_at_gather)
     const uint32_t* tab = s->sym_tab;
     V4* A = (V4*)s->sym_A;
     uint32_t S = ipb_of(shape_of(s));
-    void* args[] = {&p, &tab, &A, &rp, &S};
+    const void* sp = s->sym_spill;
+    void* args[] = {&p, &tab, &A, &rp, &S, &sp};
     NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_sym_reduce<T>, dim3(ceil_div(rp.np, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
     return NB_OK;
 }
@@ -1039,6 +1041,36 @@ int nb_integrate_pass(nb_sim* s, uint32_t reps, double* avg_ms)
     NB_HIP(s, hipGetLastError());
     s->dt = keep;
     drop_graph(s);          // buffer roles may have changed parity
+    *avg_ms = ms / reps;
+    return NB_OK;
+}
+
+int nb_force_pass(nb_sim* s, uint32_t reps, double* avg_ms)
+{
+    if (!s || !avg_ms) return NB_ERR_INVALID;
+    if (!s->uploaded) return fail(s, NB_ERR_STATE, "nb_force_pass: nothing uploaded yet");
+    if (s->fused) return fail(s, NB_ERR_STATE, "nb_force_pass: a fused handle has no separate force kernel (create it with NB_FLAG_NO_FUSE)");
+    if (reps == 0) return fail(s, NB_ERR_INVALID, "nb_force_pass: reps must be >= 1");
+    NB_HIP(s, hipSetDevice(s->device));
+    if (int rc = finish_gather(s)) return rc;
+    if (int rc = ensure_gm(s)) return rc;
+    auto once = [&]() -> int {
+        if (s->sym_rank) return s->f64 ? nbi::sym_rank_phase_a_t<double>(s, nullptr, false) : nbi::sym_rank_phase_a_t<float>(s, nullptr, false);
+        if (s->f64) launch_force<double>(s); else launch_force<float>(s);
+        return NB_OK;
+    };
+    hipEvent_t e0, e1;
+    NB_HIP(s, hipEventCreate(&e0));
+    NB_HIP(s, hipEventCreate(&e1));
+    if (int rc = once()) return rc;               // warm-up
+    NB_HIP(s, hipEventRecord(e0, s->stream));
+    for (uint32_t k = 0; k < reps; ++k) { if (int rc = once()) return rc; }
+    NB_HIP(s, hipEventRecord(e1, s->stream));
+    NB_HIP(s, hipEventSynchronize(e1));
+    float ms = 0;
+    NB_HIP(s, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    NB_HIP(s, hipGetLastError());
     *avg_ms = ms / reps;
     return NB_OK;
 }

@@ -104,7 +104,7 @@ struct nb_sim {
     // scattered across the ranks before the integrate kernel reads the rank's own rows of it
     bool sym_rank = false;
     uint32_t sym_g0 = 0, sym_g1 = 0;
-    uint32_t sym_rank_plan[15] = {0};   // nb::SymRankPlan: the two phases (own-row travelers first), their wave counts and layer bases
+    uint32_t sym_rank_plan[16] = {0};   // nb::SymRankPlan: the two phases (own-row travelers first), their wave counts and layer bases
     void* sym_A = nullptr;
     std::string variant, err;
     nb_exchange_fn xfn = nullptr;

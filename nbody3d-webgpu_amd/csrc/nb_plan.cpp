@@ -313,11 +313,12 @@ static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t
     rp.n_hi = n_hi; rp.H = H;
     rp.g0 = sb / S; rp.g1 = (sb + sc) / S;
     const uint32_t ng = rp.g1 - rp.g0;
-    std::vector<uint32_t> preA(ng + 1, 0), preB(ng + 1, 0);
+    std::vector<uint32_t> preA(ng + 1, 0), preB(ng + 1, 0), acut(ng, 0);
     for (uint32_t gi = 0; gi < ng; ++gi) {
         const uint32_t g = rp.g0 + gi;
         const uint32_t total = g < n_hi ? rp.total_hi : rp.total_lo, ring = total - cps;
         const uint32_t a = std::min(ring, (rp.g1 - 1 - g) * cps);       // ring distances d with g + 1 + d < g1: travelers inside the own rows
+        acut[gi] = a;
         preA[gi + 1] = preA[gi] + a + cps;                               // ... and the super-block's own chunks (resident-only)
         preB[gi + 1] = preB[gi] + (ring - a);
     }
@@ -325,40 +326,81 @@ static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t
     const uint32_t L = rp.LA + rp.LB;
     const uint32_t kw = cfg.jsplit ? cfg.jsplit : (L >= 16u * (uint32_t)n_cu ? 2u : 1u);
     const uint32_t Wfull = 4u * (uint32_t)n_cu * kw;
-    rp.WA = std::min(Wfull, rp.LA);                                      // never more waves than sweeps: every wave has work
-    rp.WB = std::min(Wfull, rp.LB);
-    // {first wave, waves} of every own super-block in each phase; B waves counted from 0 (the kernel adds WA)
-    s->sym_tab_host.assign(4 * (size_t)nsb + 2 * ((size_t)ng + 1), 0);
+    // units per sweep: a rank's share is small by construction (1 / ranks of the system in each phase), so quarter sweeps unless there
+    // are dozens of sweeps per wave in BOTH phases
+    const uint32_t ups = (cfg.flags & NB_FLAG_WHOLE_SWEEPS) ? 1u : std::max(sym_units(rp.LA, Wfull, false), sym_units(rp.LB ? rp.LB : rp.LA, Wfull, false));
+    rp.ups = ups;
+    rp.WA = std::min(Wfull, rp.LA);           // at least one sweep's worth of units per wave: every wave that touches a super-block adds a
+    rp.WB = std::min(Wfull, rp.LB);           // resident layer to it, which nb_sym_reduce reads back (N = 65,536 over 8 ranks: 744 layers otherwise)
+    const uint32_t nch = rp.np / 64u;
+    const size_t tab0 = 4 * (size_t)nsb, pre0 = tab0, sp0 = pre0 + 2 * ((size_t)ng + 1);
+    s->sym_tab_host.assign(sp0 + (ups > 1 ? 2 * (size_t)nch : 0), 0);
     uint32_t max_ra = 1, max_rb = 0;
-    auto wave_of = [](uint64_t p, uint32_t Lp, uint32_t Wp) {
-        uint32_t w = (uint32_t)(p * Wp / Lp);
-        while (w + 1 < Wp && (uint64_t)(w + 1) * Lp / Wp <= p) ++w;
-        while (w > 0 && (uint64_t)w * Lp / Wp > p) --w;
+    auto wave_of = [](uint64_t u, uint64_t Lu, uint32_t Wp) {
+        uint32_t w = (uint32_t)(u * Wp / Lu);
+        while (w + 1 < Wp && (uint64_t)(w + 1) * Lu / Wp <= u) ++w;
+        while (w > 0 && (uint64_t)w * Lu / Wp > u) --w;
         return w;
     };
     for (uint32_t gi = 0; gi < ng; ++gi) {
         uint32_t* t = &s->sym_tab_host[4 * (size_t)(rp.g0 + gi)];
-        const uint32_t fa = wave_of(preA[gi], rp.LA, rp.WA), la = wave_of(preA[gi + 1] - 1, rp.LA, rp.WA);
+        const uint64_t LuA = (uint64_t)rp.LA * ups, LuB = (uint64_t)rp.LB * ups;
+        const uint32_t fa = wave_of((uint64_t)preA[gi] * ups, LuA, rp.WA), la = wave_of((uint64_t)preA[gi + 1] * ups - 1, LuA, rp.WA);
         t[0] = fa; t[1] = la - fa + 1;
         max_ra = std::max(max_ra, t[1]);
         if (preB[gi + 1] > preB[gi]) {
-            const uint32_t fb = wave_of(preB[gi], rp.LB, rp.WB), lb = wave_of(preB[gi + 1] - 1, rp.LB, rp.WB);
+            const uint32_t fb = wave_of((uint64_t)preB[gi] * ups, LuB, rp.WB), lb = wave_of((uint64_t)preB[gi + 1] * ups - 1, LuB, rp.WB);
             t[2] = fb; t[3] = lb - fb + 1;
             max_rb = std::max(max_rb, t[3]);
         }
     }
-    std::copy(preA.begin(), preA.end(), s->sym_tab_host.begin() + 4 * (size_t)nsb);
-    std::copy(preB.begin(), preB.end(), s->sym_tab_host.begin() + 4 * (size_t)nsb + ng + 1);
+    std::copy(preA.begin(), preA.end(), s->sym_tab_host.begin() + pre0);
+    std::copy(preB.begin(), preB.end(), s->sym_tab_host.begin() + pre0 + ng + 1);
+    s->sym_spill_rows = 0;
+    if (ups > 1) {
+        // a wave whose range starts inside a sweep spills that sweep's traveler sums: per 64-row chunk the waves to add (B waves numbered from WA)
+        struct Spill { uint32_t chunk, wave; };
+        std::vector<Spill> sp;
+        for (int phase = 0; phase < 2; ++phase) {
+            const std::vector<uint32_t>& pre = phase ? preB : preA;
+            const uint64_t Lu = (uint64_t)(phase ? rp.LB : rp.LA) * ups;
+            const uint32_t Wp = phase ? rp.WB : rp.WA;
+            for (uint32_t w = 0; w < Wp; ++w) {
+                const uint64_t u = (uint64_t)w * Lu / Wp;
+                if (u % ups == 0 || (uint64_t)(w + 1) * Lu / Wp == u) continue;
+                const uint32_t p = (uint32_t)(u / ups);
+                const uint32_t gi = (uint32_t)(std::upper_bound(pre.begin(), pre.end(), p) - pre.begin()) - 1;
+                const uint32_t g = rp.g0 + gi, j = p - pre[gi];
+                const uint32_t total = g < n_hi ? rp.total_hi : rp.total_lo, ring = total - cps;
+                const uint32_t k = phase ? acut[gi] + j : (j < acut[gi] ? j : ring + (j - acut[gi]));
+                if (k >= ring) continue;                                    // resident-only sweep
+                uint32_t tb = g + 1 + k / cps;
+                if (tb >= nsb) tb -= nsb;
+                const uint32_t tstart = tb * S + (k % cps) * 64u;
+                if (tstart >= n) continue;
+                sp.push_back({tstart / 64u, (phase ? rp.WA : 0u) + w});
+            }
+        }
+        std::stable_sort(sp.begin(), sp.end(), [](const Spill& a, const Spill& b) { return a.chunk < b.chunk; });
+        const size_t ids0 = sp0 + 2 * (size_t)nch;
+        s->sym_tab_host.resize(ids0 + sp.size(), 0);
+        for (size_t e = 0; e < sp.size(); ++e) {
+            uint32_t* ent = &s->sym_tab_host[sp0 + 2 * (size_t)sp[e].chunk];
+            if (ent[1] == 0) ent[0] = (uint32_t)e;
+            ++ent[1];
+            s->sym_tab_host[ids0 + e] = sp[e].wave;
+        }
+        s->sym_spill_rows = (rp.WA + rp.WB) * 64u;
+    }
     rp.r_layer0 = 0; rp.rb_layer0 = max_ra; rp.t_layer0 = max_ra + max_rb;
     static_assert(sizeof(rp) == sizeof(s->sym_rank_plan), "LaunchPlan::sym_rank_plan holds a SymRankPlan");
     memcpy(s->sym_rank_plan, &rp, sizeof rp);
-    // the SymWPlan summary the reduction kernel and the reports read
+    // the SymWPlan summary the reports read
     nb::SymWPlan pl;
     pl.np = rp.np; pl.nsb = nsb; pl.W = rp.WA + rp.WB; pl.total_hi = rp.total_hi; pl.total_lo = rp.total_lo; pl.n_hi = n_hi; pl.H = H;
-    pl.r_layer0 = 0; pl.t_layer0 = rp.t_layer0; pl.L = L; pl.ups = 1;
+    pl.r_layer0 = 0; pl.t_layer0 = rp.t_layer0; pl.L = L; pl.ups = ups;
     pl.p0 = (rp.g0 <= n_hi ? rp.g0 * rp.total_hi : n_hi * rp.total_hi + (rp.g0 - n_hi) * rp.total_lo);
     memcpy(s->sym_plan, &pl, sizeof pl);
-    s->sym_spill_rows = 0;
     s->sym_rank = true; s->sym_g0 = rp.g0; s->sym_g1 = rp.g1;
     s->sym = true; s->symw = true; s->sym_np = rp.np; s->sym_layers = rp.t_layer0 + H + (n_hi ? 1u : 0u);
     s->ipl = sh.ipl; s->ls = 1; s->packed = !f64; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;

@@ -51,12 +51,16 @@ struct SymWPlan {
 // wait for the all-gather between them: the same waves do the same sweeps either way, so the results are bit-identical.
 // A wave's resident sums of super-block g go to layer r_layer0 + (wave - first A wave of g) or rb_layer0 + (wave - first B wave of g);
 // table: {first A wave, A waves, first B wave (counted from WA), B waves} per super-block, then prefixA[g1 - g0 + 1], prefixB[g1 - g0 + 1].
+// ups: work units per sweep, as in SymWPlan -- each phase's wave ranges are floor/ceil-equal in units of 64 / ups rotation steps; a
+// wave that starts inside a sweep keeps that sweep's traveler sums in its spill row (rows of wave w at w * 64; B waves numbered from
+// WA), and the per-chunk spill lists ({offset, count} per 64-row chunk, then the wave numbers) follow the prefix tables.
 struct SymRankPlan {
     uint32_t np, nsb;
     uint32_t total_hi, total_lo, n_hi, H;
     uint32_t r_layer0, rb_layer0, t_layer0;
     uint32_t g0, g1;
     uint32_t LA, LB, WA, WB;
+    uint32_t ups;
 };
 }  // namespace nb
 
@@ -96,7 +100,7 @@ struct LaunchPlan {
     uint32_t sym_np = 0, sym_layers = 0, sym_g0 = 0, sym_g1 = 0;
     uint32_t sym_plan[12] = {0};         // nb::SymWPlan (symw) or nb::SymPlan, as plain words
     uint32_t sym_spill_rows = 0;         // wave-granular form with ups > 1: rows of the spill buffer (W x travelers per chunk)
-    uint32_t sym_rank_plan[15] = {0};    // rank form: nb::SymRankPlan as plain words (sym_plan then holds the SymWPlan summary: W = WA + WB, L = LA + LB)
+    uint32_t sym_rank_plan[16] = {0};    // rank form: nb::SymRankPlan as plain words (sym_plan then holds the SymWPlan summary: W = WA + WB, L = LA + LB)
     std::vector<uint32_t> sym_tab_host;  // wave-granular form: {first wave, wave count} per super-block [2 nsb words]; with ups > 1
                                          // followed by {offset, count} per traveler chunk [2 np / CH words] and the spill lists' wave numbers
     std::string variant;

@@ -57,7 +57,7 @@ class nb_plan_info(C.Structure):
         "kind", "ipl", "ls", "x", "jsplit", "j_per_split", "own_split0", "own_splits",
         "sym", "symw", "sym_rank", "sym_np", "sym_layers", "sym_g0", "sym_g1")] + [
         ("sym_plan", C.c_uint32 * 11), ("tab_len", C.c_uint32), ("variant", C.c_char * 112),
-        ("sym_ups", C.c_uint32), ("sym_spill_rows", C.c_uint32), ("sym_rank_plan", C.c_uint32 * 15)]
+        ("sym_ups", C.c_uint32), ("sym_spill_rows", C.c_uint32), ("sym_rank_plan", C.c_uint32 * 16)]
 
 
 class nb_step_timing(C.Structure):          # include/nbody3d_hip.h
@@ -78,7 +78,7 @@ SYMBOLS = ["nb_abi_version", "nb_device_count", "nb_create", "nb_destroy", "nb_u
            "nb_multi_download", "nb_multi_sync", "nb_multi_last_error", "nb_multi_variant_name",
            "nb_multi_diagnostics", "nb_multi_set_collective", "nb_multi_collective_info",
            "nb_rccl_unique_id", "nb_rccl_attach", "nb_rccl_detach", "nb_rccl_info",
-           "nb_step_times", "nb_step_times2", "nb_integrate_pass", "nb_frame_request", "nb_frame_acquire", "nb_shape_info", "nb_plan_query"]
+           "nb_step_times", "nb_step_times2", "nb_integrate_pass", "nb_force_pass", "nb_frame_request", "nb_frame_acquire", "nb_shape_info", "nb_plan_query"]
 
 _lib = None
 
@@ -140,6 +140,7 @@ def load_library():
                                 C.POINTER(C.c_uint32)]
     L.nb_step_times2.argtypes = [vp, C.POINTER(nb_step_timing)]
     L.nb_integrate_pass.argtypes = [vp, C.c_uint32, C.POINTER(C.c_double)]
+    L.nb_force_pass.argtypes = [vp, C.c_uint32, C.POINTER(C.c_double)]
     L.nb_shape_info.argtypes = [vp] + [C.POINTER(C.c_uint32)] * 4
     L.nb_plan_query.argtypes = [C.POINTER(nb_config), C.c_int, C.c_double, C.POINTER(nb_plan_info), C.POINTER(C.c_uint32), C.c_uint32]
     L.nb_frame_request.argtypes = [vp]
@@ -172,7 +173,7 @@ def _ptr(a):
 
 
 SYMW_PLAN_WORDS = ("np", "nsb", "W", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "t_layer0", "L", "p0")
-SYM_RANK_PLAN_WORDS = ("np", "nsb", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "rb_layer0", "t_layer0", "g0", "g1", "LA", "LB", "WA", "WB")
+SYM_RANK_PLAN_WORDS = ("np", "nsb", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "rb_layer0", "t_layer0", "g0", "g1", "LA", "LB", "WA", "WB", "ups")
 SYM_PLAN_WORDS = ("np", "nsb", "q", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "t_layer0")
 
 
@@ -214,13 +215,18 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
             out["rank_tab"] = tab[:4 * nsb].reshape(-1, 4)
             out["prefix_a"] = tab[4 * nsb:4 * nsb + ng + 1]
             out["prefix_b"] = tab[4 * nsb + ng + 1:4 * nsb + 2 * (ng + 1)]
+            if rp["ups"] > 1:
+                nch = rp["np"] // 64
+                base = 4 * nsb + 2 * (ng + 1)
+                out["spill_tab"] = tab[base:base + 2 * nch].reshape(-1, 2)
+                out["spill_ids"] = tab[base + 2 * nch:]
             out["tab"] = out["rank_tab"][:, :2]
         else:
             out["tab"] = tab[:2 * nsb].reshape(-1, 2)
         out["ups"], out["spill_rows"] = int(info.sym_ups), int(info.sym_spill_rows)
         if info.symw:
             out["plan"]["ups"] = int(info.sym_ups)
-        if info.sym_ups > 1:
+        if info.sym_ups > 1 and not info.sym_rank:
             # the spill lists (wave ranges cut inside sweeps): {offset, count} per traveler chunk, then the wave numbers
             ch = 128 if info.x == 1 else 64
             nch = out["plan"]["np"] // ch
@@ -406,6 +412,13 @@ class Simulation:
         the particle state is garbage afterwards)."""
         ms = C.c_double()
         self._check(self._L.nb_integrate_pass(self._h, int(reps), C.byref(ms)))
+        return ms.value
+
+    def force_pass(self, reps):
+        """Average ms of the force pass alone over ``reps`` runs (a rank-form shard: both phases + nb_sym_reduce); no communicator
+        needed, the state is left untouched.  What one rank of an N-rank partition spends in its force pass, timed on one GPU."""
+        ms = C.c_double()
+        self._check(self._L.nb_force_pass(self._h, int(reps), C.byref(ms)))
         return ms.value
 
     # -- native RCCL collective (one process per GPU) ------------------------

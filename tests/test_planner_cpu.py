@@ -187,18 +187,18 @@ def test_workgroup_form_plan(n, jsplit):
 
 
 def walk_rank(q, n):
-    """The two phases of a rank-form plan as the kernel walks them: {phase: (g, k, wave)} arrays over the phase's positions."""
+    """The two phases of a rank-form plan as the kernel walks them: per phase (g, k, wave that starts the sweep, wave of every unit, first unit of every wave)."""
     rp, S = q["rank_plan"], 64 * q["ipl"]
-    cps = S // 64
+    cps, ups = S // 64, rp["ups"]
     g0, g1, ng = rp["g0"], rp["g1"], rp["g1"] - rp["g0"]
     out = {}
     for phase, L, W, pre in (("A", rp["LA"], rp["WA"], q["prefix_a"]), ("B", rp["LB"], rp["WB"], q["prefix_b"])):
         assert len(pre) == ng + 1 and pre[0] == 0 and pre[-1] == L and np.all(np.diff(pre.astype(np.int64)) >= 0)
         if L == 0:
             assert W == 0
-            out[phase] = (np.zeros(0, np.int64),) * 3
+            out[phase] = (np.zeros(0, np.int64),) * 5
             continue
-        assert 1 <= W <= L
+        assert 1 <= W <= L                                    # at least one sweep's worth of units per wave
         p = np.arange(L, dtype=np.int64)
         gi = np.searchsorted(pre.astype(np.int64), p, side="right") - 1
         g = g0 + gi
@@ -208,14 +208,15 @@ def walk_rank(q, n):
         a = np.minimum(ring, (g1 - 1 - g) * cps)
         k = (a + j) if phase == "B" else np.where(j < a, j, ring + (j - a))
         assert np.all(k < total)
-        starts = (np.arange(W + 1, dtype=np.int64) * L) // W
-        assert np.diff(starts).min() >= 1 and np.diff(starts).max() - np.diff(starts).min() <= 1
-        w = np.searchsorted(starts, p, side="right") - 1
-        out[phase] = (g, k, w)
+        Lu = L * ups
+        starts = (np.arange(W + 1, dtype=np.int64) * Lu) // W
+        assert np.diff(starts).min() >= 1 and np.diff(starts).max() - np.diff(starts).min() <= 1      # balanced to one UNIT
+        wu = np.searchsorted(starts, np.arange(Lu, dtype=np.int64), side="right") - 1
+        out[phase] = (g, k, wu[::ups], wu, starts)
     return out
 
 
-@pytest.mark.parametrize("n,g,prec", [(8192, 2, "f32"), (65536, 8, "f32"), (262144, 8, "f32"), (262144, 3, "f32"), (1048576, 8, "f32"),
+@pytest.mark.parametrize("n,g,prec", [(8192, 2, "f32"), (65536, 8, "f32"), (262144, 8, "f32"), (262144, 3, "f32"), (1048576, 8, "f32"), (40960, 5, "f32"),
                                      (16384, 4, "f64"), (262144, 8, "f64")])
 def test_rank_form_plans_tile_the_pair_list(n, g, prec):
     """NB_FLAG_SYM_SHARD: rank r sweeps the chunk lists of its own super-blocks only -- the ranks together evaluate every unordered
@@ -240,11 +241,14 @@ def test_rank_form_plans_tile_the_pair_list(n, g, prec):
         S = 64 * q["ipl"]
         cps = S // 64
         assert rp["g0"] == q["sym_g0"] == b // S and rp["g1"] == q["sym_g1"] == (b + cnt) // S
-        assert pl["L"] == rp["LA"] + rp["LB"] and pl["W"] == rp["WA"] + rp["WB"] and pl["ups"] == 1 and q["spill_rows"] == 0
+        ups = rp["ups"]
+        assert pl["L"] == rp["LA"] + rp["LB"] and pl["W"] == rp["WA"] + rp["WB"] and pl["ups"] == ups and q["ups"] == ups
+        assert q["spill_rows"] == (0 if ups == 1 else 64 * (rp["WA"] + rp["WB"]))
         assert q["own_splits"] == rp["WA"] and q["own_split0"] == 0          # what nb_shape_info reports: the waves issued before the wait
         wk = walk_rank(q, n)
+        want_spill = {}
         for phase in "AB":
-            gg, kk, ww = wk[phase]
+            gg, kk, ww, wu, starts = wk[phase]
             if len(gg) == 0:
                 continue
             np.add.at(seen, off(gg) + kk, 1)
@@ -258,14 +262,28 @@ def test_rank_form_plans_tile_the_pair_list(n, g, prec):
                 assert not np.any(own & (tb > gg))            # an own target ahead on the ring would have been phase A's
             # the table: first wave and wave count of every own super-block in this phase
             col = 0 if phase == "A" else 2
+            # a wave that starts inside a symmetric sweep over real rows spills it: B waves numbered from WA
+            for wv in range(len(starts) - 1):
+                u0 = int(starts[wv])
+                if u0 % ups:
+                    sw = u0 // ups
+                    if sym[sw] and int(tb[sw]) * S + int(kk[sw] % cps) * 64 < n:
+                        want_spill.setdefault(int(tb[sw]) * (S // 64) + int(kk[sw] % cps), []).append(wv + (rp["WA"] if phase == "B" else 0))
+            gu = np.repeat(gg, ups)
             for sb in range(rp["g0"], rp["g1"]):
-                ws = np.unique(ww[gg == sb])
+                ws = np.unique(wu[gu == sb])
                 if len(ws):
                     assert ws[0] == q["rank_tab"][sb, col] and len(ws) == q["rank_tab"][sb, col + 1] and ws[-1] - ws[0] + 1 == len(ws)
                 else:
                     assert q["rank_tab"][sb, col + 1] == 0
         assert rp["r_layer0"] == 0 and rp["rb_layer0"] == q["rank_tab"][:, 1].max() and rp["t_layer0"] == rp["rb_layer0"] + q["rank_tab"][:, 3].max()
         assert q["sym_layers"] == rp["t_layer0"] + rp["H"] + (1 if rp["n_hi"] else 0)
+        if ups > 1:
+            st, ids = q["spill_tab"], q["spill_ids"]
+            got = {ci: [int(x) for x in ids[int(st[ci, 0]):int(st[ci, 0]) + int(st[ci, 1])]] for ci in range(st.shape[0]) if st[ci, 1]}
+            assert got == {k2: sorted(v2) for k2, v2 in want_spill.items()} and sum(len(v2) for v2 in got.values()) == len(ids)
+        else:
+            assert not want_spill
         if g > 1:
             assert 0.5 / g < rp["LA"] / pl["L"] < 2.0 / g       # about 1 / ranks of the work runs before the wait
     assert np.all(seen == 1)                                     # the ranks' phases tile the system's pair list
