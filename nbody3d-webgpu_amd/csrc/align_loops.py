@@ -14,8 +14,8 @@ are read off the backward branches, and an `s_nop 0` (32 bits, one issue slot of
 64-bit instruction of a loop that would start at 4 mod 8.  The result is assembled, linked and bundled by the Makefile exactly as
 hipcc would have done with its own output (clang -cc1as / lld / clang-offload-bundler / -fcuda-include-gpubinary).  Inserting a
 no-op only lengthens the distance between instructions: no hazard can appear that was not there, and branch offsets are
-labels.  A function whose loops would need more than one no-op per 16 instructions is left as hipcc wrote it (fp64 code
-alternates 32- and 64-bit encodings: there the no-ops cost more than they save).  tests/test_isa_guard.py checks the built library:
+labels.  Functions with fp64 arithmetic in their loops are left as hipcc wrote them (they alternate 32- and 64-bit encodings:
+there the no-ops cost more than they save, measured), and so is any function that would need a no-op per 12 loop instructions.  tests/test_isa_guard.py checks the built library:
 no misaligned 64-bit instruction in any loop of the packed-f32 force kernels.
 """
 import os
@@ -25,7 +25,7 @@ import sys
 import tempfile
 
 LLVM = os.environ.get("NB_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
-DENSITY_LIMIT = 16          # at most one inserted no-op per this many loop instructions, else the function is left alone
+DENSITY_LIMIT = 12          # at most one inserted no-op per this many loop instructions, else the function is left alone
 DIS_LINE = re.compile(r"^\s*(\S+)\s.*//\s*([0-9A-Fa-f]+):\s+((?:[0-9A-Fa-f]{8}\s*)+)")
 
 
@@ -104,9 +104,9 @@ def process(src_lines, dis):
                 continue
             in_loop.update(range(dis_index[hk], dis_index[kk] + 1))
         out.append(src_lines[i])
-        # dry run first: a no-op costs an issue slot, so a function whose loops would need one per DENSITY_LIMIT instructions or more
-        # is left as hipcc wrote it (the fp64 loops alternate 32-bit v_fmac_f64_e32 / v_rsq_f64_e32 with 64-bit VOP3 instructions:
-        # aligned that way nb_force_symw64 ran 3.4 % SLOWER, profiles/r04/README.md)
+        # dry run first: a no-op costs an issue slot.  Left as hipcc wrote them: functions with fp64 arithmetic in their loops (they
+        # alternate 32-bit v_fmac_f64_e32 / v_rsq_f64_e32 with 64-bit VOP3 instructions: aligned by no-ops nb_force_symw64 ran 3.4 %
+        # SLOWER, profiles/r04/README.md) and functions that would need a no-op per DENSITY_LIMIT loop instructions or more
         def walk(emit):
             parity, inserted, wide = 0, 0, 0
             for li, ln in enumerate(body):
@@ -129,7 +129,8 @@ def process(src_lines, dis):
             return inserted, wide
         need, wide_in_loops = walk(None)
         loop_instr = sum(1 for li in in_loop if li in size_of)
-        if need and need * DENSITY_LIMIT > loop_instr:
+        fp64 = any("_f64" in body[li].split(";")[0].split()[0] for li in in_loop if li in size_of)
+        if need and (fp64 or need * DENSITY_LIMIT > loop_instr):
             out.extend(body)
             report.append((name, len(in_loop), wide_in_loops, 0, need))
             i = j
