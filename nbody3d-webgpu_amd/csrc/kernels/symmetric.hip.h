@@ -428,6 +428,9 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
 // Waves [0, WA) sweep phase A (travelers = the rank's own rows), waves [WA, WA + WB) phase B; `wave0` / `wave_end` select the part
 // of them a launch runs (everything, or A before the wait for the all-gather and B after it).  A phase's sweeps are laid end to
 // end; prefix[gi] is where own super-block g0 + gi begins.
+// Layers are COMPACT: a layer holds the (g1 - g0) * S rows this rank can write -- resident layers the rows of its own super-blocks,
+// traveler layer d the sums super-block g produced for the rows of block g + 1 + d, filed under the SOURCE g -- so a rank of 8
+// allocates an eighth of what the whole-system form does (N = 1,048,576: 0.8 GB instead of 6.4).
 __device__ __forceinline__ uint32_t rank_find(const uint32_t* __restrict__ prefix, uint32_t ng, uint32_t p)
 {
     uint32_t lo = 0, hi = ng;                         // largest gi with prefix[gi] <= p  (prefix[ng] > p)
@@ -451,6 +454,7 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
     const bool phase_b = w >= pl.WA;
     const uint32_t wl = phase_b ? w - pl.WA : w, Lp = phase_b ? pl.LB : pl.LA, Wp = phase_b ? pl.WB : pl.WA;
     const uint32_t ng = pl.g1 - pl.g0;
+    const size_t lstride = (size_t)ng * S;             // rows per (compact) layer
     const uint32_t* __restrict__ prefix = tab + 4 * pl.nsb + (phase_b ? ng + 1 : 0);
     // the wave's range in units of 64 / ups rotation steps of its phase (see nb_force_symw)
     const uint32_t ups = pl.ups, ustep = 64u / ups;
@@ -541,13 +545,13 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
                 bz = nb_f2{wave_rot1(bz.x), wave_rot1(bz.y)};
             }
             if (sym) {
-                SymRow* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)w * 64u) + (((uint32_t)lane - s1) & 63u);
+                SymRow* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * lstride + (size_t)gi * S + (k % CPS) * 64u : spill + (size_t)w * 64u) + (((uint32_t)lane - s1) & 63u);
                 *out = SymRow{bx.x + bx.y, by.x + by.y, bz.x + bz.y};
             }
         }
         // resident sums of this wave's part of g's list in this phase
         const uint32_t* gt = tab + 4 * g;
-        SymRow* out = partial + (size_t)(phase_b ? pl.rb_layer0 + (wl - gt[2]) : pl.r_layer0 + (wl - gt[0])) * pl.np + (size_t)g * S + lane;
+        SymRow* out = partial + (size_t)(phase_b ? pl.rb_layer0 + (wl - gt[2]) : pl.r_layer0 + (wl - gt[0])) * lstride + (size_t)gi * S + lane;
 #pragma unroll
         for (int c = 0; c < NG; ++c) {
             out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
@@ -570,6 +574,7 @@ void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* _
     const bool phase_b = w >= pl.WA;
     const uint32_t wl = phase_b ? w - pl.WA : w, Lp = phase_b ? pl.LB : pl.LA, Wp = phase_b ? pl.WB : pl.WA;
     const uint32_t ng = pl.g1 - pl.g0;
+    const size_t lstride = (size_t)ng * S;             // rows per (compact) layer
     const uint32_t* __restrict__ prefix = tab + 4 * pl.nsb + (phase_b ? ng + 1 : 0);
     const uint32_t ups = pl.ups, ustep = 64u / ups;
     const uint64_t Lu = (uint64_t)Lp * ups;
@@ -639,12 +644,12 @@ void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* _
                 bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz);
             }
             if (sym) {
-                SymRowT<double>* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)w * 64u) + (((uint32_t)lane - s1) & 63u);
+                SymRowT<double>* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * lstride + (size_t)gi * S + (k % CPS) * 64u : spill + (size_t)w * 64u) + (((uint32_t)lane - s1) & 63u);
                 *out = SymRowT<double>{bx, by, bz};
             }
         }
         const uint32_t* gt = tab + 4 * g;
-        SymRowT<double>* out = partial + (size_t)(phase_b ? pl.rb_layer0 + (wl - gt[2]) : pl.r_layer0 + (wl - gt[0])) * pl.np + (size_t)g * S + lane;
+        SymRowT<double>* out = partial + (size_t)(phase_b ? pl.rb_layer0 + (wl - gt[2]) : pl.r_layer0 + (wl - gt[0])) * lstride + (size_t)gi * S + lane;
 #pragma unroll
         for (int c = 0; c < IPL; ++c) out[c * 64] = SymRowT<double>{ax[c], ay[c], az[c]};
     }
@@ -665,19 +670,21 @@ __global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __rest
     using V4 = typename vec4<T>::type;
     const uint32_t j = blockIdx.x * kBlock + threadIdx.x;
     if (j >= pl.np) return;
-    const uint32_t b = j / S, g0 = pl.g0, g1 = pl.g1;
+    const uint32_t b = j / S, g0 = pl.g0, g1 = pl.g1, within = j - b * S;
+    const size_t lstride = (size_t)(g1 - g0) * S;                // compact layers: rows filed under the own super-block that wrote them
     T sx = 0, sy = 0, sz = 0;
     if (b >= g0 && b < g1) {                                     // resident layers: phase A's waves, then phase B's
         const uint32_t na = tab[4 * b + 1], nb_ = tab[4 * b + 3];
-        for (uint32_t e = 0; e < na; ++e) { const SymRow r = partial[(size_t)(pl.r_layer0 + e) * pl.np + j]; sx += r.x; sy += r.y; sz += r.z; }
-        for (uint32_t e = 0; e < nb_; ++e) { const SymRow r = partial[(size_t)(pl.rb_layer0 + e) * pl.np + j]; sx += r.x; sy += r.y; sz += r.z; }
+        const size_t row = (size_t)(b - g0) * S + within;
+        for (uint32_t e = 0; e < na; ++e) { const SymRow r = partial[(size_t)(pl.r_layer0 + e) * lstride + row]; sx += r.x; sy += r.y; sz += r.z; }
+        for (uint32_t e = 0; e < nb_; ++e) { const SymRow r = partial[(size_t)(pl.rb_layer0 + e) * lstride + row]; sx += r.x; sy += r.y; sz += r.z; }
     }
     if (g1 - g0 > pl.H) {
         for (uint32_t d = 0; d <= pl.H; ++d) {                   // few ring distances, many own super-blocks: ascending distance
             uint32_t g = b + pl.nsb - 1 - d;
             if (g >= pl.nsb) g -= pl.nsb;
             if (g < g0 || g >= g1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
-            const SymRow r = partial[(size_t)(pl.t_layer0 + d) * pl.np + j];
+            const SymRow r = partial[(size_t)(pl.t_layer0 + d) * lstride + (size_t)(g - g0) * S + within];
             sx += r.x; sy += r.y; sz += r.z;
         }
     } else {
@@ -685,7 +692,7 @@ __global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __rest
             uint32_t d = b + pl.nsb - 1 - g;
             if (d >= pl.nsb) d -= pl.nsb;
             if (d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
-            const SymRow r = partial[(size_t)(pl.t_layer0 + d) * pl.np + j];
+            const SymRow r = partial[(size_t)(pl.t_layer0 + d) * lstride + (size_t)(g - g0) * S + within];
             sx += r.x; sy += r.y; sz += r.z;
         }
     }

@@ -198,6 +198,9 @@ Shape shape_of(const nb_sim* s)
     return {kScalar, s->ipl, s->ls, 1};
 }
 
+// Rows of one partial-sum layer of a symmetric handle: the padded system, or (rank form: compact layers) the handle's own super-blocks.
+size_t sym_layer_rows(const nb_sim* s) { return s->sym_rank ? (size_t)(s->sym_g1 - s->sym_g0) * ipb_of(shape_of(s)) : (size_t)s->sym_np; }
+
 // The packed f32 K1 forms stream their j-bodies as (x, y, z, G*m) rows (nb_internal.h, `gm`).
 bool streams_gm(const nb_sim* s) { return !s->f64 && s->packed && !s->jpk; }
 bool gm_active(const nb_sim* s) { return streams_gm(s) && (float)s->G != 1.0f; }
@@ -643,7 +646,7 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
         // (other handles, other processes).  A whole-system handle then takes the ordered-pair kernels instead of failing in
         // hipMalloc.  (A rank-form shard does not: its peers would still expect the reduce-scatter -- it fails loudly below.)
         size_t free_b = 0, total_b = 0;
-        const double need = 3.0 * s->esz * s->sym_np * s->sym_layers + 12.0 * s->esz * s->sym_np;
+        const double need = 3.0 * s->esz * (double)sym_layer_rows(s) * s->sym_layers + 12.0 * s->esz * s->sym_np;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > 0.9 * (double)free_b) {
             cfg.flags |= NB_FLAG_NO_SYM;
             plan_handle(s, cfg, n_cu, clock_hz, (double)prop.totalGlobalMem);
@@ -671,7 +674,8 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
         return hipMalloc(&s->partial, bytes);
     };
     if (s->sym) {
-        NB_HIPC(alloc_partial((size_t)3 * s->esz * s->sym_np * s->sym_layers));       // layers of (x, y, z) rows: 12 bytes (24 in f64)
+        // layers of (x, y, z) rows: 12 bytes (24 in f64); a rank-form handle's layers hold the rows of its own super-blocks only
+        NB_HIPC(alloc_partial((size_t)3 * s->esz * sym_layer_rows(s) * s->sym_layers));
         if (s->sym_rank) NB_HIPC(hipMalloc(&s->sym_A, 4 * s->esz * s->sym_np));
         if (s->sym_spill_rows) {
             // zeroed once: a wave that never spills (its range starts at a sweep boundary) leaves its row alone, and nobody reads it
@@ -685,7 +689,7 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     } else if (!s->fused) {
         NB_HIPC(alloc_partial(row * s->sc * s->jsplit));
     }
-    if (s->partial_bytes != (s->sym ? (size_t)3 * s->esz * s->sym_np * s->sym_layers : s->fused ? (size_t)0 : row * s->sc * s->jsplit))
+    if (s->partial_bytes != (s->sym ? (size_t)3 * s->esz * sym_layer_rows(s) * s->sym_layers : s->fused ? (size_t)0 : row * s->sc * s->jsplit))
         return bail(NB_ERR_STATE, "nb_create: the partial-sum buffer does not have the size this handle's kernels index");
     if (s->jpk) {
         // pairs: whole 4-pair units (128 B) plus one spare the loop's last request may touch; everything past the
@@ -1026,7 +1030,7 @@ int nb_integrate_pass(nb_sim* s, uint32_t reps, double* avg_ms)
     const double dt = s->dt > 0 ? s->dt : 1e-3;
     const double keep = s->dt;
     s->dt = dt;
-    if (s->steps_done == 0) NB_HIP(s, hipMemsetAsync(s->partial, 0, s->sym ? (size_t)3 * s->esz * s->sym_np * s->sym_layers : 4 * s->esz * s->sc * s->jsplit, s->stream));
+    if (s->steps_done == 0) NB_HIP(s, hipMemsetAsync(s->partial, 0, s->sym ? (size_t)3 * s->esz * sym_layer_rows(s) * s->sym_layers : 4 * s->esz * s->sc * s->jsplit, s->stream));
     hipEvent_t e0, e1;
     NB_HIP(s, hipEventCreate(&e0));
     NB_HIP(s, hipEventCreate(&e1));

@@ -502,7 +502,7 @@ LaunchPlan plan_launch(const PlanInput& in)
     if ((cfg.flags & NB_FLAG_SYM_SHARD) && !(cfg.flags & NB_FLAG_NO_SYM) && !cfg.ext_bodies && cfg.shard_count != 0)
         for (uint32_t S : {1024u, 512u})
             if (!rank_ipl && !(f64 && S != 512u) && sb % S == 0 && sc % S == 0 && n % S == 0 && n / S >= 2 &&        // f64: 8 residents per lane only
-                sym_layer_bytes(n, S, esz) <= layer_budget) rank_ipl = (int)(S / 64u);
+                sym_layer_bytes(n, S, esz) * ((double)sc / (double)n) <= layer_budget) rank_ipl = (int)(S / 64u);       // a rank's layers hold its own super-blocks' rows only
     const uint32_t variant = rank_ipl ? 0u : cfg.force_variant;
     bool pinned = false;
     if (rank_ipl) { sh = {kSym, rank_ipl, 1, 3}; pinned = true; if (js == 0) js = 0xffffffffu; }     // js: placeholder, set with the plan below
