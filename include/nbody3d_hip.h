@@ -365,6 +365,12 @@ typedef struct nb_plan_info {
                                  holds {first A wave, A waves, first B wave, B waves} per super-block (4 * nsb words), the two
                                  phases' prefix tables (g1 - g0 + 1 words each) and, with ups > 1, the spill lists ({offset, count}
                                  per 64-row chunk, then the wave numbers) */
+  uint32_t sym_pass;       /* IN/OUT: which pass of the rank-form pipeline sym_rank_plan and `tab` describe (set before the call; 0 when
+                              in doubt).  A whole system whose traveler layers would not fit the layer budget runs its ring distances
+                              in sym_passes passes that reuse the layers (variant suffix "_pN") */
+  uint32_t sym_passes;     /* passes of the rank-form pipeline (1 for an ordinary rank; 0 when the handle is not in the rank form) */
+  uint32_t sym_pass_k_lo, sym_pass_k_hi, sym_pass_d0; /* the pass's window of every super-block's ring sweeps [k_lo, k_hi) and its first ring distance */
+  uint32_t sym_local;      /* the rank-form pipeline of a WHOLE system on one device: no communicator, nothing exchanged */
 } nb_plan_info;
 int nb_plan_query(const nb_config *cfg, int n_cu, double clock_hz, nb_plan_info *out, uint32_t *tab,
                   uint32_t tab_cap);

@@ -444,7 +444,8 @@ __device__ __forceinline__ uint32_t rank_find(const uint32_t* __restrict__ prefi
 template <int NG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : 4)))
 void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ partial, const uint32_t* __restrict__ tab, const SymRankPlan pl,
-                        const uint32_t n, const float eps2, const uint32_t wave0, const uint32_t wave_end, SymRow* __restrict__ spill)
+                        const uint32_t n, const float eps2, const uint32_t wave0, const uint32_t wave_end, SymRow* __restrict__ spill,
+                        const uint32_t k_lo, const uint32_t k_hi, const uint32_t d0)
 {
     constexpr uint32_t S = 128u * NG, CPS = S / 64u;
     constexpr int GW = NG < 4 ? NG : 4;
@@ -471,6 +472,11 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
         const uint32_t total = g < pl.n_hi ? pl.total_hi : pl.total_lo, ring = total - CPS;
         uint32_t a = (pl.g1 - 1 - g) * CPS;                          // sweeps of g whose travelers are own rows
         if (a > ring) a = ring;
+        // the pass's window [k_lo, k_hi) of the ring sweeps (one pass: everything): phase A runs [a_lo, a_lo + a_len) and then the
+        // resident-only sweeps (if the pass has them: its prefix table says so), phase B [b_lo, ...)
+        const uint32_t a_lo = a < k_lo ? a : k_lo, a_len = (a < k_hi ? a : k_hi) - a_lo;
+        uint32_t b_lo = a > k_lo ? a : k_lo;
+        if (b_lo > ring) b_lo = ring;
 
         nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
         {
@@ -488,7 +494,7 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
             if (nun > ug_end - u) nun = ug_end - u;
             const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
             u += nun;
-            const uint32_t k = phase_b ? a + j : (j < a ? j : ring + (j - a));       // position in g's list
+            const uint32_t k = phase_b ? b_lo + j : (j < a_len ? a_lo + j : ring + (j - a_len));       // position in g's list
             ++j;
             const bool sym = k < ring;
             const uint32_t d = k / CPS;
@@ -545,7 +551,7 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
                 bz = nb_f2{wave_rot1(bz.x), wave_rot1(bz.y)};
             }
             if (sym) {
-                SymRow* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * lstride + (size_t)gi * S + (k % CPS) * 64u : spill + (size_t)w * 64u) + (((uint32_t)lane - s1) & 63u);
+                SymRow* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d - d0) * lstride + (size_t)gi * S + (k % CPS) * 64u : spill + (size_t)w * 64u) + (((uint32_t)lane - s1) & 63u);
                 *out = SymRow{bx.x + bx.y, by.x + by.y, bz.x + bz.y};
             }
         }
@@ -564,7 +570,7 @@ template <int IPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* __restrict__ partial, const uint32_t* __restrict__ tab,
                           const SymRankPlan pl, const uint32_t n, const double G, const double eps2, const uint32_t wave0, const uint32_t wave_end,
-                          SymRowT<double>* __restrict__ spill)
+                          SymRowT<double>* __restrict__ spill, const uint32_t k_lo, const uint32_t k_hi, const uint32_t d0)
 {
     constexpr uint32_t S = 64u * IPL, CPS = S / 64u;
     constexpr int GW = 4;
@@ -589,6 +595,9 @@ void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* _
         const uint32_t total = g < pl.n_hi ? pl.total_hi : pl.total_lo, ring = total - CPS;
         uint32_t a = (pl.g1 - 1 - g) * CPS;
         if (a > ring) a = ring;
+        const uint32_t a_lo = a < k_lo ? a : k_lo, a_len = (a < k_hi ? a : k_hi) - a_lo;         // the pass's window: see nb_force_symw_rank
+        uint32_t b_lo = a > k_lo ? a : k_lo;
+        if (b_lo > ring) b_lo = ring;
         double xi[IPL], yi[IPL], zi[IPL], mi[IPL], ax[IPL], ay[IPL], az[IPL];
 #pragma unroll
         for (int c = 0; c < IPL; ++c) {
@@ -602,7 +611,7 @@ void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* _
             if (nun > ug_end - u) nun = ug_end - u;
             const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
             u += nun;
-            const uint32_t k = phase_b ? a + j : (j < a ? j : ring + (j - a));
+            const uint32_t k = phase_b ? b_lo + j : (j < a_len ? a_lo + j : ring + (j - a_len));
             ++j;
             const bool sym = k < ring;
             const uint32_t d = k / CPS;
@@ -644,7 +653,7 @@ void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* _
                 bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz);
             }
             if (sym) {
-                SymRowT<double>* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * lstride + (size_t)gi * S + (k % CPS) * 64u : spill + (size_t)w * 64u) + (((uint32_t)lane - s1) & 63u);
+                SymRowT<double>* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d - d0) * lstride + (size_t)gi * S + (k % CPS) * 64u : spill + (size_t)w * 64u) + (((uint32_t)lane - s1) & 63u);
                 *out = SymRowT<double>{bx, by, bz};
             }
         }
@@ -664,7 +673,7 @@ void nb_force_symw64_rank(const double4* __restrict__ bodies, SymRowT<double>* _
 template <typename T>
 __global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __restrict__ partial, const uint32_t* __restrict__ tab,
                                                        typename vec4<T>::type* __restrict__ A, const SymRankPlan pl, uint32_t S,
-                                                       const SymRowT<T>* __restrict__ spill)
+                                                       const SymRowT<T>* __restrict__ spill, uint32_t d0, uint32_t d1, uint32_t accumulate)
 {
     using SymRow = SymRowT<T>;
     using V4 = typename vec4<T>::type;
@@ -680,19 +689,19 @@ __global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __rest
         for (uint32_t e = 0; e < nb_; ++e) { const SymRow r = partial[(size_t)(pl.rb_layer0 + e) * lstride + row]; sx += r.x; sy += r.y; sz += r.z; }
     }
     if (g1 - g0 > pl.H) {
-        for (uint32_t d = 0; d <= pl.H; ++d) {                   // few ring distances, many own super-blocks: ascending distance
+        for (uint32_t d = d0; d <= pl.H && d < d1; ++d) {        // few ring distances, many own super-blocks: ascending distance
             uint32_t g = b + pl.nsb - 1 - d;
             if (g >= pl.nsb) g -= pl.nsb;
-            if (g < g0 || g >= g1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
-            const SymRow r = partial[(size_t)(pl.t_layer0 + d) * lstride + (size_t)(g - g0) * S + within];
+            if (d < d0 || d >= d1 || g < g0 || g >= g1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;       // [d0, d1): the ring distances of this pass
+            const SymRow r = partial[(size_t)(pl.t_layer0 + d - d0) * lstride + (size_t)(g - g0) * S + within];
             sx += r.x; sy += r.y; sz += r.z;
         }
     } else {
         for (uint32_t g = g0; g < g1; ++g) {                     // a rank of many: only its own super-blocks can have written a layer of row j
             uint32_t d = b + pl.nsb - 1 - g;
             if (d >= pl.nsb) d -= pl.nsb;
-            if (d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
-            const SymRow r = partial[(size_t)(pl.t_layer0 + d) * lstride + (size_t)(g - g0) * S + within];
+            if (d < d0 || d >= d1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
+            const SymRow r = partial[(size_t)(pl.t_layer0 + d - d0) * lstride + (size_t)(g - g0) * S + within];
             sx += r.x; sy += r.y; sz += r.z;
         }
     }
@@ -702,6 +711,7 @@ __global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __rest
         const uint32_t* ids = tab + base + 2 * (pl.np >> 6) + so;
         for (uint32_t e = 0; e < ns; ++e) { const SymRow r = spill[(size_t)ids[e] * 64u + (j & 63u)]; sx += r.x; sy += r.y; sz += r.z; }
     }
+    if (accumulate) { const V4 o = ld4(A + j); sx += o.x; sy += o.y; sz += o.z; }      // a later pass over the ring distances: layers reused, sums carried in A
     A[j] = V4{sx, sy, sz, 0};
 }
 

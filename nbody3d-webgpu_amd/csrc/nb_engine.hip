@@ -182,6 +182,8 @@ void plan_handle(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz, dou
     memcpy(s->sym_plan, p.sym_plan, sizeof s->sym_plan);
     static_assert(sizeof(s->sym_rank_plan) == sizeof(p.sym_rank_plan), "nb_sim::sym_rank_plan mirrors LaunchPlan::sym_rank_plan");
     memcpy(s->sym_rank_plan, p.sym_rank_plan, sizeof s->sym_rank_plan);
+    s->sym_passes = std::move(p.sym_passes);
+    s->sym_local = p.sym_local;
     s->sym_tab_host = std::move(p.sym_tab_host);
     s->sym_spill_rows = p.sym_spill_rows;
     s->variant = std::move(p.variant);
@@ -244,22 +246,23 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
     const Shape sh = shape_of(s);
     if (s->sym_rank) {
         // part 0: every wave; 1: phase A (travelers = own rows; nothing of the other ranks is read); 2: phase B
+        const nbp::LaunchPlan::SymPass& ps = s->sym_passes[s->sym_pass];
         nb::SymRankPlan rp;
-        memcpy(&rp, s->sym_rank_plan, sizeof rp);
+        memcpy(&rp, ps.plan, sizeof rp);
         uint32_t w0 = part == 2 ? rp.WA : 0u, w1 = part == 1 ? rp.WA : rp.WA + rp.WB;
         if (w1 <= w0) return;
         const void* b = jstream(s, s->cur);
         void* p = s->partial;
-        const uint32_t* tab = s->sym_tab;
-        uint32_t n = s->n;
+        const uint32_t* tab = s->sym_tab + ps.tab_off;
+        uint32_t n = s->n, k_lo = ps.k_lo, k_hi = ps.k_hi, d0 = ps.d0;
         void* sp = s->sym_spill;
         if (s->f64) {
             double G = s->G, e2 = s->eps2;
-            void* args[] = {&b, &p, &tab, &rp, &n, &G, &e2, &w0, &w1, &sp};
+            void* args[] = {&b, &p, &tab, &rp, &n, &G, &e2, &w0, &w1, &sp, &k_lo, &k_hi, &d0};
             launch_kernel(rank_kernel_of(true, sh.ipl), dim3(ceil_div(w1 - w0, 4u)), dim3(256), args, s->stream, t0, t1);
         } else {
             float e2 = (float)s->eps2;
-            void* args[] = {&b, &p, &tab, &rp, &n, &e2, &w0, &w1, &sp};
+            void* args[] = {&b, &p, &tab, &rp, &n, &e2, &w0, &w1, &sp, &k_lo, &k_hi, &d0};
             launch_kernel(rank_kernel_of(false, sh.ipl), dim3(ceil_div(w1 - w0, 4u)), dim3(256), args, s->stream, t0, t1);
         }
         return;
@@ -508,23 +511,31 @@ template <typename T>
 int sym_rank_phase_a_t(nb_sim* s, hipEvent_t after_force, bool split_at_gather)
 {
     using V4 = typename nb::vec4<T>::type;
-    if (split_at_gather) {
-        launch_force<T>(s, 1);                        // own-row travelers: needs nothing from the other ranks
-        if (int rc = finish_gather(s)) return rc;     // the engine stream waits for their rows here
-        launch_force<T>(s, 2);
-    } else {
-        launch_force<T>(s);
+    const uint32_t npass = (uint32_t)s->sym_passes.size();
+    for (uint32_t q = 0; q < npass; ++q) {
+        s->sym_pass = q;
+        if (split_at_gather && q == 0) {
+            launch_force<T>(s, 1);                        // own-row travelers: needs nothing from the other ranks
+            if (int rc = finish_gather(s)) return rc;     // the engine stream waits for their rows here
+            launch_force<T>(s, 2);
+        } else {
+            launch_force<T>(s);
+        }
+        if (after_force && q + 1 == npass) NB_HIP(s, hipEventRecord(after_force, s->stream));
+        // this pass's sums for every row: into sym_A (first pass) or on top of it
+        const nbp::LaunchPlan::SymPass& ps = s->sym_passes[q];
+        nb::SymRankPlan rp;
+        memcpy(&rp, ps.plan, sizeof rp);
+        const nb::SymRowT<T>* p = (const nb::SymRowT<T>*)s->partial;
+        const uint32_t* tab = s->sym_tab + ps.tab_off;
+        V4* A = (V4*)s->sym_A;
+        uint32_t S = ipb_of(shape_of(s));
+        const void* sp = s->sym_spill;
+        uint32_t d0 = ps.d0, d1 = ps.k_hi == 0xffffffffu ? 0xffffffffu : ps.k_hi / (S / 64u), acc = q ? 1u : 0u;
+        void* args[] = {&p, &tab, &A, &rp, &S, &sp, &d0, &d1, &acc};
+        NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_sym_reduce<T>, dim3(ceil_div(rp.np, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
     }
-    if (after_force) NB_HIP(s, hipEventRecord(after_force, s->stream));
-    nb::SymRankPlan rp;
-    memcpy(&rp, s->sym_rank_plan, sizeof rp);
-    const nb::SymRowT<T>* p = (const nb::SymRowT<T>*)s->partial;
-    const uint32_t* tab = s->sym_tab;
-    V4* A = (V4*)s->sym_A;
-    uint32_t S = ipb_of(shape_of(s));
-    const void* sp = s->sym_spill;
-    void* args[] = {&p, &tab, &A, &rp, &S, &sp};
-    NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_sym_reduce<T>, dim3(ceil_div(rp.np, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
+    s->sym_pass = 0;
     return NB_OK;
 }
 
@@ -798,7 +809,7 @@ int nb_step(nb_sim* s, uint32_t nsteps)
     if (int rc = ensure_gm(s)) return rc;   // the packed K1 forms' (x, y, z, G*m) j-stream, likewise
     // Multi-step calls on the engine's own stream replay a captured graph of
     // kGraphChunk steps (no exchange, no per-kernel timing requested).
-    if (s->own_stream && s->graphs_ok && !exchange && !s->timing && nsteps >= kGraphChunk) {
+    if (s->own_stream && s->graphs_ok && !exchange && !s->timing && !s->sym_rank && nsteps >= kGraphChunk) {
         for (int which = 1; which >= 0; --which) {
             while (nsteps >= kGraphSteps[which] && ensure_graph(s, which)) {
                 NB_HIP(s, hipGraphLaunch(s->graphs[which].exec, s->stream));
@@ -818,7 +829,7 @@ int nb_step(nb_sim* s, uint32_t nsteps)
         if (s->sym_rank) {
             // rank form of the symmetric pass: force pass -> this rank's sums for every row -> reduce-scatter across the ranks
             // -> integrate own rows -> all-gather of the new positions
-            if (!s->rccl) return fail(s, NB_ERR_STATE, "nb_step: an NB_FLAG_SYM_SHARD handle needs nb_rccl_attach (or nb_multi) for its reduce-scatter");
+            if (!s->rccl && !s->sym_local) return fail(s, NB_ERR_STATE, "nb_step: an NB_FLAG_SYM_SHARD handle needs nb_rccl_attach (or nb_multi) for its reduce-scatter");
             // an overlapped all-gather of the previous step still in flight: the sweeps whose travelers are this rank's own rows
             // (phase A, ~1 / ranks of the work) are issued before the engine stream waits for it
             const bool split = s->gather_pending;
@@ -828,11 +839,12 @@ int nb_step(nb_sim* s, uint32_t nsteps)
             if (recr) NB_HIP(s, hipEventRecord(evr.e[0], s->stream));
             if (int rc = nbi::sym_rank_phase_a(s, recr ? evr.e[7] : nullptr, split)) return rc;
             if (recr) { NB_HIP(s, hipEventRecord(evr.e[1], s->stream)); evr.rs = true; }
-            if (int rc = nbi::rccl_reduce_scatter_A(s)) return rc;
+            if (!s->sym_local) { if (int rc = nbi::rccl_reduce_scatter_A(s)) return rc; }
             if (recr) NB_HIP(s, hipEventRecord(evr.e[6], s->stream));
             if (int rc = nbi::sym_rank_phase_b(s)) return rc;
             if (recr) NB_HIP(s, hipEventRecord(evr.e[2], s->stream));
             NB_HIP(s, hipGetLastError());
+            if (s->sym_local) { if (recr) s->pending.push_back(evr); continue; }      // a whole system on this device: nothing to exchange
             if (int rc = nbi::rccl_exchange_begin(s)) return rc;
             if (nbi::rccl_overlapped(s)) s->gather_pending = true;        // waited for inside the next force pass (or by whoever reads the positions first)
             else if (recr) { NB_HIP(s, hipEventRecord(evr.e[5], s->stream)); evr.xchg = true; }
@@ -1119,7 +1131,7 @@ int nb_plan_query(const nb_config* cfg_in, int n_cu, double clock_hz, nb_plan_in
     plan_handle(&tmp, cfg, n_cu, clock_hz, device_mem);
     const Shape sh = shape_of(&tmp);
     if (!kernel_of(tmp.f64, sh)) return fail(nullptr, NB_ERR_INVALID, "nb_plan_query: no kernel for shape " + tmp.variant);
-    const uint32_t size = out->struct_size;
+    const uint32_t size = out->struct_size, want_pass = out->sym_pass;
     memset(out, 0, sizeof *out);
     out->struct_size = size;
     out->kind = (uint32_t)sh.kind; out->ipl = (uint32_t)sh.ipl; out->ls = (uint32_t)sh.ls; out->x = (uint32_t)sh.x;
@@ -1132,9 +1144,21 @@ int nb_plan_query(const nb_config* cfg_in, int n_cu, double clock_hz, nb_plan_in
     out->sym_spill_rows = tmp.sym_spill_rows;
     static_assert(sizeof(out->sym_rank_plan) == sizeof(tmp.sym_rank_plan), "nb_plan_info::sym_rank_plan mirrors nb_sim::sym_rank_plan");
     memcpy(out->sym_rank_plan, tmp.sym_rank_plan, sizeof out->sym_rank_plan);
-    out->tab_len = (uint32_t)tmp.sym_tab_host.size();
+    out->sym_passes = (uint32_t)tmp.sym_passes.size();
+    out->sym_local = tmp.sym_local;
+    size_t tab_from = 0, tab_to = tmp.sym_tab_host.size();
+    if (!tmp.sym_passes.empty()) {
+        if (want_pass >= tmp.sym_passes.size()) return fail(nullptr, NB_ERR_INVALID, "nb_plan_query: sym_pass out of range");
+        const auto& ps = tmp.sym_passes[want_pass];
+        out->sym_pass = want_pass;
+        memcpy(out->sym_rank_plan, ps.plan, sizeof out->sym_rank_plan);
+        out->sym_pass_k_lo = ps.k_lo; out->sym_pass_k_hi = ps.k_hi; out->sym_pass_d0 = ps.d0;
+        tab_from = ps.tab_off;
+        tab_to = want_pass + 1 < tmp.sym_passes.size() ? tmp.sym_passes[want_pass + 1].tab_off : tmp.sym_tab_host.size();
+    }
+    out->tab_len = (uint32_t)(tab_to - tab_from);
     snprintf(out->variant, sizeof out->variant, "%s", tmp.variant.c_str());
-    if (tab) memcpy(tab, tmp.sym_tab_host.data(), sizeof(uint32_t) * (out->tab_len < tab_cap ? out->tab_len : tab_cap));
+    if (tab) memcpy(tab, tmp.sym_tab_host.data() + tab_from, sizeof(uint32_t) * (out->tab_len < tab_cap ? out->tab_len : tab_cap));
     return NB_OK;
 }
 

@@ -105,6 +105,9 @@ struct nb_sim {
     bool sym_rank = false;
     uint32_t sym_g0 = 0, sym_g1 = 0;
     uint32_t sym_rank_plan[16] = {0};   // nb::SymRankPlan: the two phases (own-row travelers first), their wave counts and layer bases
+    std::vector<nbp::LaunchPlan::SymPass> sym_passes;   // the passes over the ring distances (one, or several when the layers of one would not fit)
+    uint32_t sym_pass = 0;              // the pass launch_force runs
+    bool sym_local = false;             // the rank-form pipeline of a WHOLE system on this device: no communicator, no collectives
     void* sym_A = nullptr;
     std::string variant, err;
     nb_exchange_fn xfn = nullptr;

@@ -303,39 +303,37 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, u
 
 // Rank form (NB_FLAG_SYM_SHARD): the handle's own super-blocks [sb / S, (sb + sc) / S), their lists split into the sweeps whose
 // travelers are own rows (phase A) and the rest (phase B); see nb::SymRankPlan.
-static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, uint32_t sb, uint32_t sc, const nb_config& cfg, int n_cu)
+// One pass of the rank form: the sweeps of the own super-blocks [g0, g1) whose position in their list lies in the window
+// [k_lo, k_hi) (ring sweeps) -- plus, when `with_own_chunks`, each super-block's resident-only sweeps -- split into phase A (travelers
+// inside the own rows) and phase B, each cut into its wave ranges.  Appends the pass's tables to s->sym_tab_host.
+static LaunchPlan::SymPass build_rank_pass(LaunchPlan* s, nb::SymRankPlan rp, uint32_t n, uint32_t S, uint32_t Wfull, bool whole_sweeps,
+                                           uint32_t k_lo, uint32_t k_hi, bool with_own_chunks, uint32_t* layers_out, uint32_t* spill_rows_out)
 {
-    const uint32_t S = ipb_of(sh), cps = S / 64u;                    // one traveler per lane
-    const uint32_t nsb = ceil_div(n, S), H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
-    nb::SymRankPlan rp;
-    rp.np = nsb * S; rp.nsb = nsb;
-    rp.total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps; rp.total_lo = (H + 1) * cps;
-    rp.n_hi = n_hi; rp.H = H;
-    rp.g0 = sb / S; rp.g1 = (sb + sc) / S;
+    const uint32_t cps = S / 64u, nsb = rp.nsb, n_hi = rp.n_hi;
     const uint32_t ng = rp.g1 - rp.g0;
-    std::vector<uint32_t> preA(ng + 1, 0), preB(ng + 1, 0), acut(ng, 0);
+    std::vector<uint32_t> preA(ng + 1, 0), preB(ng + 1, 0), a_lo(ng, 0), a_len(ng, 0), b_lo(ng, 0);
     for (uint32_t gi = 0; gi < ng; ++gi) {
         const uint32_t g = rp.g0 + gi;
         const uint32_t total = g < n_hi ? rp.total_hi : rp.total_lo, ring = total - cps;
         const uint32_t a = std::min(ring, (rp.g1 - 1 - g) * cps);       // ring distances d with g + 1 + d < g1: travelers inside the own rows
-        acut[gi] = a;
-        preA[gi + 1] = preA[gi] + a + cps;                               // ... and the super-block's own chunks (resident-only)
-        preB[gi + 1] = preB[gi] + (ring - a);
+        a_lo[gi] = std::min(a, k_lo);
+        a_len[gi] = std::min(a, k_hi) - a_lo[gi];
+        b_lo[gi] = std::min(ring, std::max(a, k_lo));
+        const uint32_t b_hi = std::min(ring, std::max(a, k_hi));
+        preA[gi + 1] = preA[gi] + a_len[gi] + (with_own_chunks ? cps : 0u);      // ... and the super-block's own chunks (resident-only)
+        preB[gi + 1] = preB[gi] + (b_hi - b_lo[gi]);
     }
     rp.LA = preA[ng]; rp.LB = preB[ng];
-    const uint32_t L = rp.LA + rp.LB;
-    const uint32_t kw = cfg.jsplit ? cfg.jsplit : (L >= 16u * (uint32_t)n_cu ? 2u : 1u);
-    const uint32_t Wfull = 4u * (uint32_t)n_cu * kw;
     // units per sweep: a rank's share is small by construction (1 / ranks of the system in each phase), so quarter sweeps unless there
     // are dozens of sweeps per wave in BOTH phases
-    const uint32_t ups = (cfg.flags & NB_FLAG_WHOLE_SWEEPS) ? 1u : std::max(sym_units(rp.LA, Wfull, false), sym_units(rp.LB ? rp.LB : rp.LA, Wfull, false));
+    const uint32_t ups = whole_sweeps ? 1u : std::max(sym_units(rp.LA ? rp.LA : rp.LB, Wfull, false), sym_units(rp.LB ? rp.LB : rp.LA, Wfull, false));
     rp.ups = ups;
     rp.WA = std::min(Wfull, rp.LA);           // at least one sweep's worth of units per wave: every wave that touches a super-block adds a
     rp.WB = std::min(Wfull, rp.LB);           // resident layer to it, which nb_sym_reduce reads back (N = 65,536 over 8 ranks: 744 layers otherwise)
     const uint32_t nch = rp.np / 64u;
-    const size_t tab0 = 4 * (size_t)nsb, pre0 = tab0, sp0 = pre0 + 2 * ((size_t)ng + 1);
-    s->sym_tab_host.assign(sp0 + (ups > 1 ? 2 * (size_t)nch : 0), 0);
-    uint32_t max_ra = 1, max_rb = 0;
+    const size_t tab0 = s->sym_tab_host.size(), pre0 = tab0 + 4 * (size_t)nsb, sp0 = pre0 + 2 * ((size_t)ng + 1);
+    s->sym_tab_host.resize(sp0 + (ups > 1 ? 2 * (size_t)nch : 0), 0);
+    uint32_t max_ra = rp.LA ? 1u : 0u, max_rb = 0;
     auto wave_of = [](uint64_t u, uint64_t Lu, uint32_t Wp) {
         uint32_t w = (uint32_t)(u * Wp / Lu);
         while (w + 1 < Wp && (uint64_t)(w + 1) * Lu / Wp <= u) ++w;
@@ -343,11 +341,13 @@ static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t
         return w;
     };
     for (uint32_t gi = 0; gi < ng; ++gi) {
-        uint32_t* t = &s->sym_tab_host[4 * (size_t)(rp.g0 + gi)];
+        uint32_t* t = &s->sym_tab_host[tab0 + 4 * (size_t)(rp.g0 + gi)];
         const uint64_t LuA = (uint64_t)rp.LA * ups, LuB = (uint64_t)rp.LB * ups;
-        const uint32_t fa = wave_of((uint64_t)preA[gi] * ups, LuA, rp.WA), la = wave_of((uint64_t)preA[gi + 1] * ups - 1, LuA, rp.WA);
-        t[0] = fa; t[1] = la - fa + 1;
-        max_ra = std::max(max_ra, t[1]);
+        if (preA[gi + 1] > preA[gi]) {
+            const uint32_t fa = wave_of((uint64_t)preA[gi] * ups, LuA, rp.WA), la = wave_of((uint64_t)preA[gi + 1] * ups - 1, LuA, rp.WA);
+            t[0] = fa; t[1] = la - fa + 1;
+            max_ra = std::max(max_ra, t[1]);
+        }
         if (preB[gi + 1] > preB[gi]) {
             const uint32_t fb = wave_of((uint64_t)preB[gi] * ups, LuB, rp.WB), lb = wave_of((uint64_t)preB[gi + 1] * ups - 1, LuB, rp.WB);
             t[2] = fb; t[3] = lb - fb + 1;
@@ -356,7 +356,7 @@ static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t
     }
     std::copy(preA.begin(), preA.end(), s->sym_tab_host.begin() + pre0);
     std::copy(preB.begin(), preB.end(), s->sym_tab_host.begin() + pre0 + ng + 1);
-    s->sym_spill_rows = 0;
+    *spill_rows_out = 0;
     if (ups > 1) {
         // a wave whose range starts inside a sweep spills that sweep's traveler sums: per 64-row chunk the waves to add (B waves numbered from WA)
         struct Spill { uint32_t chunk, wave; };
@@ -370,9 +370,9 @@ static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t
                 if (u % ups == 0 || (uint64_t)(w + 1) * Lu / Wp == u) continue;
                 const uint32_t p = (uint32_t)(u / ups);
                 const uint32_t gi = (uint32_t)(std::upper_bound(pre.begin(), pre.end(), p) - pre.begin()) - 1;
-                const uint32_t g = rp.g0 + gi, j = p - pre[gi];
+                const uint32_t g = rp.g0 + gi, jj = p - pre[gi];
                 const uint32_t total = g < n_hi ? rp.total_hi : rp.total_lo, ring = total - cps;
-                const uint32_t k = phase ? acut[gi] + j : (j < acut[gi] ? j : ring + (j - acut[gi]));
+                const uint32_t k = phase ? b_lo[gi] + jj : (jj < a_len[gi] ? a_lo[gi] + jj : ring + (jj - a_len[gi]));
                 if (k >= ring) continue;                                    // resident-only sweep
                 uint32_t tb = g + 1 + k / cps;
                 if (tb >= nsb) tb -= nsb;
@@ -381,7 +381,7 @@ static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t
                 sp.push_back({tstart / 64u, (phase ? rp.WA : 0u) + w});
             }
         }
-        std::stable_sort(sp.begin(), sp.end(), [](const Spill& a, const Spill& b) { return a.chunk < b.chunk; });
+        std::stable_sort(sp.begin(), sp.end(), [](const Spill& x, const Spill& y) { return x.chunk < y.chunk; });
         const size_t ids0 = sp0 + 2 * (size_t)nch;
         s->sym_tab_host.resize(ids0 + sp.size(), 0);
         for (size_t e = 0; e < sp.size(); ++e) {
@@ -390,24 +390,69 @@ static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t
             ++ent[1];
             s->sym_tab_host[ids0 + e] = sp[e].wave;
         }
-        s->sym_spill_rows = (rp.WA + rp.WB) * 64u;
+        *spill_rows_out = (rp.WA + rp.WB) * 64u;
     }
     rp.r_layer0 = 0; rp.rb_layer0 = max_ra; rp.t_layer0 = max_ra + max_rb;
-    static_assert(sizeof(rp) == sizeof(s->sym_rank_plan), "LaunchPlan::sym_rank_plan holds a SymRankPlan");
-    memcpy(s->sym_rank_plan, &rp, sizeof rp);
-    // the SymWPlan summary the reports read
+    const uint32_t d0 = k_lo / cps;
+    const uint32_t dmax = rp.H + (n_hi ? 1u : 0u);                         // ring distances of the system
+    const uint32_t d1 = std::min(dmax, k_hi == 0xffffffffu ? dmax : k_hi / cps);
+    *layers_out = rp.t_layer0 + (d1 > d0 ? d1 - d0 : 0u);
+    LaunchPlan::SymPass pass;
+    static_assert(sizeof(rp) == sizeof(pass.plan), "SymPass::plan holds a SymRankPlan");
+    memcpy(pass.plan, &rp, sizeof rp);
+    pass.tab_off = (uint32_t)tab0; pass.k_lo = k_lo; pass.k_hi = k_hi; pass.d0 = d0;
+    return pass;
+}
+
+// Rank form (NB_FLAG_SYM_SHARD): the handle's own super-blocks [sb / S, (sb + sc) / S), their lists split into the sweeps whose
+// travelers are own rows (phase A) and the rest (phase B); see nb::SymRankPlan.  local_passes > 0: the same pipeline for a WHOLE
+// system on one device (no communicator), its ring distances processed in that many passes so that the traveler layers fit the budget.
+static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, uint32_t sb, uint32_t sc, const nb_config& cfg, int n_cu,
+                              uint32_t local_passes)
+{
+    const uint32_t S = ipb_of(sh), cps = S / 64u;                    // one traveler per lane
+    const uint32_t nsb = ceil_div(n, S), H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
+    nb::SymRankPlan rp;
+    memset(&rp, 0, sizeof rp);
+    rp.np = nsb * S; rp.nsb = nsb;
+    rp.total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps; rp.total_lo = (H + 1) * cps;
+    rp.n_hi = n_hi; rp.H = H;
+    rp.g0 = local_passes ? 0u : sb / S; rp.g1 = local_passes ? nsb : (sb + sc) / S;
+    const uint64_t Lown = (uint64_t)(rp.g1 - rp.g0) * rp.total_lo;
+    const uint32_t kw = cfg.jsplit ? cfg.jsplit : (Lown >= 16u * (uint64_t)n_cu ? 2u : 1u);
+    const uint32_t Wfull = 4u * (uint32_t)n_cu * kw;
+    const bool whole_sweeps = (cfg.flags & NB_FLAG_WHOLE_SWEEPS) != 0 || local_passes > 1;       // spill rows belong to one pass: several passes keep whole sweeps
+    s->sym_tab_host.clear();
+    s->sym_passes.clear();
+    uint32_t layers = 0, spill_rows = 0;
+    const uint32_t dmax = H + (n_hi ? 1u : 0u), passes = local_passes ? local_passes : 1u;
+    const uint32_t per = ceil_div(dmax, passes);                      // ring distances per pass
+    for (uint32_t q = 0; q < passes; ++q) {
+        const uint32_t k_lo = q * per * cps, k_hi = q + 1 == passes ? 0xffffffffu : (q + 1) * per * cps;
+        uint32_t lay = 0, sp = 0;
+        s->sym_passes.push_back(build_rank_pass(s, rp, n, S, Wfull, whole_sweeps, k_lo, k_hi, q + 1 == passes, &lay, &sp));
+        layers = std::max(layers, lay); spill_rows = std::max(spill_rows, sp);
+    }
+    memcpy(&rp, s->sym_passes[0].plan, sizeof rp);
+    memcpy(s->sym_rank_plan, s->sym_passes[0].plan, sizeof s->sym_rank_plan);
+    s->sym_spill_rows = spill_rows;
+    s->sym_local = local_passes != 0;
+    // the SymWPlan summary the reports read (first pass)
     nb::SymWPlan pl;
+    uint32_t Lsum = 0;
+    for (const auto& ps : s->sym_passes) Lsum += ps.plan[11] + ps.plan[12];
     pl.np = rp.np; pl.nsb = nsb; pl.W = rp.WA + rp.WB; pl.total_hi = rp.total_hi; pl.total_lo = rp.total_lo; pl.n_hi = n_hi; pl.H = H;
-    pl.r_layer0 = 0; pl.t_layer0 = rp.t_layer0; pl.L = L; pl.ups = ups;
+    pl.r_layer0 = 0; pl.t_layer0 = rp.t_layer0; pl.L = Lsum; pl.ups = rp.ups;
     pl.p0 = (rp.g0 <= n_hi ? rp.g0 * rp.total_hi : n_hi * rp.total_hi + (rp.g0 - n_hi) * rp.total_lo);
     memcpy(s->sym_plan, &pl, sizeof pl);
     s->sym_rank = true; s->sym_g0 = rp.g0; s->sym_g1 = rp.g1;
-    s->sym = true; s->symw = true; s->sym_np = rp.np; s->sym_layers = rp.t_layer0 + H + (n_hi ? 1u : 0u);
+    s->sym = true; s->symw = true; s->sym_np = rp.np; s->sym_layers = layers;
     s->ipl = sh.ipl; s->ls = 1; s->packed = !f64; s->sgpr = false; s->fused = false; s->direct = false; s->jpk = false;
     s->ws = sh.x; s->tl = 1;
-    s->jsplit = rp.WA + rp.WB; s->j_per_split = ceil_div(L, std::max(1u, rp.WA + rp.WB)) * 64u; s->swap_acc = false;
-    s->own_split0 = 0; s->own_splits = rp.WA;          // the waves whose sweeps read the rank's own rows only: issued before the wait for the gather
+    s->jsplit = rp.WA + rp.WB; s->j_per_split = ceil_div(Lsum, std::max(1u, rp.WA + rp.WB)) * 64u; s->swap_acc = false;
+    s->own_split0 = 0; s->own_splits = local_passes ? 0u : rp.WA;          // the waves whose sweeps read the rank's own rows only: issued before the wait for the gather
     name_variant(s, f64, sh);
+    if (local_passes) { char buf[24]; snprintf(buf, sizeof buf, "_p%u", local_passes); s->variant += buf; }
 }
 
 // Workgroup form (nb_force_sym<4,4,2>, the A/B arm): Q segments per super-block's chunk list.
@@ -495,7 +540,8 @@ LaunchPlan plan_launch(const PlanInput& in)
     }
 
     Shape sh{f64 ? kScalar : kPkLds, 2, 1, 1};
-    uint32_t js = cfg.jsplit, sym_k = 0, sym_ups = 0;
+    uint32_t js = cfg.jsplit, sym_k = 0, sym_ups = 0, sym_passes = 0, ordered_js = 0;
+    Shape ordered_sh{kScalar, 1, 1, 1};
     // NB_FLAG_SYM_SHARD: a rank's shard whose cross-rank reduction the engine's native exchange provides takes the RANK form of the
     // symmetric pass when its rows are whole super-blocks (1,024 rows, or 512); otherwise the flag is ignored
     int rank_ipl = 0;
@@ -639,6 +685,21 @@ LaunchPlan plan_launch(const PlanInput& in)
         if (!pinned && whole && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
             const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, f64, layer_budget, (cfg.flags & NB_FLAG_WHOLE_SWEEPS) != 0);
             if (sc2.ipl && sc2.t < 0.98 * (pick ? pick->t : best_t)) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; sym_ups = sc2.ups; }     // a clear win only: both estimates are good to ~3 %
+            else if (!sc2.ipl) {
+                // no resident count whose layers fit the budget (they grow with N^2: 103 GB at 4 M bodies): the rank-form pipeline on
+                // this one device, its ring distances in PASSES that reuse the layers -- still every unordered pair once (~80 % of the
+                // roofline) instead of the ordered-pair kernels' 60 %
+                const uint32_t S = f64 ? 512u : 1024u, nsb = ceil_div(n, S);
+                const double full = sym_layer_bytes(n, S, esz);
+                if (nsb >= 8 && nsb <= 32768 && full > layer_budget) {          // up to 32 M bodies: the tables are O(super-blocks) per pass
+                    const uint32_t dmax = (nsb - 1) / 2 + ((nsb & 1u) ? 0u : 1u);
+                    uint32_t passes = (uint32_t)std::ceil(full / (0.75 * layer_budget));
+                    passes = std::min(std::min(std::max(passes, 2u), dmax), 64u);
+                    ordered_sh = sh; ordered_js = js;                           // what to fall back to if even one distance per pass does not fit
+                    sh = {kSym, (int)(S / 64u), 1, 3};
+                    sym_passes = ceil_div(dmax, ceil_div(dmax, passes));        // no empty pass
+                }
+            }
         }
     }
     if (js < 1) {   // pinned shape outside the model's candidate list: fill ~4096 workgroups
@@ -648,7 +709,22 @@ LaunchPlan plan_launch(const PlanInput& in)
         if (js < 1) js = 1;
     }
     if (sh.kind == kFused || sh.kind == kDirect) js = 1;
-    if (sh.kind == kSym && rank_ipl) { lay_out_symw_rank(s, sh, f64, n, sb, sc, cfg, n_cu); return plan; }
+    if (sh.kind == kSym && sym_passes) {
+        // the layers actually needed (traveler layers of a pass + the resident layers of its waves) against the budget: more passes
+        // until they fit; if one distance per pass still does not, the ordered-pair kernels
+        const uint32_t S = ipb_of(sh), nsb = ceil_div(n, S), dmax = (nsb - 1) / 2 + ((nsb & 1u) ? 0u : 1u);
+        for (int tries = 0; tries < 6; ++tries) {
+            plan = LaunchPlan();
+            lay_out_symw_rank(s, sh, f64, n, sb, sc, cfg, n_cu, sym_passes);
+            if (3.0 * (double)esz * s->sym_np * s->sym_layers <= layer_budget) return plan;
+            if (sym_passes >= dmax || sym_passes >= 256u) break;
+            sym_passes = std::min(std::min(dmax, 256u), sym_passes * 2);
+            sym_passes = ceil_div(dmax, ceil_div(dmax, sym_passes));
+        }
+        plan = LaunchPlan();
+        sh = ordered_sh; js = ordered_js;
+    }
+    if (sh.kind == kSym && rank_ipl) { lay_out_symw_rank(s, sh, f64, n, sb, sc, cfg, n_cu, 0); return plan; }
     if (sh.kind == kSym && sh.x != 4) { lay_out_symw(s, sh, f64, n, sb, sc, cfg, n_cu, 0, sym_k, sym_ups); return plan; }
     if (sh.kind == kSym) { lay_out_sym_wg(s, sh, f64, n, cfg, n_cu); return plan; }
     s->ipl = sh.ipl; s->ls = sh.ls;

@@ -101,6 +101,16 @@ struct LaunchPlan {
     uint32_t sym_plan[12] = {0};         // nb::SymWPlan (symw) or nb::SymPlan, as plain words
     uint32_t sym_spill_rows = 0;         // wave-granular form with ups > 1: rows of the spill buffer (W x travelers per chunk)
     uint32_t sym_rank_plan[16] = {0};    // rank form: nb::SymRankPlan as plain words (sym_plan then holds the SymWPlan summary: W = WA + WB, L = LA + LB)
+    // The rank-form pipeline in PASSES over the ring distances (layers reused from pass to pass, nb_sym_reduce accumulating): one
+    // pass for an ordinary rank; several for a whole system whose traveler layers would not fit the layer budget (sym_local: no
+    // communicator -- force passes, reduce, integrate on one device; N = 4 M bodies: 100 GB of layers in one pass).
+    struct SymPass {
+        uint32_t plan[16];               // nb::SymRankPlan of the pass
+        uint32_t tab_off;                // where the pass's tables start in sym_tab_host
+        uint32_t k_lo, k_hi, d0;         // the pass's window of every super-block's ring sweeps [k_lo, k_hi) and its first ring distance
+    };
+    std::vector<SymPass> sym_passes;
+    bool sym_local = false;
     std::vector<uint32_t> sym_tab_host;  // wave-granular form: {first wave, wave count} per super-block [2 nsb words]; with ups > 1
                                          // followed by {offset, count} per traveler chunk [2 np / CH words] and the spill lists' wave numbers
     std::string variant;

@@ -57,7 +57,9 @@ class nb_plan_info(C.Structure):
         "kind", "ipl", "ls", "x", "jsplit", "j_per_split", "own_split0", "own_splits",
         "sym", "symw", "sym_rank", "sym_np", "sym_layers", "sym_g0", "sym_g1")] + [
         ("sym_plan", C.c_uint32 * 11), ("tab_len", C.c_uint32), ("variant", C.c_char * 112),
-        ("sym_ups", C.c_uint32), ("sym_spill_rows", C.c_uint32), ("sym_rank_plan", C.c_uint32 * 16)]
+        ("sym_ups", C.c_uint32), ("sym_spill_rows", C.c_uint32), ("sym_rank_plan", C.c_uint32 * 16),
+        ("sym_pass", C.c_uint32), ("sym_passes", C.c_uint32), ("sym_pass_k_lo", C.c_uint32), ("sym_pass_k_hi", C.c_uint32),
+        ("sym_pass_d0", C.c_uint32), ("sym_local", C.c_uint32)]
 
 
 class nb_step_timing(C.Structure):          # include/nbody3d_hip.h
@@ -178,7 +180,7 @@ SYM_PLAN_WORDS = ("np", "nsb", "q", "total_hi", "total_lo", "n_hi", "H", "r_laye
 
 
 def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=0, n_cu=256, clock_hz=2.4e9, device=-1,
-               layer_budget_mib=0):
+               layer_budget_mib=0, sym_pass=0):
     """nb_plan_query: the launch plan nb_create would build -- the engine's planner run on the host alone (works without a
     GPU when n_cu and clock_hz are given; 0 means "as on the device").  Returns a dict: the shape digits, the j-partitions,
     and for the symmetric pass `plan` (the words the kernels receive, by name) and `tab` (first wave, wave count per super-block)."""
@@ -194,16 +196,20 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
     cfg.layer_budget_mib = int(layer_budget_mib)
     info = nb_plan_info()
     info.struct_size = C.sizeof(nb_plan_info)
+    info.sym_pass = int(sym_pass)
     rc = L.nb_plan_query(C.byref(cfg), int(n_cu), float(clock_hz), C.byref(info), None, 0)
     if rc != 0:
         raise NBodyError(rc, L.nb_last_error(None).decode())
     tab = np.zeros(info.tab_len, np.uint32)
     if info.tab_len:
+        info.sym_pass = int(sym_pass)
         rc = L.nb_plan_query(C.byref(cfg), int(n_cu), float(clock_hz), C.byref(info), tab.ctypes.data_as(C.POINTER(C.c_uint32)), tab.size)
         if rc != 0:
             raise NBodyError(rc, L.nb_last_error(None).decode())
     out = {k: int(getattr(info, k)) for k, _ in nb_plan_info._fields_[1:16]}
     out["variant"] = info.variant.decode()
+    out.update(passes=int(info.sym_passes), local=int(info.sym_local), pass_k_lo=int(info.sym_pass_k_lo), pass_k_hi=int(info.sym_pass_k_hi),
+               pass_d0=int(info.sym_pass_d0))
     if info.sym:
         out["plan"] = dict(zip(SYMW_PLAN_WORDS if info.symw else SYM_PLAN_WORDS, (int(w) for w in info.sym_plan)))
         nsb = out["plan"]["nsb"]

@@ -289,6 +289,52 @@ def test_rank_form_plans_tile_the_pair_list(n, g, prec):
     assert np.all(seen == 1)                                     # the ranks' phases tile the system's pair list
 
 
+@pytest.mark.parametrize("n,prec,budget", [(100000, "f32", 48), (131072, "f32", 64), (65536, "f64", 48), (2500000, "f32", 16384), (4194304, "f32", 0)])
+def test_layer_budget_passes_tile_the_pair_list(n, prec, budget):
+    """A whole system whose traveler layers would not fit the layer budget: the rank-form pipeline on one device ("local": no
+    communicator), the ring distances in passes that reuse the layers.  Walked pass by pass as the kernel does: every position of
+    every super-block's list exactly once, the traveler layers a pass writes lie inside its window, and the layers fit the budget."""
+    q0 = capi.plan_query(n, precision=prec, layer_budget_mib=budget)
+    assert q0["sym_rank"] and q0["local"] and q0["passes"] >= 2 and q0["variant"].endswith("_p%d" % q0["passes"]), q0["variant"]
+    esz = 8 if prec == "f64" else 4
+    limit = budget * 2**20 if budget else min(288e9 / 3, 96 * 2**30)
+    assert 3 * esz * q0["sym_np"] * q0["sym_layers"] <= limit
+    S = 64 * q0["ipl"]
+    cps = S // 64
+    rp0 = q0["rank_plan"]
+    nsb, n_hi, H = rp0["nsb"], rp0["n_hi"], rp0["H"]
+    totals = np.where(np.arange(nsb) < n_hi, rp0["total_hi"], rp0["total_lo"])
+    seen = [np.zeros(t, np.int32) for t in totals]
+    if nsb > 512:                 # big systems: check a sample of super-blocks (the walk is O(sweeps))
+        sample = set(np.linspace(0, nsb - 1, 64).astype(int).tolist())
+    else:
+        sample = set(range(nsb))
+    for ps in range(q0["passes"]):
+        q = capi.plan_query(n, precision=prec, layer_budget_mib=budget, sym_pass=ps)
+        rp = q["rank_plan"]
+        assert rp["g0"] == 0 and rp["g1"] == nsb and rp["ups"] == 1 and q["spill_rows"] == 0
+        k_lo, k_hi, d0 = q["pass_k_lo"], q["pass_k_hi"], q["pass_d0"]
+        assert k_lo == d0 * cps and (ps == 0) == (k_lo == 0) and (ps == q0["passes"] - 1) == (k_hi == 0xffffffff)
+        d1 = (k_hi // cps) if k_hi != 0xffffffff else H + (1 if n_hi else 0)
+        assert rp["t_layer0"] + (d1 - d0) <= q0["sym_layers"]
+        for phase, L, W, pre in (("A", rp["LA"], rp["WA"], q["prefix_a"]), ("B", rp["LB"], rp["WB"], q["prefix_b"])):
+            assert len(pre) == nsb + 1 and pre[0] == 0 and pre[-1] == L and (W == min(4 * 256 * 2, L))
+            for g in sample:
+                ring = totals[g] - cps
+                a = min(ring, (nsb - 1 - g) * cps)
+                a_lo, a_len = min(a, k_lo), min(a, k_hi) - min(a, k_lo)
+                b_lo = min(ring, max(a, k_lo))
+                ln = int(pre[g + 1]) - int(pre[g])
+                j = np.arange(ln)
+                k = (b_lo + j) if phase == "B" else np.where(j < a_len, a_lo + j, ring + (j - a_len))
+                assert np.all(k < totals[g])
+                sym = k < ring
+                assert np.all((k[sym] >= k_lo) & (k[sym] < k_hi))                  # ring sweeps inside the window: layers t_layer0 + d - d0
+                seen[g][k] += 1
+    for g in sample:
+        assert np.all(seen[g] == 1), g
+
+
 def test_rank_form_needs_whole_super_blocks():
     assert not capi.plan_query(262144, shard=(1000, 32768), flags=NB_FLAG_SYM_SHARD)["sym"]           # unaligned rows
     assert not capi.plan_query(262144, shard=(0, 32768), flags=NB_FLAG_SYM_SHARD | NB_FLAG_NO_SYM)["sym"]
@@ -331,9 +377,12 @@ def test_model_choice_table():
     for n, prefix in want.items():
         assert capi.plan_query(n)["variant"].startswith(prefix), (n, capi.plan_query(n)["variant"])
     assert capi.plan_query(262144, precision="f64")["variant"].startswith("f64_symw_ipl8_j1_w2048")
-    # the layers grow with N^2: past the budget (a third of the device memory, at most 96 GiB; nb_config.layer_budget_mib) ordered pairs
-    assert capi.plan_query(2500000)["sym"] == 1 and capi.plan_query(2500000, layer_budget_mib=16384)["sym"] == 0
-    assert capi.plan_query(4500000)["sym"] == 0 and capi.plan_query(1048576, precision="f64")["sym"] == 1
+    # the layers grow with N^2: past the budget (a third of the device memory, at most 96 GiB; nb_config.layer_budget_mib) the ring
+    # distances go in passes that reuse the layers (the rank-form pipeline on one device, "_pN"); ordered pairs only when not even one
+    # distance per pass fits
+    assert capi.plan_query(2500000)["variant"].startswith("f32pk_symw_ipl16") and capi.plan_query(2500000, layer_budget_mib=16384)["variant"].endswith("_p3")
+    assert capi.plan_query(4500000)["variant"].startswith("f32pk_symwrank_ipl16") and "_p" in capi.plan_query(4500000)["variant"]
+    assert capi.plan_query(1048576, precision="f64")["sym"] == 1 and capi.plan_query(40002, layer_budget_mib=4)["sym"] == 0
 
 
 def test_bad_arguments_are_errors():

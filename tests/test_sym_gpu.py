@@ -217,7 +217,9 @@ def test_handles_that_cannot_use_the_symmetric_pass_fall_back():
         assert "sgpr" in s.variant, s.variant
     with Simulation(n) as s:
         assert "symw" in s.variant, s.variant
-    with Simulation(2500000, layer_budget_mib=16384) as s:       # the traveler layers grow with N^2 (here 37 GB): past the budget the ordered-pair kernel runs
+    with Simulation(2500000, layer_budget_mib=16384) as s:       # the traveler layers grow with N^2 (here 37 GB): past the budget the ring distances go in passes
+        assert "symwrank" in s.variant and s.variant.endswith("_p3"), s.variant
+    with Simulation(40002, layer_budget_mib=4) as s:             # ... and when not even one distance per pass fits, the ordered-pair kernel
         assert "sgpr" in s.variant, s.variant
 
 
@@ -244,6 +246,55 @@ def test_two_million_bodies_take_the_symmetric_pass():
     x = b[:, :3].astype(np.float64)
     m = b[:, 3].astype(np.float64)
     for i in (0, 1, 999999, 1234567, n - 1):
+        d = x - x[i]
+        r2 = (d * d).sum(1) + 1e-4
+        want = (m[:, None] * d / (r2 * np.sqrt(r2))[:, None]).sum(0)
+        assert np.abs(acc[i, :3] - want).max() <= 2e-5 * np.abs(want).max(), i
+    f = m[:, None] * acc[:, :3].astype(np.float64)
+    assert np.all(np.abs(f.sum(0)) < 1e-6 * np.abs(f).sum(0))
+
+
+@pytest.mark.parametrize("n,precision,budget,passes", [(100000, "f32", 48, 49), (131072, "f32", 64, 64), (65536, "f64", 48, 64), (100001, "f32", 48, None)])
+def test_layer_budget_passes_match_the_oracle_and_the_single_pass(n, precision, budget, passes):
+    """A whole system whose traveler layers do not fit the layer budget (nb_config.layer_budget_mib; by default a third of the device
+    memory: N ~ 4 M bodies) runs the rank-form pipeline on this one device -- force pass, nb_sym_reduce, integrate; no communicator --
+    with its ring distances in PASSES that reuse the layers, instead of falling back to the ordered-pair kernels.  Tiny budgets make
+    small systems do it: against the fp64 oracle, against the single-pass handle, deterministic, and graph-free multi-step calls."""
+    dt_np = np.float64 if precision == "f64" else np.float32
+    b, v = ic.plummer(n, seed=95)
+    b, v = b.astype(dt_np), v.astype(dt_np)
+    bb, vv, aa, name = run(b, v, 3, precision=precision, layer_budget_mib=budget)
+    assert "symwrank" in name and "_p" in name and (passes is None or name.endswith("_p%d" % passes)), name
+    rb, _, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 3)
+    tol_p, tol_a = (1e-12, 1e-11) if precision == "f64" else (TOL_TIGHT, TOL_ACC)
+    assert rel_pos_err(bb, rb, 1.0) < tol_p and np.abs(aa[:, :3] - ra[:, :3]).max() < tol_a * np.abs(ra[:, :3]).max(), name
+    ob, ov, oa, oname = run(b, v, 3, precision=precision)
+    assert "symw_" in oname, oname
+    assert np.abs(aa[:, :3] - oa[:, :3]).max() < (1e-11 if precision == "f64" else 4e-6) * np.abs(oa[:, :3]).max(), (name, oname)
+    again = run(b, v, 3, precision=precision, layer_budget_mib=budget)
+    assert again[0].tobytes() == bb.tobytes() and again[2].tobytes() == aa.tobytes()
+    with Simulation(n, precision=precision, layer_budget_mib=budget) as sim:        # 20 steps in one call = 20 single steps (no graph for this form)
+        sim.init(b, v)
+        sim.simulate(3, 1e-3, 1.0)
+        assert sim.read()[0].tobytes() == bb.tobytes()
+        ke, pe, _ = sim.diagnostics()
+        assert np.isfinite(ke) and np.isfinite(pe)
+
+
+def test_four_million_bodies_keep_the_symmetric_pass():
+    """N = 4,194,304: one pass would need 103 GB of traveler layers (a third of the device memory is the default budget), so the
+    ring distances go in two passes over 49 GB of layers -- every unordered pair still evaluated once.  One step, sampled rows against
+    an fp64 direct sum, momentum of the pair sums."""
+    n = 4194304
+    b, v = ic.plummer(n, seed=8)
+    with Simulation(n) as s:
+        assert "symwrank_ipl16" in s.variant and "_p" in s.variant, s.variant
+        s.init(b, v)
+        s.simulate(1, 1e-3, 1.0)
+        acc = s.read(bodies=False, vel=False)[2]
+    x = b[:, :3].astype(np.float64)
+    m = b[:, 3].astype(np.float64)
+    for i in (0, 1, 2097151, 3456789, n - 1):
         d = x - x[i]
         r2 = (d * d).sum(1) + 1e-4
         want = (m[:, None] * d / (r2 * np.sqrt(r2))[:, None]).sum(0)
