@@ -175,7 +175,7 @@ double sym_layer_budget(const nb_config& cfg, double device_mem)
 uint32_t sym_units(uint64_t L, uint32_t W, bool whole_only)
 {
     if (whole_only || W == 0) return 1;
-    return L < (uint64_t)48 * W ? 4u : 1u;
+    return L < (uint64_t)12 * W ? 8u : L < (uint64_t)48 * W ? 4u : 1u;      // eighths below a dozen sweeps per wave (N = 16,384: 57.2 vs 58.3 us)
 }
 
 SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64, double layer_budget, bool whole_only)
@@ -195,10 +195,12 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
         if (per_simd < 1.0) continue;
         for (uint32_t k = 1; k <= 2; ++k) {
+            if (k == 2 && per_simd < 6.0) continue;      // under ~3 sweeps per wave a second wave's own prologue and resident loads cost more than it hides
+                                                         // (N = 20,000, 16 residents: 85.1 us with two waves per SIMD, 81.8 with one)
             const uint32_t ups = sym_units(L, (uint32_t)simds * k, whole_only);
             // in units of 1 / ups sweep: a wave gets floor or ceil of its share; two waves of a SIMD both round up about min(1, 2p) of the time
             const double pu = per_simd * ups, pw = pu / 2.0, fl = std::floor(pw);
-            const double units = k == 1 ? std::ceil(pu) * 1.019 : (2.0 * fl + 2.0 * std::min(1.0, 2.0 * (pw - fl))) * 1.01;
+            const double units = k == 1 ? std::ceil(pu) * 1.032 : (2.0 * fl + 2.0 * std::min(1.0, 2.0 * (pw - fl))) * 1.01;
             const double sweeps = units / ups;
             const double segs = per_simd / k / (double)total_lo + 1.0;             // super-blocks a wave's range touches
             const double spill = ups > 1 ? simds * k * 64.0 / n : 0.0;             // spill rows K2 adds per body (one 64-row spill per wave)

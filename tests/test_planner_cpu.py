@@ -372,7 +372,7 @@ def test_shard_own_splits_lie_inside_the_shard(n, g):
 
 def test_model_choice_table():
     """The automatic choice at the sizes DESIGN.md quotes (256 CUs, 2.4 GHz): a change of the cost model shows up here."""
-    want = {1024: "f32pk_fused_regs1024", 10000: "f32pk_fused_jpairs", 16384: "f32pk_symw_ipl8_j1_w1024_r34t16_u4", 40002: "f32pk_symw_ipl16_j1_w1024_r28t20_u4",
+    want = {1024: "f32pk_fused_regs1024", 10000: "f32pk_fused_jpairs", 16384: "f32pk_symw_ipl16_j1_w1024_r69t8_u8", 20000: "f32pk_symw_ipl16_j1_w1024_r55t10_u8", 40002: "f32pk_symw_ipl16_j1_w2048_r54t20_u8",
             65536: "f32pk_symw_ipl16_j1_w2048", 262144: "f32pk_symw_ipl16_j1_w2048_r10t128", 1048576: "f32pk_symw_ipl16_j1_w2048"}
     for n, prefix in want.items():
         assert capi.plan_query(n)["variant"].startswith(prefix), (n, capi.plan_query(n)["variant"])
