@@ -76,7 +76,7 @@ def loops(disassembly, min_dwords=64):
             ins.append((int(mm.group(2), 16), size, mm.group(1), ln))
         addr_index = {a: i for i, (a, _, _, _) in enumerate(ins)}
         for i, (a, size, op, ln) in enumerate(ins):
-            if not op.startswith("s_cbranch"):
+            if not (op.startswith("s_cbranch") or op == "s_branch"):
                 continue
             off = int(ln.split()[1])
             if off < 32768:
