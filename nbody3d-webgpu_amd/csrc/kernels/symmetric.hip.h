@@ -179,12 +179,13 @@ void nb_force_sym(const float4* __restrict__ bodies, SymRow* __restrict__ partia
     }
 }
 
-// The same pass with the WAVE as the unit of work (no LDS, no barrier): a super-block is one wave's 128*NG residents, and
+// The same pass with the WAVE as the unit of work (no LDS in the sweeps, one barrier at the very end): a super-block is one wave's 128*NG residents, and
 // the chunk lists of all super-blocks, laid end to end (L chunk-sweeps), are cut into W contiguous ranges of floor/ceil(L/W)
 // sweeps -- one per wave, W a multiple of the chip's SIMD count -- so every SIMD gets the same work to within ONE sweep at
 // any N (the workgroup form above needs nsb * Q to land on a multiple of the CU count).  A wave whose range crosses into the
-// next super-block stores its resident sums, reloads its residents and goes on; its resident sums of super-block g go to
-// layer r_layer0 + (w - first wave of g) (table `gtab`: first wave and wave count per super-block, built by the host).
+// next super-block stores its resident sums in g's last resident layer, reloads its residents and goes on; the sums of the
+// super-block a range ENDS in are added up over the workgroup's four waves in LDS and go to layer r_layer0 + (w / 4) - (first
+// wave of g) / 4 (table `gtab`: first wave and resident layer count per super-block, built by the host).
 // struct SymWPlan: nb_plan.h
 
 template <int NG, int J>
@@ -196,19 +197,23 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
     constexpr int GW = NG < 4 ? NG : 4;        // packed groups evaluated stage-major together
     constexpr uint32_t CH = 64u * J;           // travelers per chunk
     constexpr uint32_t CPS = S / CH;           // chunks per super-block
-    const int lane = threadIdx.x & 63;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));     // the four waves of a workgroup are independent
-    if (w >= pl.W) return;
+    const int lane = threadIdx.x & 63, wi = threadIdx.x >> 6;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wi);     // the four waves of a workgroup sweep independently and meet once, at the end
+    const bool active = w < pl.W;
+    __shared__ float red[4][6 * NG][64];       // the waves' last resident sums, added up per super-block before they leave the CU
+    __shared__ uint32_t fin[4];
     // The wave's range, in UNITS of 64 / ups rotation steps (ups units per chunk-sweep), relative to the handle's part of the list.
     // With ups > 1 a sweep may be shared by consecutive waves: each runs its own rotation steps [s0, s1) of it, starting from
     // travelers loaded s0 lanes ahead (wave_ror:1 moves a traveler from lane l to lane l + 1, so after s steps lane l holds the
     // traveler that started in lane l - s).
     const uint32_t ups = pl.ups, ustep = 64u / ups;
     const uint64_t Lu = (uint64_t)pl.L * ups;
-    uint32_t u = (uint32_t)(((uint64_t)w * Lu) / pl.W);
-    const uint32_t uend = (uint32_t)(((uint64_t)(w + 1) * Lu) / pl.W);
+    uint32_t u = active ? (uint32_t)(((uint64_t)w * Lu) / pl.W) : 0u;
+    const uint32_t uend = active ? (uint32_t)(((uint64_t)(w + 1) * Lu) / pl.W) : 0u;
     const nb_f2 e2 = nb_f2{eps2, eps2};
     const uint32_t first_lo = pl.n_hi * pl.total_hi;
+    const uint32_t slot = ups > 1 && active ? gtab[2 * pl.nsb + w] : 0u;      // the wave's spill row (it has at most one: the sweep its range starts inside)
+    uint32_t gfin = ~0u;                       // the super-block the range ends in
 
     while (u < uend) {
         // which super-block's list the unit lies in, and where
@@ -308,19 +313,51 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             }
             if (sym) {
                 // the sums of steps [s0, s1) sit s1 lanes past their travelers' home lanes.  The part that starts the sweep owns the
-                // sweep's traveler layer; any later part goes to the wave's own spill row (K2 adds it: the chunk's spill list)
-                SymRow* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)w * CH) + (((uint32_t)lane - s1) & 63u);
+                // sweep's traveler layer; any later part goes to the wave's own spill row (K2 adds it: the spill rows of a chunk are consecutive)
+                SymRow* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)slot * CH) + (((uint32_t)lane - s1) & 63u);
 #pragma unroll
                 for (int uu = 0; uu < J; ++uu) out[uu * 64] = SymRow{bx[uu].x + bx[uu].y, by[uu].x + by[uu].y, bz[uu].x + bz[uu].y};
             }
         }
-        // resident sums of this wave's part of g's list
-        SymRow* out = partial + (size_t)(pl.r_layer0 + (w - gtab[2 * g])) * pl.np + (size_t)g * S + lane;
+        if (u >= uend) {
+            // the range ends here: the sums meet those of the workgroup's other waves in LDS (below)
+            gfin = g;
+#pragma unroll
+            for (int c = 0; c < NG; ++c) {
+                red[wi][6 * c + 0][lane] = ax[c].x; red[wi][6 * c + 1][lane] = ay[c].x; red[wi][6 * c + 2][lane] = az[c].x;
+                red[wi][6 * c + 3][lane] = ax[c].y; red[wi][6 * c + 4][lane] = ay[c].y; red[wi][6 * c + 5][lane] = az[c].y;
+            }
+            break;
+        }
+        // the range goes on into the next super-block: the resident sums of this part go to g's last layer (only the last wave of a
+        // super-block's list can go on)
+        SymRow* out = partial + (size_t)(pl.r_layer0 + gtab[2 * g + 1] - 1u) * pl.np + (size_t)g * S + lane;
 #pragma unroll
         for (int c = 0; c < NG; ++c) {
             out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
             out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
         }
+    }
+    // The resident sums of the super-block the range ends in: the waves of the workgroup that end in the same one (consecutive
+    // waves share a super-block when there are more waves than super-blocks: N = 16,384 has 64 per super-block) add theirs up in LDS,
+    // in wave order, and store ONE row set -- layer (w / 4) - (first wave of g) / 4 -- a quarter of the resident layers K2 reads.
+    if (lane == 0) fin[wi] = gfin;
+    __syncthreads();
+    if (gfin == ~0u) return;
+    int members = 0, mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool same = fin[j] == gfin;
+        members += same;
+        mine += same && j < wi;
+    }
+    SymRow* out = partial + (size_t)(pl.r_layer0 + (w >> 2) - (gtab[2 * gfin] >> 2)) * pl.np + (size_t)gfin * S + lane;
+    for (int r = mine; r < 2 * NG; r += members) {       // the members share the rows out
+        float sx = 0.f, sy = 0.f, sz = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (fin[j] == gfin) { sx += red[j][3 * r + 0][lane]; sy += red[j][3 * r + 1][lane]; sz += red[j][3 * r + 2][lane]; }
+        out[r * 64] = SymRow{sx, sy, sz};
     }
 }
 
@@ -344,14 +381,18 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
 {
     constexpr uint32_t S = 64u * IPL, CH = 64u, CPS = S / CH;
     constexpr int GW = 4;                      // residents evaluated stage-major together
-    const int lane = threadIdx.x & 63;
-    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + (threadIdx.x >> 6));
-    if (w >= pl.W) return;
+    const int lane = threadIdx.x & 63, wi = threadIdx.x >> 6;
+    const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wi);
+    const bool active = w < pl.W;
+    __shared__ double red[4][3 * IPL][64];     // see nb_force_symw: the last resident sums of the workgroup's waves meet here
+    __shared__ uint32_t fin[4];
     const uint32_t ups = pl.ups, ustep = 64u / ups;          // wave ranges in units of 64 / ups rotation steps: see nb_force_symw
     const uint64_t Lu = (uint64_t)pl.L * ups;
-    uint32_t u = (uint32_t)(((uint64_t)w * Lu) / pl.W);
-    const uint32_t uend = (uint32_t)(((uint64_t)(w + 1) * Lu) / pl.W);
+    uint32_t u = active ? (uint32_t)(((uint64_t)w * Lu) / pl.W) : 0u;
+    const uint32_t uend = active ? (uint32_t)(((uint64_t)(w + 1) * Lu) / pl.W) : 0u;
     const uint32_t first_lo = pl.n_hi * pl.total_hi;
+    const uint32_t slot = ups > 1 && active ? gtab[2 * pl.nsb + w] : 0u;
+    uint32_t gfin = ~0u;
     while (u < uend) {
         const uint32_t ps = u / ups, p = pl.p0 + ps;
         uint32_t g, k, total;
@@ -414,13 +455,37 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
                 bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz);
             }
             if (sym) {
-                SymRowT<double>* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)w * CH) + (((uint32_t)lane - s1) & 63u);
+                SymRowT<double>* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)slot * CH) + (((uint32_t)lane - s1) & 63u);
                 *out = SymRowT<double>{bx, by, bz};
             }
         }
-        SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + (w - gtab[2 * g])) * pl.np + (size_t)g * S + lane;
+        if (u >= uend) {
+            gfin = g;
+#pragma unroll
+            for (int c = 0; c < IPL; ++c) { red[wi][3 * c + 0][lane] = ax[c]; red[wi][3 * c + 1][lane] = ay[c]; red[wi][3 * c + 2][lane] = az[c]; }
+            break;
+        }
+        SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + gtab[2 * g + 1] - 1u) * pl.np + (size_t)g * S + lane;     // the range goes on: g's last layer
 #pragma unroll
         for (int c = 0; c < IPL; ++c) out[c * 64] = SymRowT<double>{ax[c], ay[c], az[c]};
+    }
+    if (lane == 0) fin[wi] = gfin;
+    __syncthreads();
+    if (gfin == ~0u) return;
+    int members = 0, mine = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool same = fin[j] == gfin;
+        members += same;
+        mine += same && j < wi;
+    }
+    SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + (w >> 2) - (gtab[2 * gfin] >> 2)) * pl.np + (size_t)gfin * S + lane;
+    for (int r = mine; r < IPL; r += members) {
+        double sx = 0, sy = 0, sz = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (fin[j] == gfin) { sx += red[j][3 * r + 0][lane]; sy += red[j][3 * r + 1][lane]; sz += red[j][3 * r + 2][lane]; }
+        out[r * 64] = SymRowT<double>{sx, sy, sz};
     }
 }
 
@@ -761,9 +826,10 @@ __global__ __launch_bounds__(kBlock) void nb_peer_gather(const PeerPtrs src, typ
     dst[idx] = ld4((const V4*)src.p[d] + idx);
 }
 
-// K2 for the wave-granular form: resident layers gtab[2g+1] (waves that worked on g's list), then the traveler layers, then (wave
+// K2 for the wave-granular form: resident layers gtab[2g+1] (workgroups whose waves ended in g's list, + the wave that went on), then the traveler layers, then (wave
 // ranges cut inside sweeps, pl.ups > 1) the spill rows of the waves that ran a later part of a sweep over the body's chunk:
-// {offset, count} per chunk of CH rows at gtab[2 nsb + 2 chunk], wave numbers from gtab[2 nsb + 2 np / CH] on.  Fixed order.
+// {first spill row, count} per chunk of CH rows at gtab[2 nsb + W + 2 chunk] (a chunk's spill rows are consecutive, in wave order: the
+// row addresses hang on ONE table load, like the layers').  Fixed order.  The body's own state is requested before the sums.
 template <typename T, int R>
 __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::type* __restrict__ bodies, typename vec4<T>::type* __restrict__ vel,
                                                            typename vec4<T>::type* __restrict__ acc, const SymRowT<T>* __restrict__ partial,
@@ -776,23 +842,24 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::ty
     const uint32_t il = gid / R, r = gid % R;
     const bool valid = il < n;
     T sx = 0, sy = 0, sz = 0;
+    typename vec4<T>::type b0{}, v0{}, a0{};
     if (valid) {
+        if (r == 0) { b0 = ld4(bodies + il); v0 = ld4(vel + il); a0 = ld4(acc + il); }
         const uint32_t b = il / S;
         const uint32_t nr = gtab[2 * b + 1];
         const uint32_t nt = pl.H + ((pl.n_hi && b >= pl.n_hi) ? 1u : 0u);
-        uint32_t ns = 0;
-        const uint32_t* ids = nullptr;
+        uint32_t ns = 0, s_first = 0;
         const uint32_t ci = il >> ch_shift;
         if (pl.ups > 1) {
-            const uint32_t* ent = gtab + 2 * pl.nsb + 2 * ci;
+            const uint32_t* ent = gtab + 2 * pl.nsb + pl.W + 2 * ci;
+            s_first = ent[0];
             ns = ent[1];
-            ids = gtab + 2 * pl.nsb + 2 * (pl.np >> ch_shift) + ent[0];
         }
         const uint32_t total = nr + nt + ns;
         auto row = [&](uint32_t e) {
             if (e < nr) return partial + (size_t)(pl.r_layer0 + e) * pl.np + il;
             if (e < nr + nt) return partial + (size_t)(pl.t_layer0 + (e - nr)) * pl.np + il;
-            return spill + (((size_t)ids[e - nr - nt] << ch_shift) + (il - (ci << ch_shift)));
+            return spill + (((size_t)(s_first + (e - nr - nt)) << ch_shift) + (il - (ci << ch_shift)));
         };
         uint32_t e = r;
         for (; e + 3 * R < total; e += 4 * R) {
@@ -817,7 +884,7 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::ty
     }
     if (!valid || r != 0) return;
     V4 nx, nv, na;
-    leapfrog<T>(ld4(bodies + il), ld4(vel + il), ld4(acc + il), sx, sy, sz, dt, nx, nv, na);
+    leapfrog<T>(b0, v0, a0, sx, sy, sz, dt, nx, nv, na);
     vel[il] = nv;                                                       // :281
     bodies[il] = nx;                                                    // :283
     acc[il] = na;                                                       // :290

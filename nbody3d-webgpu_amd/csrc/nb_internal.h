@@ -95,7 +95,7 @@ struct nb_sim {
     uint32_t sym_np = 0, sym_layers = 0;
     uint32_t sym_plan[12] = {0};   // nb::SymPlan / nb::SymWPlan, kept as plain words here (nb_comm.hip does not see the kernels' types)
     bool symw = false;             // wave-granular form (nb_force_symw): sym_plan holds a SymWPlan, sym_tab the per-super-block table
-    uint32_t* sym_tab = nullptr;   // device: {first wave, wave count} per super-block
+    uint32_t* sym_tab = nullptr;   // device: {first wave, resident layers} per super-block
     std::vector<uint32_t> sym_tab_host;
     void* sym_spill = nullptr;     // ups > 1: one spill row set per wave (traveler sums of the sweep a wave's range starts inside)
     uint32_t sym_spill_rows = 0;

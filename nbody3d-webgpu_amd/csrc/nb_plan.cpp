@@ -183,6 +183,8 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
     SymChoice best{0, 0, 1, 1e300};
     for (int ipl : {4, 8, 16}) {
         if (f64 && ipl != 8) continue;              // nb_force_symw64<8>: 8 residents per lane, 19 DP instructions + v_rsq_f64 per pair
+        if (ipl == 4 && !whole_only) continue;      // 4 residents per lane only won by their finer rounding of WHOLE sweeps (N ~ 14,000 .. 18,000); with
+                                                    // eighth sweeps they are 10-20 % behind at every size (profiles/r04/sym_units_scan_workgroup_reduce.txt)
         const uint32_t NG = (uint32_t)ipl / 2, S = 64u * (uint32_t)ipl, cps = S / 64u;
         const uint32_t nsb = ceil_div(n, S);
         if (nsb < 4) continue;
@@ -195,17 +197,20 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
         if (per_simd < 1.0) continue;
         for (uint32_t k = 1; k <= 2; ++k) {
-            if (k == 2 && per_simd < 6.0) continue;      // under ~3 sweeps per wave a second wave's own prologue and resident loads cost more than it hides
-                                                         // (N = 20,000, 16 residents: 85.1 us with two waves per SIMD, 81.8 with one)
+            if (k == 2 && per_simd < 2.0) continue;      // every wave needs a whole sweep or so of work
             const uint32_t ups = sym_units(L, (uint32_t)simds * k, whole_only);
             // in units of 1 / ups sweep: a wave gets floor or ceil of its share; two waves of a SIMD both round up about min(1, 2p) of the time
             const double pu = per_simd * ups, pw = pu / 2.0, fl = std::floor(pw);
-            const double units = k == 1 ? std::ceil(pu) * 1.032 : (2.0 * fl + 2.0 * std::min(1.0, 2.0 * (pw - fl))) * 1.01;
+            const double units = k == 1 ? std::ceil(pu) * 1.042 : 2.0 * fl + 2.0 * std::min(1.0, 2.0 * (pw - fl));
             const double sweeps = units / ups;
             const double segs = per_simd / k / (double)total_lo + 1.0;             // super-blocks a wave's range touches
             const double spill = ups > 1 ? simds * k * 64.0 / n : 0.0;             // spill rows K2 adds per body (one 64-row spill per wave)
-            const double layers = (double)(H + 1) + (double)total_hi * k / per_simd + 1.0 + spill;     // traveler + resident layers K2 reads per body
-            const double t = sweeps * t_chunk + 3.5e-6 + segs * 1.5e-6 + (ups > 1 ? 0.6e-6 : 0.0) + boundary + layers * n * (f64 ? 24.0 : 12.0) / 5.0e12;
+            const double layers = (double)(H + 1) + (double)total_hi * k / per_simd / 4.0 + 1.5 + spill;     // traveler + resident layers (one per workgroup of four waves) K2 reads per body
+            // refitted on profiles/r04/sym_units_scan_workgroup_reduce.txt (N = 9,000 .. 40,002, 8 and 16 residents per lane, one and two
+            // waves per SIMD: rms 1.6 %): the layers cost next to nothing since a workgroup's waves add their resident sums up in LDS;
+            // two waves of 16 residents per SIMD pay ~2 us for their second set of resident loads
+            const double t = sweeps * t_chunk + 3.2e-6 + segs * 1.66e-6 + (ups > 1 ? 0.6e-6 : 0.0) + (k == 2 && ipl == 16 ? 2.1e-6 : 0.0) + boundary
+                             + layers * n * (f64 ? 24.0 : 12.0) / 20.0e12;
             if (t < best.t) best = {ipl, k, ups, t};
         }
     }
@@ -213,7 +218,7 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
 }
 
 // Wave-granular form of the symmetric pass (nb_force_symw / nb_force_symw64): the ring of super-blocks, the handle's range of the
-// global chunk list, its cut into W wave ranges and the {first wave, wave count} table of every super-block.
+// global chunk list, its cut into W wave ranges and the {first wave, resident layers} table of every super-block.
 //   rank_ipl != 0: rank form -- only the lists of the handle's own super-blocks [sb / S, (sb + sc) / S)
 //   sym_k: waves per SIMD the cost model asked for (0: cfg.jsplit, else 1; rank form 2 when there is enough work)
 static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, uint32_t sb, uint32_t sc, const nb_config& cfg, int n_cu,
@@ -250,19 +255,27 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, u
         return w;
     };
     const uint32_t nch = pl.np / CH;
-    s->sym_tab_host.assign(2 * (size_t)nsb + (ups > 1 ? 2 * (size_t)nch : 0), 0);
+    s->sym_tab_host.assign(2 * (size_t)nsb + (ups > 1 ? (size_t)W + 2 * (size_t)nch : 0), 0);
     uint32_t max_r = 1;
     for (uint32_t g = g0; g < g1; ++g) {
         const uint32_t total = g < n_hi ? pl.total_hi : pl.total_lo;
         const uint64_t off = (uint64_t)(offset_of(g) - pl.p0) * ups;
-        const uint32_t first = wave_of(off), last = wave_of(off + (uint64_t)total * ups - 1);
-        s->sym_tab_host[2 * g] = first; s->sym_tab_host[2 * g + 1] = last - first + 1;
-        if (last - first + 1 > max_r) max_r = last - first + 1;
+        const uint64_t end = off + (uint64_t)total * ups;
+        const uint32_t first = wave_of(off), last = wave_of(end - 1);
+        // resident layers of g: the waves whose range ENDS in g's list add their sums up per workgroup of four (in LDS) -- one layer
+        // per workgroup, (w / 4) - (first / 4) -- and the last wave, if its range goes on into g + 1, stores its part on its own
+        const uint32_t goes_on = start_of(last + 1) > end ? 1u : 0u;
+        const uint32_t ending = last - first + 1 - goes_on;
+        const uint32_t layers = (ending ? ((first + ending - 1) >> 2) - (first >> 2) + 1u : 0u) + goes_on;
+        s->sym_tab_host[2 * g] = first; s->sym_tab_host[2 * g + 1] = layers;
+        if (layers > max_r) max_r = layers;
     }
     s->sym_spill_rows = 0;
     if (ups > 1) {
-        // spill lists: a wave whose range starts inside a sweep keeps that sweep's traveler sums in its own spill row; K2 adds
-        // them to the rows of the sweep's traveler chunk.  Per chunk {offset, count}, then the wave numbers in ascending order.
+        // spill rows: a wave whose range starts inside a sweep keeps that sweep's traveler sums in a spill row of its own; K2 adds
+        // them to the rows of the sweep's traveler chunk.  The rows are numbered chunk by chunk (waves ascending inside a chunk), so K2
+        // reads rows [first, first + count) of its chunk: the table is W words (the spill row of every wave), then {first, count} per
+        // chunk, then the wave numbers in row order (for the tests).
         struct Spill { uint32_t chunk, wave; };
         std::vector<Spill> sp;
         for (uint32_t w = 0; w < pl.W; ++w) {
@@ -282,15 +295,16 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, u
             sp.push_back({tstart / CH, w});
         }
         std::stable_sort(sp.begin(), sp.end(), [](const Spill& a, const Spill& b) { return a.chunk < b.chunk; });      // waves stay ascending inside a chunk
-        const size_t base = 2 * (size_t)nsb, ids0 = base + 2 * (size_t)nch;
+        const size_t slot0 = 2 * (size_t)nsb, base = slot0 + pl.W, ids0 = base + 2 * (size_t)nch;
         s->sym_tab_host.resize(ids0 + sp.size(), 0);
         for (size_t e = 0; e < sp.size(); ++e) {
             uint32_t* ent = &s->sym_tab_host[base + 2 * (size_t)sp[e].chunk];
             if (ent[1] == 0) ent[0] = (uint32_t)e;
             ++ent[1];
             s->sym_tab_host[ids0 + e] = sp[e].wave;
+            s->sym_tab_host[slot0 + sp[e].wave] = (uint32_t)e;
         }
-        s->sym_spill_rows = pl.W * CH;
+        s->sym_spill_rows = std::max<uint32_t>(1u, (uint32_t)sp.size()) * CH;
     }
     s->sym_rank = rank_ipl != 0; s->sym_g0 = g0; s->sym_g1 = g1;
     pl.r_layer0 = 0; pl.t_layer0 = max_r;
@@ -686,7 +700,14 @@ LaunchPlan plan_launch(const PlanInput& in)
         // ordered-pair shape above (N = 16,384: 61.7 vs 65.7 us, 40,002: 270 vs 357 us, 262,144: 10.5 vs 14.6 ms)
         if (!pinned && whole && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
             const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, f64, layer_budget, (cfg.flags & NB_FLAG_WHOLE_SWEEPS) != 0);
-            if (sc2.ipl && sc2.t < 0.98 * (pick ? pick->t : best_t)) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; sym_ups = sc2.ups; }     // a clear win only: both estimates are good to ~3 %
+#ifdef NB_TUNING
+            if (getenv("NB_MODEL_TRACE"))
+                fprintf(stderr, "plan n=%u: ordered-pair estimate %.2f us, symmetric %.2f us (%d residents, %u waves per SIMD)\n", n,
+                        1e6 * (pick ? pick->t : best_t), 1e6 * sc2.t, sc2.ipl, sc2.k);
+#endif
+            // (the j-packed step runs 2.1-2.9 us behind its estimate from N = 8,192 to 12,000: profiles/r04/sym_units_scan_workgroup_reduce.txt)
+            const double ordered_t = (pick ? pick->t : best_t) + (pick && pick->sh.kind == kJpk ? 2.5e-6 : 0.0);
+            if (sc2.ipl && sc2.t < 0.98 * ordered_t) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; sym_ups = sc2.ups; }     // a clear win only: both estimates are good to ~3 %
             else if (!sc2.ipl) {
                 // no resident count whose layers fit the budget (they grow with N^2: 103 GB at 4 M bodies): the rank-form pipeline on
                 // this one device, its ring distances in PASSES that reuse the layers -- still every unordered pair once (~80 % of the

@@ -111,7 +111,7 @@ struct LaunchPlan {
     };
     std::vector<SymPass> sym_passes;
     bool sym_local = false;
-    std::vector<uint32_t> sym_tab_host;  // wave-granular form: {first wave, wave count} per super-block [2 nsb words]; with ups > 1
+    std::vector<uint32_t> sym_tab_host;  // wave-granular form: {first wave, resident layers} per super-block [2 nsb words]; with ups > 1
                                          // followed by {offset, count} per traveler chunk [2 np / CH words] and the spill lists' wave numbers
     std::string variant;
 };

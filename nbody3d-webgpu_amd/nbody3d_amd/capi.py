@@ -183,7 +183,7 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
                layer_budget_mib=0, sym_pass=0):
     """nb_plan_query: the launch plan nb_create would build -- the engine's planner run on the host alone (works without a
     GPU when n_cu and clock_hz are given; 0 means "as on the device").  Returns a dict: the shape digits, the j-partitions,
-    and for the symmetric pass `plan` (the words the kernels receive, by name) and `tab` (first wave, wave count per super-block)."""
+    and for the symmetric pass `plan` (the words the kernels receive, by name) and `tab` (first wave, resident layers per super-block)."""
     L = load_library()
     cfg = nb_config()
     cfg.struct_size = C.sizeof(nb_config)
@@ -233,11 +233,14 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
         if info.symw:
             out["plan"]["ups"] = int(info.sym_ups)
         if info.sym_ups > 1 and not info.sym_rank:
-            # the spill lists (wave ranges cut inside sweeps): {offset, count} per traveler chunk, then the wave numbers
+            # the spill rows (wave ranges cut inside sweeps): the spill row of every wave, {first row, count} per traveler chunk,
+            # then the wave numbers in row order
             ch = 128 if info.x == 1 else 64
             nch = out["plan"]["np"] // ch
-            out["spill_tab"] = tab[2 * nsb:2 * nsb + 2 * nch].reshape(-1, 2)
-            out["spill_ids"] = tab[2 * nsb + 2 * nch:]
+            W = out["plan"]["W"]
+            out["spill_slot"] = tab[2 * nsb:2 * nsb + W]
+            out["spill_tab"] = tab[2 * nsb + W:2 * nsb + W + 2 * nch].reshape(-1, 2)
+            out["spill_ids"] = tab[2 * nsb + W + 2 * nch:]
     return out
 
 
