@@ -845,11 +845,15 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::ty
     typename vec4<T>::type b0{}, v0{}, a0{};
     if (valid) {
         if (r == 0) { b0 = ld4(bodies + il); v0 = ld4(vel + il); a0 = ld4(acc + il); }
-        const uint32_t b = il / S;
+        // a workgroup's kBlock / R bodies lie in ONE super-block and ONE traveler chunk (both are multiples of 64 rows): the table
+        // entries are the same for the whole workgroup -- scalar loads
+        static_assert((kBlock / R) <= 64 && 64 % (kBlock / R) == 0, "a workgroup's bodies stay inside one 64-row chunk");
+        const uint32_t il0 = blockIdx.x * (kBlock / R);
+        const uint32_t b = il0 / S;
         const uint32_t nr = gtab[2 * b + 1];
         const uint32_t nt = pl.H + ((pl.n_hi && b >= pl.n_hi) ? 1u : 0u);
         uint32_t ns = 0, s_first = 0;
-        const uint32_t ci = il >> ch_shift;
+        const uint32_t ci = il0 >> ch_shift;
         if (pl.ups > 1) {
             const uint32_t* ent = gtab + 2 * pl.nsb + pl.W + 2 * ci;
             s_first = ent[0];
