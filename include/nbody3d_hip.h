@@ -347,7 +347,8 @@ int nb_shape_info(nb_sim *s, uint32_t *jsplit, uint32_t *j_per_split, uint32_t *
  *                      t_layer0, L, p0; workgroup form nb::SymPlan: np, nsb, q, total_hi, total_lo, n_hi, H, r_layer0, t_layer0)
  *   tab                (caller's array of tab_cap words, may be NULL) first wave and resident layer count of every super-block's
  *                      list (a layer per workgroup of four waves ending there, one more if the last wave goes on), 2 * nsb
- *                      words; with sym_ups > 1 followed by the spill tables -- the spill row of every wave (W words), {first
+ *                      words; the W + 1 wave starts (first unit of every wave's range: equal in work, a sweep over a chunk of
+ *                      padding rows counts nothing); with sym_ups > 1 followed by the spill tables -- the spill row of every wave (W words), {first
  *                      spill row, count} per traveler chunk (2 * sym_np / 64 words), then the wave numbers in spill-row order;
  *                      tab_len reports how many words there are
  *   sym_ups            work units per chunk-sweep: the wave ranges are floor/ceil-equal in units of 64 / sym_ups rotation steps */

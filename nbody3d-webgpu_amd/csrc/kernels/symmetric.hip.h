@@ -206,13 +206,13 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
     // With ups > 1 a sweep may be shared by consecutive waves: each runs its own rotation steps [s0, s1) of it, starting from
     // travelers loaded s0 lanes ahead (wave_ror:1 moves a traveler from lane l to lane l + 1, so after s steps lane l holds the
     // traveler that started in lane l - s).
+    // The ranges are equal in WORK (a sweep over a chunk of padding rows costs nothing): the planner's table of wave starts.
     const uint32_t ups = pl.ups, ustep = 64u / ups;
-    const uint64_t Lu = (uint64_t)pl.L * ups;
-    uint32_t u = active ? (uint32_t)(((uint64_t)w * Lu) / pl.W) : 0u;
-    const uint32_t uend = active ? (uint32_t)(((uint64_t)(w + 1) * Lu) / pl.W) : 0u;
+    uint32_t u = active ? gtab[2 * pl.nsb + w] : 0u;
+    const uint32_t uend = active ? gtab[2 * pl.nsb + w + 1] : 0u;
     const nb_f2 e2 = nb_f2{eps2, eps2};
     const uint32_t first_lo = pl.n_hi * pl.total_hi;
-    const uint32_t slot = ups > 1 && active ? gtab[2 * pl.nsb + w] : 0u;      // the wave's spill row (it has at most one: the sweep its range starts inside)
+    const uint32_t slot = ups > 1 && active ? gtab[2 * pl.nsb + pl.W + 1 + w] : 0u;      // the wave's spill row (it has at most one: the sweep its range starts inside)
     uint32_t gfin = ~0u;                       // the super-block the range ends in
 
     while (u < uend) {
@@ -386,12 +386,11 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
     const bool active = w < pl.W;
     __shared__ double red[4][3 * IPL][64];     // see nb_force_symw: the last resident sums of the workgroup's waves meet here
     __shared__ uint32_t fin[4];
-    const uint32_t ups = pl.ups, ustep = 64u / ups;          // wave ranges in units of 64 / ups rotation steps: see nb_force_symw
-    const uint64_t Lu = (uint64_t)pl.L * ups;
-    uint32_t u = active ? (uint32_t)(((uint64_t)w * Lu) / pl.W) : 0u;
-    const uint32_t uend = active ? (uint32_t)(((uint64_t)(w + 1) * Lu) / pl.W) : 0u;
+    const uint32_t ups = pl.ups, ustep = 64u / ups;          // wave ranges in units of 64 / ups rotation steps, starts from the table: see nb_force_symw
+    uint32_t u = active ? gtab[2 * pl.nsb + w] : 0u;
+    const uint32_t uend = active ? gtab[2 * pl.nsb + w + 1] : 0u;
     const uint32_t first_lo = pl.n_hi * pl.total_hi;
-    const uint32_t slot = ups > 1 && active ? gtab[2 * pl.nsb + w] : 0u;
+    const uint32_t slot = ups > 1 && active ? gtab[2 * pl.nsb + pl.W + 1 + w] : 0u;
     uint32_t gfin = ~0u;
     while (u < uend) {
         const uint32_t ps = u / ups, p = pl.p0 + ps;
@@ -828,7 +827,7 @@ __global__ __launch_bounds__(kBlock) void nb_peer_gather(const PeerPtrs src, typ
 
 // K2 for the wave-granular form: resident layers gtab[2g+1] (workgroups whose waves ended in g's list, + the wave that went on), then the traveler layers, then (wave
 // ranges cut inside sweeps, pl.ups > 1) the spill rows of the waves that ran a later part of a sweep over the body's chunk:
-// {first spill row, count} per chunk of CH rows at gtab[2 nsb + W + 2 chunk] (a chunk's spill rows are consecutive, in wave order: the
+// {first spill row, count} per chunk of CH rows at gtab[2 nsb + 2 W + 1 + 2 chunk] (a chunk's spill rows are consecutive, in wave order: the
 // row addresses hang on ONE table load, like the layers').  Fixed order.  The body's own state is requested before the sums.
 template <typename T, int R>
 __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::type* __restrict__ bodies, typename vec4<T>::type* __restrict__ vel,
@@ -855,7 +854,7 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::ty
         uint32_t ns = 0, s_first = 0;
         const uint32_t ci = il0 >> ch_shift;
         if (pl.ups > 1) {
-            const uint32_t* ent = gtab + 2 * pl.nsb + pl.W + 2 * ci;
+            const uint32_t* ent = gtab + 2 * pl.nsb + 2 * pl.W + 1 + 2 * ci;
             s_first = ent[0];
             ns = ent[1];
         }

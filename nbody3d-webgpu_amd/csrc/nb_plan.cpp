@@ -191,27 +191,38 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         if (sym_layer_bytes(n, S, f64 ? 8 : 4) > layer_budget) continue;
         const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
         const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (uint64_t)(H + 1) * cps;
-        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo;
+        // sweeps over chunks of padding rows only cost nothing (the wave ranges are cut by work): (np - n) / 64 chunks of the last
+        // super-block, each on the list of the H (+1) super-blocks that sweep it and on its own
+        const uint64_t pad_sweeps = (uint64_t)((nsb * S - n) / 64u) * (H + (n_hi ? 1u : 0u) + 1u);
+        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo - pad_sweeps;
         // f64: 92 issue cycles per resident and step + 14 DPP; the loop runs at 96 % of that (N = 262,144: 23.7 ms, profiles/r03/sym_f64_first.txt)
         const double t_chunk = f64 ? 64.0 * (92.0 * ipl + 56.0) / 0.96 / clock : 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.95 : 0.935) / clock;
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
         if (per_simd < 1.0) continue;
         for (uint32_t k = 1; k <= 2; ++k) {
             if (k == 2 && per_simd < 2.0) continue;      // every wave needs a whole sweep or so of work
-            const uint32_t ups = sym_units(L, (uint32_t)simds * k, whole_only);
-            // in units of 1 / ups sweep: a wave gets floor or ceil of its share; two waves of a SIMD both round up about min(1, 2p) of the time
-            const double pu = per_simd * ups, pw = pu / 2.0, fl = std::floor(pw);
-            const double units = k == 1 ? std::ceil(pu) * 1.042 : 2.0 * fl + 2.0 * std::min(1.0, 2.0 * (pw - fl));
-            const double sweeps = units / ups;
-            const double segs = per_simd / k / (double)total_lo + 1.0;             // super-blocks a wave's range touches
-            const double spill = ups > 1 ? simds * k * 64.0 / n : 0.0;             // spill rows K2 adds per body (one 64-row spill per wave)
-            const double layers = (double)(H + 1) + (double)total_hi * k / per_simd / 4.0 + 1.5 + spill;     // traveler + resident layers (one per workgroup of four waves) K2 reads per body
-            // refitted on profiles/r04/sym_units_scan_workgroup_reduce.txt (N = 9,000 .. 40,002, 8 and 16 residents per lane, one and two
-            // waves per SIMD: rms 1.6 %): the layers cost next to nothing since a workgroup's waves add their resident sums up in LDS;
-            // two waves of 16 residents per SIMD pay ~2 us for their second set of resident loads
-            const double t = sweeps * t_chunk + 3.2e-6 + segs * 1.66e-6 + (ups > 1 ? 0.6e-6 : 0.0) + (k == 2 && ipl == 16 ? 2.1e-6 : 0.0) + boundary
-                             + layers * n * (f64 ? 24.0 : 12.0) / 20.0e12;
-            if (t < best.t) best = {ipl, k, ups, t};
+            // units per sweep: whole sweeps when a wave's share happens to round well (N = 11,000: 1.93 sweeps per wave, 31.3 us against
+            // 32.7 with eighths), else eighths below a dozen sweeps per wave, quarters below 48 (sym_units)
+            const uint32_t ups_fine = sym_units(L, (uint32_t)simds * k, whole_only);
+            for (uint32_t ups : {1u, ups_fine}) {
+                if (ups == 1 && ups_fine > 1 && (k == 2 || per_simd >= 4.0)) continue;       // one wave per SIMD and a few sweeps only: with two waves the
+                                                                                             // rounding below is an average, good for fine units only
+                // in units of 1 / ups sweep: a wave gets floor or ceil of its share; two waves of a SIMD both round up about min(1, 2p) of the time
+                const double pu = per_simd * ups, pw = pu / 2.0, fl = std::floor(pw);
+                const double units = k == 1 ? std::ceil(pu) * 1.042 : 2.0 * fl + 2.0 * std::min(1.0, 2.0 * (pw - fl));
+                const double sweeps = units / ups;
+                const double segs = per_simd / k / (double)total_lo + 1.0;             // super-blocks a wave's range touches
+                const double spill = ups > 1 ? simds * k * 64.0 / n : 0.0;             // spill rows K2 adds per body (one 64-row spill per wave)
+                const double layers = (double)(H + 1) + (double)total_hi * k / per_simd / 4.0 + 1.5 + spill;     // traveler + resident layers (one per workgroup of four waves) K2 reads per body
+                // refitted on profiles/r04/sym_units_scan_workgroup_reduce.txt (N = 9,000 .. 40,002, 8 and 16 residents per lane, one and two
+                // waves per SIMD: rms 1.6 %): the layers cost next to nothing since a workgroup's waves add their resident sums up in LDS;
+                // two waves of 16 residents per SIMD pay ~2 us for their second set of resident loads; a range cut inside sweeps costs
+                // ~1.5 us (the travelers of the shared sweeps are loaded twice, their sums stored twice)
+                const double t = sweeps * t_chunk + 2.3e-6 + segs * 1.66e-6 + (ups > 1 ? 1.5e-6 : 0.0) + (k == 2 && ipl == 16 ? 2.1e-6 : 0.0) + boundary
+                                 + layers * n * (f64 ? 24.0 : 12.0) / 20.0e12;
+                if (t < best.t) best = {ipl, k, ups, t};
+                if (ups_fine == 1) break;
+            }
         }
     }
     return best;
@@ -243,19 +254,56 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, u
     const bool whole_only = rank_ipl != 0 || (cfg.flags & NB_FLAG_WHOLE_SWEEPS);
     const uint32_t ups = whole_only ? 1u : (sym_ups ? sym_ups : sym_units(pl.L, W, false));
     pl.ups = ups;
-    const uint64_t Lu = (uint64_t)pl.L * ups;                  // the handle's work in units
-    if (W > Lu) W = (uint32_t)Lu;                               // never more waves than units: every wave has work, so every resident layer the table
-                                                               // counts is written (the kernel's `w >= W` guard idles the rest of the last workgroup)
-    pl.W = W;
-    auto start_of = [&](uint32_t w) { return (uint64_t)w * Lu / pl.W; };          // first unit of wave w (relative to the handle's range)
-    auto wave_of = [&](uint64_t u) {              // u: unit inside this handle's range
-        uint32_t w = (uint32_t)(u * pl.W / Lu);
-        while (w + 1 < pl.W && start_of(w + 1) <= u) ++w;
-        while (w > 0 && start_of(w) > u) --w;
-        return w;
+    const uint64_t Lu = (uint64_t)pl.L * ups;                  // the handle's list in units
+    // What a sweep costs: nothing when its traveler chunk is padding only (rows >= n: the kernel skips it) -- a ragged N has (np - n) / CH
+    // such chunks in the last super-block, each on the list of every super-block that sweeps it: 2 % of all sweeps at N = 40,002 --
+    // else one sweep.  The wave ranges are equal in COST, not in list length: their starts come from a table.
+    const uint32_t first_lo = n_hi * pl.total_hi;
+    auto sweep_at = [&](uint32_t p, uint32_t& g, uint32_t& k, uint32_t& total) {          // p: position in the global list
+        if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
+        else { const uint32_t r = p - first_lo; g = n_hi + r / pl.total_lo; k = r - (g - n_hi) * pl.total_lo; total = pl.total_lo; }
     };
+    auto tstart_at = [&](uint32_t g, uint32_t k, uint32_t total) {
+        const uint32_t ring = total - cps;
+        if (k >= ring) return g * S + (k - ring) * CH;                                      // resident-only sweep of an own chunk
+        uint32_t tb = g + 1 + k / cps;
+        if (tb >= nsb) tb -= nsb;
+        return tb * S + (k % cps) * CH;
+    };
+    // The sweeps that cost nothing sit in at most H + 2 runs of `m` list positions: the padded chunks [cz, cps) of the last super-block Z
+    // on the list of every super-block that sweeps Z, and on Z's own (resident-only) part.  runs[j] = first position of run j, ascending.
+    const uint32_t Z = nsb - 1, cz = ceil_div(n - Z * S, CH), m = cps - cz;
+    std::vector<uint64_t> runs;
+    if (m && !rank_ipl) {
+        for (uint32_t g = 0; g < Z; ++g) {
+            const uint32_t d = Z - 1 - g;                                                   // Z = g + 1 + d
+            if (d < H + (g < n_hi ? 1u : 0u)) runs.push_back((uint64_t)offset_of(g) + (uint64_t)d * cps + cz);
+        }
+        runs.push_back((uint64_t)offset_of(Z) + ((Z < n_hi ? pl.total_hi : pl.total_lo) - cps) + cz);
+    }
+    const uint64_t Cu = ((uint64_t)pl.L - (uint64_t)runs.size() * m) * ups;                 // the handle's work in units
+    if (W > Cu) W = (uint32_t)Cu;                               // never more waves than units of work: every wave has work, so every resident layer the
+                                                               // table counts is written (the kernel's `w >= W` guard idles the rest of the last workgroup)
+    pl.W = W;
+    std::vector<uint32_t> starts((size_t)W + 1);               // first unit of wave w (relative to the handle's range)
+    {
+        size_t q = 0;                                          // runs wholly before the wave's first sweep
+        for (uint32_t w = 0; w < W; ++w) {
+            const uint64_t target = (uint64_t)w * Cu / W;      // units of work before the wave
+            const uint64_t t = target / ups;                   // ... = real sweeps before its first one
+            while (q < runs.size() && runs[q] - q * m <= t) ++q;      // run q starts after (runs[q] - q m) real sweeps
+            starts[w] = (uint32_t)((t + q * m) * ups + target % ups);
+        }
+    }
+    starts[0] = 0;
+    starts[W] = (uint32_t)Lu;
+    auto start_of = [&](uint32_t w) { return (uint64_t)starts[w]; };
+    auto wave_of = [&](uint64_t u) { return (uint32_t)(std::upper_bound(starts.begin(), starts.begin() + W, (uint32_t)u) - starts.begin()) - 1u; };      // u: unit inside this handle's range
     const uint32_t nch = pl.np / CH;
-    s->sym_tab_host.assign(2 * (size_t)nsb + (ups > 1 ? (size_t)W + 2 * (size_t)nch : 0), 0);
+    // the table: {first wave, resident layers} per super-block, the W + 1 wave starts, then (ups > 1) the spill tables
+    const size_t starts0 = 2 * (size_t)nsb;
+    s->sym_tab_host.assign(starts0 + W + 1 + (ups > 1 ? (size_t)W + 2 * (size_t)nch : 0), 0);
+    std::copy(starts.begin(), starts.end(), s->sym_tab_host.begin() + starts0);
     uint32_t max_r = 1;
     for (uint32_t g = g0; g < g1; ++g) {
         const uint32_t total = g < n_hi ? pl.total_hi : pl.total_lo;
@@ -274,28 +322,22 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, u
     if (ups > 1) {
         // spill rows: a wave whose range starts inside a sweep keeps that sweep's traveler sums in a spill row of its own; K2 adds
         // them to the rows of the sweep's traveler chunk.  The rows are numbered chunk by chunk (waves ascending inside a chunk), so K2
-        // reads rows [first, first + count) of its chunk: the table is W words (the spill row of every wave), then {first, count} per
-        // chunk, then the wave numbers in row order (for the tests).
+        // reads rows [first, first + count) of its chunk: W words (the spill row of every wave), then {first, count} per chunk, then the
+        // wave numbers in row order (for the tests).
         struct Spill { uint32_t chunk, wave; };
         std::vector<Spill> sp;
         for (uint32_t w = 0; w < pl.W; ++w) {
             const uint64_t u = start_of(w);
             if (u % ups == 0 || start_of(w + 1) == u) continue;               // starts a sweep, or has no work
-            const uint32_t p = pl.p0 + (uint32_t)(u / ups);
-            const uint32_t first_lo = n_hi * pl.total_hi;
             uint32_t g, k, total;
-            if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
-            else { const uint32_t r = p - first_lo; g = n_hi + r / pl.total_lo; k = r - (g - n_hi) * pl.total_lo; total = pl.total_lo; }
-            const uint32_t ring = total - cps;
-            if (k >= ring) continue;                                            // resident-only sweep: no traveler sums
-            uint32_t tb = g + 1 + k / cps;
-            if (tb >= nsb) tb -= nsb;
-            const uint32_t tstart = tb * S + (k % cps) * CH;
+            sweep_at(pl.p0 + (uint32_t)(u / ups), g, k, total);
+            if (k >= total - cps) continue;                                     // resident-only sweep: no traveler sums
+            const uint32_t tstart = tstart_at(g, k, total);
             if (tstart >= n) continue;                                          // a chunk of padding rows: skipped by the kernel
             sp.push_back({tstart / CH, w});
         }
         std::stable_sort(sp.begin(), sp.end(), [](const Spill& a, const Spill& b) { return a.chunk < b.chunk; });      // waves stay ascending inside a chunk
-        const size_t slot0 = 2 * (size_t)nsb, base = slot0 + pl.W, ids0 = base + 2 * (size_t)nch;
+        const size_t slot0 = starts0 + W + 1, base = slot0 + pl.W, ids0 = base + 2 * (size_t)nch;
         s->sym_tab_host.resize(ids0 + sp.size(), 0);
         for (size_t e = 0; e < sp.size(); ++e) {
             uint32_t* ent = &s->sym_tab_host[base + 2 * (size_t)sp[e].chunk];

@@ -229,6 +229,9 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
             out["tab"] = out["rank_tab"][:, :2]
         else:
             out["tab"] = tab[:2 * nsb].reshape(-1, 2)
+            if info.symw:
+                W = out["plan"]["W"]
+                out["starts"] = tab[2 * nsb:2 * nsb + W + 1]              # first unit of every wave's range (equal in work), then the list's end
         out["ups"], out["spill_rows"] = int(info.sym_ups), int(info.sym_spill_rows)
         if info.symw:
             out["plan"]["ups"] = int(info.sym_ups)
@@ -238,9 +241,10 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
             ch = 128 if info.x == 1 else 64
             nch = out["plan"]["np"] // ch
             W = out["plan"]["W"]
-            out["spill_slot"] = tab[2 * nsb:2 * nsb + W]
-            out["spill_tab"] = tab[2 * nsb + W:2 * nsb + W + 2 * nch].reshape(-1, 2)
-            out["spill_ids"] = tab[2 * nsb + W + 2 * nch:]
+            base = 2 * nsb + W + 1
+            out["spill_slot"] = tab[base:base + W]
+            out["spill_tab"] = tab[base + W:base + W + 2 * nch].reshape(-1, 2)
+            out["spill_ids"] = tab[base + W + 2 * nch:]
     return out
 
 

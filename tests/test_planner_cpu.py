@@ -40,11 +40,17 @@ def walk_symw(q, n, rank=False):
     tb = np.where(sym, (g + 1 + d) % nsb, g)
     c = np.where(sym, k % cps, k - ring)
     tstart = tb * S + c * CH
-    # the waves: W floor/ceil-equal ranges of the handle's L * ups units, none of them empty
+    # the waves: W ranges of the handle's L * ups units, equal in WORK to one unit -- a sweep over a chunk of padding rows only
+    # (tstart >= n: the kernel skips it) costs nothing -- none of them without work; their starts are a table of the plan
     Lu = L * ups
-    starts = (np.arange(W + 1, dtype=np.int64) * Lu) // W
-    assert starts[0] == 0 and starts[-1] == Lu and W <= Lu
-    assert np.diff(starts).min() >= 1 and np.diff(starts).max() - np.diff(starts).min() <= 1      # balanced to one unit, every wave has work
+    if rank:
+        starts = (np.arange(W + 1, dtype=np.int64) * Lu) // W
+    else:
+        starts = q["starts"].astype(np.int64)
+    assert len(starts) == W + 1 and starts[0] == 0 and starts[-1] == Lu and W <= Lu and np.diff(starts).min() >= 1
+    work = np.repeat((tstart < n).astype(np.int64), ups)                                        # per unit
+    per_wave = np.add.reduceat(work, starts[:-1])
+    assert per_wave.sum() == work.sum() and per_wave.min() >= 1 and per_wave.max() - per_wave.min() <= 1, (per_wave.min(), per_wave.max())
     wu = np.searchsorted(starts, np.arange(Lu, dtype=np.int64), side="right") - 1               # the wave of every unit
     assert np.all((wu >= 0) & (wu < W))
     w = wu[::ups]                                # the wave that starts each sweep (steps from 0): it owns the sweep's traveler layer
@@ -382,7 +388,7 @@ def test_shard_own_splits_lie_inside_the_shard(n, g):
 
 def test_model_choice_table():
     """The automatic choice at the sizes DESIGN.md quotes (256 CUs, 2.4 GHz): a change of the cost model shows up here."""
-    want = {1024: "f32pk_fused_regs1024", 10000: "f32pk_fused_jpairs", 16384: "f32pk_symw_ipl16_j1_w1024_r19t8_u8", 12000: "f32pk_symw_ipl16_j1_w1024_r25t6_u8", 20000: "f32pk_symw_ipl16_j1_w2048_r29t10_u8", 40002: "f32pk_symw_ipl16_j1_w2048_r15t20_u8",
+    want = {1024: "f32pk_fused_regs1024", 9000: "f32pk_fused_jpairs", 11000: "f32pk_symw_ipl8_j1_w1024_r14t11", 13000: "f32pk_symw_ipl8_j1_w2048_r23t13_u8", 16384: "f32pk_symw_ipl16_j1_w1024_r19t8_u8", 20000: "f32pk_symw_ipl16_j1_w2048_r30t10_u8", 40002: "f32pk_symw_ipl16_j1_w2048_r16t20_u8",
             65536: "f32pk_symw_ipl16_j1_w2048", 262144: "f32pk_symw_ipl16_j1_w2048_r4t128", 1048576: "f32pk_symw_ipl16_j1_w2048"}
     for n, prefix in want.items():
         assert capi.plan_query(n)["variant"].startswith(prefix), (n, capi.plan_query(n)["variant"])

@@ -347,13 +347,13 @@ def test_integrate_pass_measures_the_integrator_alone():
 # ---- the automatic launch shape ----------------------------------------------------------------
 
 @pytest.mark.parametrize("n,family,classic", [(512, "fused_regs", None), (1024, "fused_regs", None), (2002, "fused_lds", None), (4096, "fused_lds", None),
-                                              (6000, "fused_lds", None), (8192, "fused", None), (10000, "fused_jpairs", None), (12000, "symw", "fused_jpairs"), (14000, "symw_ipl8_j1_w2048", None),
+                                              (6000, "fused_lds", None), (8192, "fused", None), (9000, "fused_jpairs", None), (12000, "symw", "fused_jpairs"), (14000, "symw_ipl16_j1_w1024", None),
                                               (20000, "symw", "sgpr"), (32768, "symw", "sgpr"),
                                               (40002, "symw_ipl16_j1_w2048", "sgpr"), (65536, "symw_ipl16", "sgpr"), (131072, "symw_ipl16_j1_w2048", "sgpr"),
                                               (262144, "symw_ipl16_j1_w2048", "sgpr_ipl8_ws4"), (500010, "symw_ipl16", "sgpr"), (1048576, "symw_ipl16", "sgpr")])
 def test_default_launch_shape_family_by_size(n, family, classic):
     """the planner's (csrc/nb_plan.cpp) pick per system size, as measured best (profiles/r02/size_scan_final_4k_65k.txt below N ~ 14,000,
-    profiles/r04/sym_units_scan_workgroup_reduce.txt above): from N ~ 10,500 the symmetric pass; with NB_FLAG_NO_SYM the
+    profiles/r04/sym_units_scan_workgroup_reduce.txt above): from N ~ 10,000 the symmetric pass; with NB_FLAG_NO_SYM the
     ordered-pair families of round 2.  (A refit of one model constant once moved N = 12,000 .. 32,768 onto a shape 1-6 %
     slower without any test noticing.)"""
     with Simulation(n) as s:
