@@ -344,10 +344,11 @@ int nb_shape_info(nb_sim *s, uint32_t *jsplit, uint32_t *j_per_split, uint32_t *
  *   jsplit..own_splits as nb_shape_info
  *   sym*               symmetric pass only: padded rows, partial-sum layers, the rank form's super-block range, and the
  *                      plan words the kernels receive (nb::SymWPlan: np, nsb, W, total_hi, total_lo, n_hi, H, r_layer0,
- *                      t_layer0, L, p0; workgroup form nb::SymPlan: np, nsb, q, total_hi, total_lo, n_hi, H, r_layer0, t_layer0)
+ *                      t_layer0, L, zc -- nsb: the whole super-blocks of the ring, zc: the real chunks of the short block a ragged
+ *                      N leaves behind them; workgroup form nb::SymPlan: np, nsb, q, total_hi, total_lo, n_hi, H, r_layer0, t_layer0)
  *   tab                (caller's array of tab_cap words, may be NULL) first wave and resident layer count of every super-block's
- *                      list (a layer per workgroup of four waves ending there, one more if the last wave goes on), 2 * nsb
- *                      words; the W + 1 wave starts (first unit of every wave's range: equal in work, a sweep over a chunk of
+ *                      list (a layer per workgroup of four waves ending there, one more if the last wave goes on), 2 words per
+ *                      block of rows (sym_np / rows per super-block: the short block last); the W + 1 wave starts (first unit of every wave's range: equal in work, a sweep over a chunk of
  *                      padding rows counts nothing); with sym_ups > 1 followed by the spill tables -- the spill row of every wave (W words), {first
  *                      spill row, count} per traveler chunk (2 * sym_np / 64 words), then the wave numbers in spill-row order;
  *                      tab_len reports how many words there are
@@ -361,7 +362,7 @@ typedef struct nb_plan_info {
   uint32_t tab_len;
   char variant[112];
   uint32_t sym_ups;        /* wave-granular symmetric pass: work units per chunk-sweep (1: whole sweeps; 4: quarter sweeps) */
-  uint32_t sym_spill_rows; /* rows of the spill buffer (one row set per wave that starts inside a sweep; 0 with whole sweeps) */
+  uint32_t sym_spill_rows; /* rows of the spill buffer: the z-rows (a super-block's sums for a chunk of the short block), then one row set per wave that starts inside a sweep */
   uint32_t sym_rank_plan[16]; /* rank form (sym_rank): np, nsb, total_hi, total_lo, n_hi, H, r_layer0, rb_layer0, t_layer0, g0, g1, LA, LB,
                                  WA, WB, ups -- phase A = the sweeps whose travelers are the rank's own rows (LA sweeps, waves [0, WA):
                                  what an overlapped step issues before it waits for the all-gather), phase B the rest.  `tab` then

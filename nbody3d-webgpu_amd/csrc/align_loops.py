@@ -6,7 +6,7 @@
 Why.  Measured on MI355X (profiles/r04/README.md, "instruction alignment"): a wave issues a 64-bit encoded instruction (VOP3P
 packed f32, VOP3, DPP, SMEM ...) that straddles an 8-byte boundary more slowly -- the symmetric pass's 295-dword loop ran 12 %
 longer at one wave per SIMD and 5 % at two when its head sat at 4 mod 8, config 2's LDS-tile kernel lost 1.9 % between two
-builds whose loops execute the same 476 instructions.  hipcc aligns loop HEADS on request (-falign-loops=8) but nothing inside a
+builds whose loops execute the same 476 instructions.  hipcc aligns loop HEADS on request (-falign-loops=32) but nothing inside a
 loop, where every 32-bit instruction (s_waitcnt, s_add_u32, v_mov_b32_e32 ...) flips the parity of all that follows.
 
 How.  The device assembly hipcc writes (-S --cuda-device-only) is assembled once to learn every instruction's size, the loops

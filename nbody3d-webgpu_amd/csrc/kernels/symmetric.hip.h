@@ -206,23 +206,28 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
     // With ups > 1 a sweep may be shared by consecutive waves: each runs its own rotation steps [s0, s1) of it, starting from
     // travelers loaded s0 lanes ahead (wave_ror:1 moves a traveler from lane l to lane l + 1, so after s steps lane l holds the
     // traveler that started in lane l - s).
-    // The ranges are equal in WORK (a sweep over a chunk of padding rows costs nothing): the planner's table of wave starts.
-    const uint32_t ups = pl.ups, ustep = 64u / ups;
-    uint32_t u = active ? gtab[2 * pl.nsb + w] : 0u;
-    const uint32_t uend = active ? gtab[2 * pl.nsb + w + 1] : 0u;
+    // The wave starts are a table of the planner (W + 1 words behind the {first wave, resident layers} pair of every block of S rows).
+    // A ragged N leaves a SHORT block Z of pl.zc real chunks behind the pl.nsb whole super-blocks of the ring: every super-block sweeps
+    // Z's chunks after its ring sweeps (both sides: the traveler sums go to z-row g * zc + c of the spill buffer), and Z -- "super-block"
+    // pl.nsb, last in the list -- sweeps only its own chunks (nb_plan.cpp::lay_out_symw).
+    const uint32_t ups = pl.ups, ustep = 64u / ups, tab1 = 2u * (pl.np / S);
+    uint32_t u = active ? gtab[tab1 + w] : 0u;
+    const uint32_t uend = active ? gtab[tab1 + w + 1] : 0u;
     const nb_f2 e2 = nb_f2{eps2, eps2};
-    const uint32_t first_lo = pl.n_hi * pl.total_hi;
-    const uint32_t slot = ups > 1 && active ? gtab[2 * pl.nsb + pl.W + 1 + w] : 0u;      // the wave's spill row (it has at most one: the sweep its range starts inside)
+    const uint32_t first_lo = pl.n_hi * pl.total_hi, first_z = first_lo + (pl.nsb - pl.n_hi) * pl.total_lo;
+    const uint32_t slot = ups > 1 && active ? gtab[tab1 + pl.W + 1 + w] : 0u;      // the wave's spill row (it has at most one: the sweep its range starts inside)
     uint32_t gfin = ~0u;                       // the super-block the range ends in
 
     while (u < uend) {
         // which super-block's list the unit lies in, and where
-        const uint32_t ps = u / ups, p = pl.p0 + ps;                 // the sweep: relative to the handle's range / in the global list
+        const uint32_t p = u / ups;                                  // the sweep
         uint32_t g, k, total;
         if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
-        else { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
-        const uint32_t ring = total - CPS;                           // symmetric chunks of g; CPS resident-only chunks follow
-        uint32_t ug_end = (ps - k + total) * ups;                    // end of g's list, in units
+        else if (p < first_z) { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
+        else { g = pl.nsb; k = p - first_z; total = pl.zc; }         // Z over its own chunks
+        const uint32_t ring = g < pl.nsb ? total - CPS - pl.zc : 0u; // sweeps over the chunks of other super-blocks
+        const uint32_t both_end = g < pl.nsb ? ring + pl.zc : 0u;    // ... then over Z's: both keep traveler sums; own chunks follow
+        uint32_t ug_end = (p - k + total) * ups;                     // end of g's list, in units
         if (ug_end > uend) ug_end = uend;
 
         nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
@@ -242,13 +247,13 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             if (nun > ug_end - u) nun = ug_end - u;
             const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
             u += nun;
-            const bool sym = k < ring;
-            const uint32_t d = k / CPS;                              // ring distance - 1 (symmetric chunks)
+            const bool sym = k < both_end, zsweep = k >= ring && sym;
+            const uint32_t d = k / CPS;                              // ring distance - 1 (ring sweeps)
             uint32_t tb = g + 1 + d;
             if (tb >= pl.nsb) tb -= pl.nsb;
-            const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
+            const uint32_t tstart = k < ring ? tb * S + (k % CPS) * CH : zsweep ? pl.nsb * S + (k - ring) * CH : g * S + (k - both_end) * CH;
+            const uint32_t zrow = g * pl.zc + (k - ring);            // (z sweeps)
             ++k;
-            if (tstart >= n) continue;   // a chunk of padding rows only (zero mass): exerts nothing, and nobody reads its sums 
             float tx[J], ty[J], tz[J], tm[J];
             nb_f2 bx[J], by[J], bz[J];
             const uint32_t src = ((uint32_t)lane - s0) & 63u;        // the traveler this lane holds after s0 rotation steps
@@ -258,7 +263,7 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
                 tx[uu] = t.x; ty[uu] = t.y; tz[uu] = t.z; tm[uu] = t.w;
                 bx[uu] = nb_f2{0, 0}; by[uu] = nb_f2{0, 0}; bz[uu] = nb_f2{0, 0};
             }
-            // (the loop head is 8-byte aligned by -falign-loops=8: a packed instruction that straddles an 8-byte boundary issues
+            // (the loop head is 32-byte aligned by -falign-loops=32: a packed instruction that straddles an 8-byte boundary issues
             // more slowly -- 12 % on this loop at one wave per SIMD, profiles/r04/README.md)
             for (uint32_t st = s0; st < s1; ++st) {
 #pragma unroll
@@ -314,7 +319,8 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             if (sym) {
                 // the sums of steps [s0, s1) sit s1 lanes past their travelers' home lanes.  The part that starts the sweep owns the
                 // sweep's traveler layer; any later part goes to the wave's own spill row (K2 adds it: the spill rows of a chunk are consecutive)
-                SymRow* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)slot * CH) + (((uint32_t)lane - s1) & 63u);
+                SymRow* out = (s0 != 0 ? spill + (size_t)slot * CH : zsweep ? spill + (size_t)zrow * CH : partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart)
+                              + (((uint32_t)lane - s1) & 63u);
 #pragma unroll
                 for (int uu = 0; uu < J; ++uu) out[uu * 64] = SymRow{bx[uu].x + bx[uu].y, by[uu].x + by[uu].y, bz[uu].x + bz[uu].y};
             }
@@ -386,19 +392,20 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
     const bool active = w < pl.W;
     __shared__ double red[4][3 * IPL][64];     // see nb_force_symw: the last resident sums of the workgroup's waves meet here
     __shared__ uint32_t fin[4];
-    const uint32_t ups = pl.ups, ustep = 64u / ups;          // wave ranges in units of 64 / ups rotation steps, starts from the table: see nb_force_symw
-    uint32_t u = active ? gtab[2 * pl.nsb + w] : 0u;
-    const uint32_t uend = active ? gtab[2 * pl.nsb + w + 1] : 0u;
-    const uint32_t first_lo = pl.n_hi * pl.total_hi;
-    const uint32_t slot = ups > 1 && active ? gtab[2 * pl.nsb + pl.W + 1 + w] : 0u;
+    const uint32_t ups = pl.ups, ustep = 64u / ups, tab1 = 2u * (pl.np / S);          // wave ranges in units of 64 / ups rotation steps, starts from the table; the short block Z: see nb_force_symw
+    uint32_t u = active ? gtab[tab1 + w] : 0u;
+    const uint32_t uend = active ? gtab[tab1 + w + 1] : 0u;
+    const uint32_t first_lo = pl.n_hi * pl.total_hi, first_z = first_lo + (pl.nsb - pl.n_hi) * pl.total_lo;
+    const uint32_t slot = ups > 1 && active ? gtab[tab1 + pl.W + 1 + w] : 0u;
     uint32_t gfin = ~0u;
     while (u < uend) {
-        const uint32_t ps = u / ups, p = pl.p0 + ps;
+        const uint32_t p = u / ups;
         uint32_t g, k, total;
         if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
-        else { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
-        const uint32_t ring = total - CPS;
-        uint32_t ug_end = (ps - k + total) * ups;
+        else if (p < first_z) { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
+        else { g = pl.nsb; k = p - first_z; total = pl.zc; }
+        const uint32_t ring = g < pl.nsb ? total - CPS - pl.zc : 0u, both_end = g < pl.nsb ? ring + pl.zc : 0u;
+        uint32_t ug_end = (p - k + total) * ups;
         if (ug_end > uend) ug_end = uend;
         double xi[IPL], yi[IPL], zi[IPL], mi[IPL], ax[IPL], ay[IPL], az[IPL];
 #pragma unroll
@@ -413,13 +420,13 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
             if (nun > ug_end - u) nun = ug_end - u;
             const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
             u += nun;
-            const bool sym = k < ring;
+            const bool sym = k < both_end, zsweep = k >= ring && sym;
             const uint32_t d = k / CPS;
             uint32_t tb = g + 1 + d;
             if (tb >= pl.nsb) tb -= pl.nsb;
-            const uint32_t tstart = sym ? tb * S + (k % CPS) * CH : g * S + (k - ring) * CH;
+            const uint32_t tstart = k < ring ? tb * S + (k % CPS) * CH : zsweep ? pl.nsb * S + (k - ring) * CH : g * S + (k - both_end) * CH;
+            const uint32_t zrow = g * pl.zc + (k - ring);
             ++k;
-            if (tstart >= n) continue;
             const double4 t = ld4(bodies + tstart + (((uint32_t)lane - s0) & 63u));
             double tx = t.x, ty = t.y, tz = t.z, tm = t.w * G, bx = 0, by = 0, bz = 0;
             for (uint32_t st = s0; st < s1; ++st) {
@@ -454,7 +461,8 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
                 bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz);
             }
             if (sym) {
-                SymRowT<double>* out = (s0 == 0 ? partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart : spill + (size_t)slot * CH) + (((uint32_t)lane - s1) & 63u);
+                SymRowT<double>* out = (s0 != 0 ? spill + (size_t)slot * CH : zsweep ? spill + (size_t)zrow * CH : partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart)
+                                       + (((uint32_t)lane - s1) & 63u);
                 *out = SymRowT<double>{bx, by, bz};
             }
         }
@@ -827,7 +835,7 @@ __global__ __launch_bounds__(kBlock) void nb_peer_gather(const PeerPtrs src, typ
 
 // K2 for the wave-granular form: resident layers gtab[2g+1] (workgroups whose waves ended in g's list, + the wave that went on), then the traveler layers, then (wave
 // ranges cut inside sweeps, pl.ups > 1) the spill rows of the waves that ran a later part of a sweep over the body's chunk:
-// {first spill row, count} per chunk of CH rows at gtab[2 nsb + 2 W + 1 + 2 chunk] (a chunk's spill rows are consecutive, in wave order: the
+// {first spill row, count} per chunk of CH rows at gtab[2 np / S + 2 W + 1 + 2 chunk] (a chunk's spill rows are consecutive, in wave order: the
 // row addresses hang on ONE table load, like the layers').  Fixed order.  The body's own state is requested before the sums.
 template <typename T, int R>
 __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::type* __restrict__ bodies, typename vec4<T>::type* __restrict__ vel,
@@ -850,18 +858,23 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::ty
         const uint32_t il0 = blockIdx.x * (kBlock / R);
         const uint32_t b = il0 / S;
         const uint32_t nr = gtab[2 * b + 1];
-        const uint32_t nt = pl.H + ((pl.n_hi && b >= pl.n_hi) ? 1u : 0u);
+        // traveler sums: a row of a whole super-block has one layer per ring distance; a row of the short block Z (b == pl.nsb) has
+        // the z-rows instead -- one per whole super-block, row g * zc + c of the spill buffer (c: its chunk inside Z)
+        const bool zb = b >= pl.nsb;
+        const uint32_t nt = zb ? pl.nsb : pl.H + ((pl.n_hi && b >= pl.n_hi) ? 1u : 0u);
         uint32_t ns = 0, s_first = 0;
         const uint32_t ci = il0 >> ch_shift;
+        const uint32_t zci = ci - ((pl.nsb * S) >> ch_shift);
         if (pl.ups > 1) {
-            const uint32_t* ent = gtab + 2 * pl.nsb + 2 * pl.W + 1 + 2 * ci;
+            const uint32_t* ent = gtab + 2 * (pl.np / S) + 2 * pl.W + 1 + 2 * ci;
             s_first = ent[0];
             ns = ent[1];
         }
         const uint32_t total = nr + nt + ns;
         auto row = [&](uint32_t e) {
             if (e < nr) return partial + (size_t)(pl.r_layer0 + e) * pl.np + il;
-            if (e < nr + nt) return partial + (size_t)(pl.t_layer0 + (e - nr)) * pl.np + il;
+            if (e < nr + nt) return zb ? spill + (((size_t)((e - nr) * pl.zc + zci) << ch_shift) + (il - (ci << ch_shift)))
+                                       : partial + (size_t)(pl.t_layer0 + (e - nr)) * pl.np + il;
             return spill + (((size_t)(s_first + (e - nr - nt)) << ch_shift) + (il - (ci << ch_shift)));
         };
         uint32_t e = r;

@@ -186,15 +186,13 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         if (ipl == 4 && !whole_only) continue;      // 4 residents per lane only won by their finer rounding of WHOLE sweeps (N ~ 14,000 .. 18,000); with
                                                     // eighth sweeps they are 10-20 % behind at every size (profiles/r04/sym_units_scan_workgroup_reduce.txt)
         const uint32_t NG = (uint32_t)ipl / 2, S = 64u * (uint32_t)ipl, cps = S / 64u;
-        const uint32_t nsb = ceil_div(n, S);
-        if (nsb < 4) continue;
+        if (ceil_div(n, S) < 4) continue;
         if (sym_layer_bytes(n, S, f64 ? 8 : 4) > layer_budget) continue;
+        // the ring of whole super-blocks; a ragged N leaves a short block of zc real chunks that every super-block sweeps (lay_out_symw)
+        const uint32_t nsb = n / S, zc = ceil_div(n % S, 64u);
         const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
-        const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps, total_lo = (uint64_t)(H + 1) * cps;
-        // sweeps over chunks of padding rows only cost nothing (the wave ranges are cut by work): (np - n) / 64 chunks of the last
-        // super-block, each on the list of the H (+1) super-blocks that sweep it and on its own
-        const uint64_t pad_sweeps = (uint64_t)((nsb * S - n) / 64u) * (H + (n_hi ? 1u : 0u) + 1u);
-        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo - pad_sweeps;
+        const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps + zc, total_lo = (uint64_t)(H + 1) * cps + zc;
+        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo + zc;
         // f64: 92 issue cycles per resident and step + 14 DPP; the loop runs at 96 % of that (N = 262,144: 23.7 ms, profiles/r03/sym_f64_first.txt)
         const double t_chunk = f64 ? 64.0 * (92.0 * ipl + 56.0) / 0.96 / clock : 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.95 : 0.935) / clock;
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
@@ -228,87 +226,67 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
     return best;
 }
 
-// Wave-granular form of the symmetric pass (nb_force_symw / nb_force_symw64): the ring of super-blocks, the handle's range of the
-// global chunk list, its cut into W wave ranges and the {first wave, resident layers} table of every super-block.
-//   rank_ipl != 0: rank form -- only the lists of the handle's own super-blocks [sb / S, (sb + sc) / S)
-//   sym_k: waves per SIMD the cost model asked for (0: cfg.jsplit, else 1; rank form 2 when there is enough work)
-static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, uint32_t sb, uint32_t sc, const nb_config& cfg, int n_cu,
-                         int rank_ipl, uint32_t sym_k, uint32_t sym_ups)
+// Wave-granular form of the symmetric pass (nb_force_symw / nb_force_symw64), whole system: the ring of super-blocks, the chunk lists
+// laid end to end, their cut into W wave ranges and the {first wave, resident layers} table of every super-block.
+//   sym_k: waves per SIMD the cost model asked for (0: cfg.jsplit, else 1);  sym_ups: its units per sweep (0: sym_units)
+//
+// A ragged N (n % S != 0) leaves a SHORT block Z of zc real chunks behind the nsb whole super-blocks.  Z stays out of the ring: as a
+// resident it would run a whole list with mostly padding in its lanes (N = 40,002: 320 sweeps for 66 real rows, 2.3 % of the step),
+// and the sweeps of others over its padded chunks would be dead entries in their lists.  Instead EVERY whole super-block sweeps Z's
+// zc real chunks (both sides; the traveler sums go to a row of their own, "z-row" g * zc + c of the spill buffer, which K2 adds for
+// the rows of Z), and Z sweeps only its own chunks (zc sweeps at the end of the list).  List of a whole super-block g:
+//   [ring sweeps: the chunks of the H (+1) super-blocks after it] [zc sweeps over Z's chunks] [cps sweeps over its own chunks]
+static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, const nb_config& cfg, int n_cu, uint32_t sym_k, uint32_t sym_ups)
 {
-    // wave-granular form: super-block = one wave's residents; the chunk lists of all super-blocks laid end to end are cut
-    // into W equal ranges, W = cfg.jsplit (default 1) waves per SIMD of the chip.
     const uint32_t S = ipb_of(sh), J = sh.x == 3 ? 1u : 2u, CH = 64u * J, cps = S / CH;
-    const uint32_t nsb = ceil_div(n, S), H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
+    const uint32_t blocks = ceil_div(n, S), rem = n % S;                       // blocks of S rows the arrays are padded to; rows of the short one
+    const uint32_t zc = rem ? ceil_div(rem, CH) : 0u;
+    const uint32_t nsb = rem ? blocks - 1u : blocks;                            // the ring (plan_launch asks for n > S: at least one whole super-block)
+    const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
     nb::SymWPlan pl;
-    pl.np = nsb * S; pl.nsb = nsb;
-    pl.total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps; pl.total_lo = (H + 1) * cps;
+    pl.np = blocks * S; pl.nsb = nsb; pl.zc = zc;
+    pl.total_hi = (H + 1 + (n_hi ? 1u : 0u)) * cps + zc; pl.total_lo = (H + 1) * cps + zc;
     pl.n_hi = n_hi; pl.H = H;
-    auto offset_of = [&](uint32_t g) { return g <= n_hi ? g * pl.total_hi : n_hi * pl.total_hi + (g - n_hi) * pl.total_lo; };
-    // a whole system sweeps every super-block's list; a rank (rank_ipl) only those of its own rows
-    const uint32_t g0 = rank_ipl ? sb / S : 0u, g1 = rank_ipl ? (sb + sc) / S : nsb;
-    pl.p0 = offset_of(g0);
-    pl.L = offset_of(g1) - pl.p0;
-    const uint32_t kw = sym_k ? sym_k : (cfg.jsplit ? cfg.jsplit : (rank_ipl && pl.L >= 16u * (uint32_t)n_cu ? 2u : 1u));
+    const uint32_t first_lo = n_hi * pl.total_hi, first_z = first_lo + (nsb - n_hi) * pl.total_lo;
+    pl.L = first_z + zc;
+    auto offset_of = [&](uint32_t g) { return g <= n_hi ? g * pl.total_hi : g < nsb ? first_lo + (g - n_hi) * pl.total_lo : first_z; };
+    auto total_of = [&](uint32_t g) { return g < n_hi ? pl.total_hi : g < nsb ? pl.total_lo : zc; };
+    const uint32_t kw = sym_k ? sym_k : (cfg.jsplit ? cfg.jsplit : 1u);
     uint32_t W = 4u * (uint32_t)n_cu * kw;
-    // work units per sweep: the rank form's reduction kernels know nothing of spill rows, so a rank keeps whole sweeps
-    const bool whole_only = rank_ipl != 0 || (cfg.flags & NB_FLAG_WHOLE_SWEEPS);
-    const uint32_t ups = whole_only ? 1u : (sym_ups ? sym_ups : sym_units(pl.L, W, false));
+    const uint32_t ups = (cfg.flags & NB_FLAG_WHOLE_SWEEPS) ? 1u : (sym_ups ? sym_ups : sym_units(pl.L, W, false));
     pl.ups = ups;
-    const uint64_t Lu = (uint64_t)pl.L * ups;                  // the handle's list in units
-    // What a sweep costs: nothing when its traveler chunk is padding only (rows >= n: the kernel skips it) -- a ragged N has (np - n) / CH
-    // such chunks in the last super-block, each on the list of every super-block that sweeps it: 2 % of all sweeps at N = 40,002 --
-    // else one sweep.  The wave ranges are equal in COST, not in list length: their starts come from a table.
-    const uint32_t first_lo = n_hi * pl.total_hi;
-    auto sweep_at = [&](uint32_t p, uint32_t& g, uint32_t& k, uint32_t& total) {          // p: position in the global list
-        if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
-        else { const uint32_t r = p - first_lo; g = n_hi + r / pl.total_lo; k = r - (g - n_hi) * pl.total_lo; total = pl.total_lo; }
-    };
-    auto tstart_at = [&](uint32_t g, uint32_t k, uint32_t total) {
-        const uint32_t ring = total - cps;
-        if (k >= ring) return g * S + (k - ring) * CH;                                      // resident-only sweep of an own chunk
-        uint32_t tb = g + 1 + k / cps;
-        if (tb >= nsb) tb -= nsb;
-        return tb * S + (k % cps) * CH;
-    };
-    // The sweeps that cost nothing sit in at most H + 2 runs of `m` list positions: the padded chunks [cz, cps) of the last super-block Z
-    // on the list of every super-block that sweeps Z, and on Z's own (resident-only) part.  runs[j] = first position of run j, ascending.
-    const uint32_t Z = nsb - 1, cz = ceil_div(n - Z * S, CH), m = cps - cz;
-    std::vector<uint64_t> runs;
-    if (m && !rank_ipl) {
-        for (uint32_t g = 0; g < Z; ++g) {
-            const uint32_t d = Z - 1 - g;                                                   // Z = g + 1 + d
-            if (d < H + (g < n_hi ? 1u : 0u)) runs.push_back((uint64_t)offset_of(g) + (uint64_t)d * cps + cz);
-        }
-        runs.push_back((uint64_t)offset_of(Z) + ((Z < n_hi ? pl.total_hi : pl.total_lo) - cps) + cz);
-    }
-    const uint64_t Cu = ((uint64_t)pl.L - (uint64_t)runs.size() * m) * ups;                 // the handle's work in units
-    if (W > Cu) W = (uint32_t)Cu;                               // never more waves than units of work: every wave has work, so every resident layer the
-                                                               // table counts is written (the kernel's `w >= W` guard idles the rest of the last workgroup)
+    const uint64_t Lu = (uint64_t)pl.L * ups;                  // the list in units
+    if (W > Lu) W = (uint32_t)Lu;                               // never more waves than units: every wave has work, so every resident layer the table
+                                                               // counts is written (the kernel's `w >= W` guard idles the rest of the last workgroup)
     pl.W = W;
-    std::vector<uint32_t> starts((size_t)W + 1);               // first unit of wave w (relative to the handle's range)
-    {
-        size_t q = 0;                                          // runs wholly before the wave's first sweep
-        for (uint32_t w = 0; w < W; ++w) {
-            const uint64_t target = (uint64_t)w * Cu / W;      // units of work before the wave
-            const uint64_t t = target / ups;                   // ... = real sweeps before its first one
-            while (q < runs.size() && runs[q] - q * m <= t) ++q;      // run q starts after (runs[q] - q m) real sweeps
-            starts[w] = (uint32_t)((t + q * m) * ups + target % ups);
-        }
-    }
-    starts[0] = 0;
-    starts[W] = (uint32_t)Lu;
+    // position in the list -> super-block, place in its list, length of that list
+    auto sweep_at = [&](uint32_t p, uint32_t& g, uint32_t& k, uint32_t& total) {
+        if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
+        else if (p < first_z) { const uint32_t r = p - first_lo; g = n_hi + r / pl.total_lo; k = r - (g - n_hi) * pl.total_lo; total = pl.total_lo; }
+        else { g = nsb; k = p - first_z; total = zc; }
+    };
+    // the traveler chunk of a sweep (first row) and whether it keeps traveler sums
+    auto traveler_of = [&](uint32_t g, uint32_t k, uint32_t total, bool& both) {
+        if (g == nsb) { both = false; return g * S + k * CH; }                              // Z over its own chunks
+        const uint32_t ring = total - cps - zc;
+        if (k < ring) { uint32_t tb = g + 1 + k / cps; if (tb >= nsb) tb -= nsb; both = true; return tb * S + (k % cps) * CH; }
+        if (k < ring + zc) { both = true; return nsb * S + (k - ring) * CH; }               // a chunk of Z
+        both = false;
+        return g * S + (k - ring - zc) * CH;                                                // an own chunk
+    };
+    // The wave ranges: equal in units (every sweep of these lists is real work; the starts are a table so that a later cost model can weight them)
+    std::vector<uint32_t> starts((size_t)W + 1);
+    for (uint32_t w = 0; w <= W; ++w) starts[w] = (uint32_t)((uint64_t)w * Lu / W);
     auto start_of = [&](uint32_t w) { return (uint64_t)starts[w]; };
-    auto wave_of = [&](uint64_t u) { return (uint32_t)(std::upper_bound(starts.begin(), starts.begin() + W, (uint32_t)u) - starts.begin()) - 1u; };      // u: unit inside this handle's range
-    const uint32_t nch = pl.np / CH;
-    // the table: {first wave, resident layers} per super-block, the W + 1 wave starts, then (ups > 1) the spill tables
-    const size_t starts0 = 2 * (size_t)nsb;
+    auto wave_of = [&](uint64_t u) { return (uint32_t)(std::upper_bound(starts.begin(), starts.begin() + W, (uint32_t)u) - starts.begin()) - 1u; };
+    const uint32_t nch = pl.np / CH, zrows = nsb * zc;
+    // the table: {first wave, resident layers} per block of S rows (Z last), the W + 1 wave starts, then (ups > 1) the spill tables
+    const size_t starts0 = 2 * (size_t)blocks;
     s->sym_tab_host.assign(starts0 + W + 1 + (ups > 1 ? (size_t)W + 2 * (size_t)nch : 0), 0);
     std::copy(starts.begin(), starts.end(), s->sym_tab_host.begin() + starts0);
     uint32_t max_r = 1;
-    for (uint32_t g = g0; g < g1; ++g) {
-        const uint32_t total = g < n_hi ? pl.total_hi : pl.total_lo;
-        const uint64_t off = (uint64_t)(offset_of(g) - pl.p0) * ups;
-        const uint64_t end = off + (uint64_t)total * ups;
+    for (uint32_t g = 0; g < blocks; ++g) {
+        const uint64_t off = (uint64_t)offset_of(g) * ups, end = off + (uint64_t)total_of(g) * ups;
         const uint32_t first = wave_of(off), last = wave_of(end - 1);
         // resident layers of g: the waves whose range ENDS in g's list add their sums up per workgroup of four (in LDS) -- one layer
         // per workgroup, (w / 4) - (first / 4) -- and the last wave, if its range goes on into g + 1, stores its part on its own
@@ -318,7 +296,8 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, u
         s->sym_tab_host[2 * g] = first; s->sym_tab_host[2 * g + 1] = layers;
         if (layers > max_r) max_r = layers;
     }
-    s->sym_spill_rows = 0;
+    // The spill buffer: the z-rows (whole super-block g's sums for chunk c of Z: row g * zc + c), then the spill rows of the waves.
+    s->sym_spill_rows = zrows * CH;
     if (ups > 1) {
         // spill rows: a wave whose range starts inside a sweep keeps that sweep's traveler sums in a spill row of its own; K2 adds
         // them to the rows of the sweep's traveler chunk.  The rows are numbered chunk by chunk (waves ascending inside a chunk), so K2
@@ -328,12 +307,12 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, u
         std::vector<Spill> sp;
         for (uint32_t w = 0; w < pl.W; ++w) {
             const uint64_t u = start_of(w);
-            if (u % ups == 0 || start_of(w + 1) == u) continue;               // starts a sweep, or has no work
+            if (u % ups == 0) continue;                                         // starts a sweep
             uint32_t g, k, total;
-            sweep_at(pl.p0 + (uint32_t)(u / ups), g, k, total);
-            if (k >= total - cps) continue;                                     // resident-only sweep: no traveler sums
-            const uint32_t tstart = tstart_at(g, k, total);
-            if (tstart >= n) continue;                                          // a chunk of padding rows: skipped by the kernel
+            sweep_at((uint32_t)(u / ups), g, k, total);
+            bool both;
+            const uint32_t tstart = traveler_of(g, k, total, both);
+            if (!both) continue;                                                // a sweep over an own chunk: no traveler sums
             sp.push_back({tstart / CH, w});
         }
         std::stable_sort(sp.begin(), sp.end(), [](const Spill& a, const Spill& b) { return a.chunk < b.chunk; });      // waves stay ascending inside a chunk
@@ -341,14 +320,14 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, u
         s->sym_tab_host.resize(ids0 + sp.size(), 0);
         for (size_t e = 0; e < sp.size(); ++e) {
             uint32_t* ent = &s->sym_tab_host[base + 2 * (size_t)sp[e].chunk];
-            if (ent[1] == 0) ent[0] = (uint32_t)e;
+            if (ent[1] == 0) ent[0] = zrows + (uint32_t)e;
             ++ent[1];
             s->sym_tab_host[ids0 + e] = sp[e].wave;
-            s->sym_tab_host[slot0 + sp[e].wave] = (uint32_t)e;
+            s->sym_tab_host[slot0 + sp[e].wave] = zrows + (uint32_t)e;
         }
-        s->sym_spill_rows = std::max<uint32_t>(1u, (uint32_t)sp.size()) * CH;
+        s->sym_spill_rows = (zrows + std::max<uint32_t>(1u, (uint32_t)sp.size())) * CH;
     }
-    s->sym_rank = rank_ipl != 0; s->sym_g0 = g0; s->sym_g1 = g1;
+    s->sym_rank = false; s->sym_g0 = 0; s->sym_g1 = blocks;
     pl.r_layer0 = 0; pl.t_layer0 = max_r;
     static_assert(sizeof(pl) <= sizeof(s->sym_plan), "LaunchPlan::sym_plan holds a SymWPlan");
     memcpy(s->sym_plan, &pl, sizeof pl);
@@ -501,7 +480,7 @@ static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t
     for (const auto& ps : s->sym_passes) Lsum += ps.plan[11] + ps.plan[12];
     pl.np = rp.np; pl.nsb = nsb; pl.W = rp.WA + rp.WB; pl.total_hi = rp.total_hi; pl.total_lo = rp.total_lo; pl.n_hi = n_hi; pl.H = H;
     pl.r_layer0 = 0; pl.t_layer0 = rp.t_layer0; pl.L = Lsum; pl.ups = rp.ups;
-    pl.p0 = (rp.g0 <= n_hi ? rp.g0 * rp.total_hi : n_hi * rp.total_hi + (rp.g0 - n_hi) * rp.total_lo);
+    pl.zc = 0;
     memcpy(s->sym_plan, &pl, sizeof pl);
     s->sym_rank = true; s->sym_g0 = rp.g0; s->sym_g1 = rp.g1;
     s->sym = true; s->symw = true; s->sym_np = rp.np; s->sym_layers = layers;
@@ -790,7 +769,7 @@ LaunchPlan plan_launch(const PlanInput& in)
         sh = ordered_sh; js = ordered_js;
     }
     if (sh.kind == kSym && rank_ipl) { lay_out_symw_rank(s, sh, f64, n, sb, sc, cfg, n_cu, 0); return plan; }
-    if (sh.kind == kSym && sh.x != 4) { lay_out_symw(s, sh, f64, n, sb, sc, cfg, n_cu, 0, sym_k, sym_ups); return plan; }
+    if (sh.kind == kSym && sh.x != 4) { lay_out_symw(s, sh, f64, n, cfg, n_cu, sym_k, sym_ups); return plan; }
     if (sh.kind == kSym) { lay_out_sym_wg(s, sh, f64, n, cfg, n_cu); return plan; }
     s->ipl = sh.ipl; s->ls = sh.ls;
     s->packed = sh.kind != kScalar; s->sgpr = sh.kind == kPkSgpr;

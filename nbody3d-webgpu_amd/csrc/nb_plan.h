@@ -30,9 +30,9 @@ struct SymWPlan {
     uint32_t np, nsb, W;
     uint32_t total_hi, total_lo, n_hi, H;
     uint32_t r_layer0, t_layer0;
-    uint32_t L;                 // chunk-sweeps of this handle: n_hi * total_hi + (nsb - n_hi) * total_lo for a whole system
-    uint32_t p0;                // where this handle's range starts in the global list (0 for a whole system; a RANK that owns
-                                // the resident super-blocks [g0, g1) works on the lists of those super-blocks only)
+    uint32_t L;                 // chunk-sweeps of this handle: n_hi * total_hi + (nsb - n_hi) * total_lo + zc
+    uint32_t zc;                // real chunks of the short block Z behind the nsb whole super-blocks of the ring (0: n is a multiple of the
+                                // super-block): every whole super-block sweeps them, Z only its own (nb_plan.cpp::lay_out_symw)
     uint32_t ups;               // work units per chunk-sweep (1, 2, 4 or 8): the W wave ranges are floor/ceil-equal in UNITS of
                                 // 64 / ups rotation steps, so a sweep may be shared by consecutive waves.  The wave that runs a
                                 // sweep's steps from 0 stores its traveler sums in the sweep's traveler layer; a wave that starts

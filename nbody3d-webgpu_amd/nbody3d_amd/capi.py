@@ -174,7 +174,7 @@ def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
 
-SYMW_PLAN_WORDS = ("np", "nsb", "W", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "t_layer0", "L", "p0")
+SYMW_PLAN_WORDS = ("np", "nsb", "W", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "t_layer0", "L", "zc")
 SYM_RANK_PLAN_WORDS = ("np", "nsb", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "rb_layer0", "t_layer0", "g0", "g1", "LA", "LB", "WA", "WB", "ups")
 SYM_PLAN_WORDS = ("np", "nsb", "q", "total_hi", "total_lo", "n_hi", "H", "r_layer0", "t_layer0")
 
@@ -228,10 +228,13 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
                 out["spill_ids"] = tab[base + 2 * nch:]
             out["tab"] = out["rank_tab"][:, :2]
         else:
+            if info.symw:
+                # one {first wave, resident layers} pair per block of S rows: the nsb whole super-blocks of the ring, then the short block Z
+                nsb = out["plan"]["np"] // (64 * int(info.ipl))
             out["tab"] = tab[:2 * nsb].reshape(-1, 2)
             if info.symw:
                 W = out["plan"]["W"]
-                out["starts"] = tab[2 * nsb:2 * nsb + W + 1]              # first unit of every wave's range (equal in work), then the list's end
+                out["starts"] = tab[2 * nsb:2 * nsb + W + 1]              # first unit of every wave's range, then the list's end
         out["ups"], out["spill_rows"] = int(info.sym_ups), int(info.sym_spill_rows)
         if info.symw:
             out["plan"]["ups"] = int(info.sym_ups)

@@ -15,60 +15,65 @@ from nbody3d_amd import capi
 NB_FLAG_NO_SYM, NB_FLAG_SYM_SHARD, NB_FLAG_WHOLE_SWEEPS = 64, 128, 256
 
 
-def walk_symw(q, n, rank=False):
-    """Every chunk-sweep of a wave-granular plan as arrays (one entry per list position of this handle), and the waves that
-    share it: the plan cuts the handle's L sweeps into W ranges of UNITS (ups units = 64 rotation steps per sweep)."""
+def walk_symw(q, n):
+    """Every chunk-sweep of a whole-system wave-granular plan as arrays (one entry per list position), and the waves that share it:
+    the plan cuts the L sweeps into W ranges of UNITS (ups units = 64 rotation steps per sweep).
+
+    The ring holds the nsb WHOLE super-blocks; a ragged n leaves a short block Z of zc real chunks behind them, which every
+    super-block sweeps after its ring sweeps ("z sweeps", both sides) and which sweeps only its own chunks, last in the list."""
     pl, tab = q["plan"], q["tab"]
     J = 2 if q["x"] == 1 else 1
     S, CH = 64 * q["ipl"], 64 * J
     cps = S // CH
-    nsb, W, L, p0, ups = pl["nsb"], pl["W"], pl["L"], pl["p0"], pl["ups"]
+    nsb, W, L, zc, ups = pl["nsb"], pl["W"], pl["L"], pl["zc"], pl["ups"]
     assert ups in (1, 2, 4, 8) and q["ups"] == ups
-    assert pl["np"] == nsb * S and nsb == -(-n // S)
+    blocks = -(-n // S)
+    assert pl["np"] == blocks * S and nsb == n // S and zc == -(-(n % S) // CH) and blocks == nsb + (1 if zc else 0)
     H, n_hi = pl["H"], pl["n_hi"]
     assert H == (nsb - 1) // 2 and n_hi == (0 if nsb % 2 else nsb // 2)
-    assert pl["total_lo"] == (H + 1) * cps and pl["total_hi"] == (H + 1 + (1 if n_hi else 0)) * cps
-    p = p0 + np.arange(L, dtype=np.int64)
+    assert pl["total_lo"] == (H + 1) * cps + zc and pl["total_hi"] == (H + 1 + (1 if n_hi else 0)) * cps + zc
     first_lo = n_hi * pl["total_hi"]
-    hi = p < first_lo
-    g = np.where(hi, p // pl["total_hi"], n_hi + (p - first_lo) // pl["total_lo"])
-    k = np.where(hi, p - g * pl["total_hi"], (p - first_lo) - (g - n_hi) * pl["total_lo"])
-    total = np.where(hi, pl["total_hi"], pl["total_lo"])
-    ring = total - cps
-    sym = k < ring
+    first_z = first_lo + (nsb - n_hi) * pl["total_lo"]
+    assert L == first_z + zc
+    p = np.arange(L, dtype=np.int64)
+    hi, zown = p < first_lo, p >= first_z
+    g = np.where(hi, p // pl["total_hi"], np.where(zown, nsb, n_hi + (p - first_lo) // pl["total_lo"]))
+    k = np.where(hi, p - g * pl["total_hi"], np.where(zown, p - first_z, (p - first_lo) - (g - n_hi) * pl["total_lo"]))
+    total = np.where(hi, pl["total_hi"], np.where(zown, zc, pl["total_lo"]))
+    ring = np.where(zown, 0, total - cps - zc)
+    both_end = np.where(zown, 0, ring + zc)
+    ringsw = k < ring                              # over a chunk of another whole super-block
+    zsw = (k >= ring) & (k < both_end)             # over a chunk of Z
+    sym = ringsw | zsw                             # both keep traveler sums
     d = k // cps
-    tb = np.where(sym, (g + 1 + d) % nsb, g)
-    c = np.where(sym, k % cps, k - ring)
+    tb = np.where(ringsw, (g + 1 + d) % max(nsb, 1), np.where(zsw, nsb, g))
+    c = np.where(ringsw, k % cps, np.where(zsw, k - ring, k - both_end))
     tstart = tb * S + c * CH
-    # the waves: W ranges of the handle's L * ups units, equal in WORK to one unit -- a sweep over a chunk of padding rows only
-    # (tstart >= n: the kernel skips it) costs nothing -- none of them without work; their starts are a table of the plan
+    assert np.all(tstart < n)                      # no sweep over padding only
+    # the waves: W ranges of the L * ups units, equal to one unit, none of them empty; their starts are a table of the plan
     Lu = L * ups
-    if rank:
-        starts = (np.arange(W + 1, dtype=np.int64) * Lu) // W
-    else:
-        starts = q["starts"].astype(np.int64)
-    assert len(starts) == W + 1 and starts[0] == 0 and starts[-1] == Lu and W <= Lu and np.diff(starts).min() >= 1
-    work = np.repeat((tstart < n).astype(np.int64), ups)                                        # per unit
-    per_wave = np.add.reduceat(work, starts[:-1])
-    assert per_wave.sum() == work.sum() and per_wave.min() >= 1 and per_wave.max() - per_wave.min() <= 1, (per_wave.min(), per_wave.max())
+    starts = q["starts"].astype(np.int64)
+    assert len(starts) == W + 1 and starts[0] == 0 and starts[-1] == Lu and W <= Lu
+    assert np.diff(starts).min() >= 1 and np.diff(starts).max() - np.diff(starts).min() <= 1
     wu = np.searchsorted(starts, np.arange(Lu, dtype=np.int64), side="right") - 1               # the wave of every unit
     assert np.all((wu >= 0) & (wu < W))
-    w = wu[::ups]                                # the wave that starts each sweep (steps from 0): it owns the sweep's traveler layer
+    w = wu[::ups]                                # the wave that starts each sweep (steps from 0): it owns the sweep's traveler layer / z-row
     w_last = wu[ups - 1::ups]                    # ... and the one that ends it
-    return dict(S=S, CH=CH, cps=cps, nsb=nsb, H=H, n_hi=n_hi, g=g, k=k, sym=sym, d=d, tb=tb, c=c, tstart=tstart, w=w, w_last=w_last, wu=wu,
-                starts=starts, ups=ups, pl=pl, tab=tab)
+    return dict(S=S, CH=CH, cps=cps, nsb=nsb, blocks=blocks, zc=zc, H=H, n_hi=n_hi, g=g, k=k, sym=sym, ringsw=ringsw, zsw=zsw, d=d, tb=tb, c=c,
+                tstart=tstart, w=w, w_last=w_last, wu=wu, starts=starts, ups=ups, pl=pl, tab=tab)
 
 
 def check_spill_lists(q, n, wk):
     """ups > 1: a wave whose range starts INSIDE a sweep keeps that sweep's traveler sums in its own spill row; the plan lists,
     per traveler chunk, the waves K2 has to add -- exactly those, in ascending order."""
     ups, W, CH, starts = wk["ups"], wk["pl"]["W"], wk["CH"], wk["starts"]
+    zrows = wk["nsb"] * wk["zc"]                  # the z-rows come first in the spill buffer: whole super-block g's sums for chunk c of Z = row g * zc + c
     if ups == 1:
-        assert q["spill_rows"] == 0 and "spill_tab" not in q
+        assert q["spill_rows"] == zrows * CH and "spill_tab" not in q
         return
     st, ids, slot = q["spill_tab"], q["spill_ids"], q["spill_slot"]
-    assert q["spill_rows"] == max(1, len(ids)) * CH and len(slot) == W
-    assert all(int(slot[int(wv)]) == e for e, wv in enumerate(ids))        # spill row e belongs to wave ids[e]: rows run chunk by chunk
+    assert q["spill_rows"] == (zrows + max(1, len(ids))) * CH and len(slot) == W
+    assert all(int(slot[int(wv)]) == zrows + e for e, wv in enumerate(ids))        # spill row zrows + e belongs to wave ids[e]: rows run chunk by chunk
     assert st.shape[0] == wk["pl"]["np"] // CH
     want = {}
     for wv in range(W):
@@ -76,11 +81,11 @@ def check_spill_lists(q, n, wk):
         if u0 % ups == 0:
             continue
         sw = u0 // ups
-        if wk["sym"][sw] and wk["tstart"][sw] < n:
+        if wk["sym"][sw]:
             want.setdefault(int(wk["tstart"][sw]) // CH, []).append(wv)
     got = {}
     for ci in range(st.shape[0]):
-        off, cnt = int(st[ci, 0]), int(st[ci, 1])
+        off, cnt = int(st[ci, 0]) - zrows, int(st[ci, 1])
         if cnt:
             got[ci] = [int(x) for x in ids[off:off + cnt]]
     assert got == want
@@ -92,31 +97,37 @@ def check_spill_lists(q, n, wk):
 def check_whole_plan(q, n):
     """A whole-system wave-granular plan: pair coverage, layer writes, and K2's read set."""
     wk = walk_symw(q, n)
-    nsb, cps, H, n_hi, pl, tab = wk["nsb"], wk["cps"], wk["H"], wk["n_hi"], wk["pl"], wk["tab"]
-    g, sym, d, tb, c, w = wk["g"], wk["sym"], wk["d"], wk["tb"], wk["c"], wk["w"]
-    assert pl["p0"] == 0 and pl["L"] == n_hi * pl["total_hi"] + (nsb - n_hi) * pl["total_lo"]
-    # (1) unordered pairs of DIFFERENT super-blocks: each (resident block, traveler chunk) at most once, and for a != b
+    nsb, blocks, zc, cps, H, n_hi, pl, tab = wk["nsb"], wk["blocks"], wk["zc"], wk["cps"], wk["H"], wk["n_hi"], wk["pl"], wk["tab"]
+    g, sym, ringsw, zsw, d, tb, c, w = wk["g"], wk["sym"], wk["ringsw"], wk["zsw"], wk["d"], wk["tb"], wk["c"], wk["w"]
+    assert tab.shape[0] == blocks
+    # (1) unordered pairs of DIFFERENT whole super-blocks: each (resident block, traveler chunk) at most once, and for a != b
     #     either a sweeps all of b's chunks or b all of a's -- never both, never neither
     visits = np.zeros((nsb, nsb, cps), np.int32)
-    np.add.at(visits, (g[sym], tb[sym], c[sym]), 1)
-    assert visits.max() == 1
+    np.add.at(visits, (g[ringsw], tb[ringsw], c[ringsw]), 1)
+    assert visits.max() <= 1
     per_pair = visits.sum(axis=2)
     assert np.all(np.diag(per_pair) == 0)
     both = per_pair + per_pair.T
     off = ~np.eye(nsb, dtype=bool)
     assert np.all(both[off] == cps) and np.all((per_pair[off] == 0) | (per_pair[off] == cps))
-    # (2) pairs INSIDE a super-block: its own chunks once each, resident-only
-    own = np.zeros((nsb, cps), np.int32)
+    # (1z) the short block Z: EVERY whole super-block sweeps each of its zc real chunks exactly once, from both sides
+    zv = np.zeros((nsb, max(zc, 1)), np.int32)
+    np.add.at(zv, (g[zsw], c[zsw]), 1)
+    assert zsw.sum() == nsb * zc and (zc == 0 or np.all(zv == 1)) and np.all(tb[zsw] == nsb)
+    # (2) pairs INSIDE a block: its own chunks once each (Z: its zc real ones), resident-only
+    own = np.zeros((blocks, cps), np.int32)
     np.add.at(own, (g[~sym], c[~sym]), 1)
-    assert np.all(own == 1) and np.all(tb[~sym] == g[~sym])
+    assert np.all(own[:nsb] == 1) and np.all(tb[~sym] == g[~sym])
+    if zc:
+        assert np.all(own[nsb, :zc] == 1) and np.all(own[nsb, zc:] == 0)
     # (3) ring distances stay inside the traveler layers
-    assert np.all(d[sym] < H + (g[sym] < n_hi)) and pl["t_layer0"] + H + (1 if n_hi else 0) == q["sym_layers"]
+    assert np.all(d[ringsw] < H + (g[ringsw] < n_hi)) and pl["t_layer0"] + H + (1 if n_hi else 0) == q["sym_layers"]
     # (4) resident layers.  The waves whose range ENDS in b's list add their sums up per workgroup of four (LDS) and write layer
     #     r_layer0 + w // 4 - first // 4; the last wave of the list, if its range goes on into b + 1, writes its part to b's last
     #     layer.  The table = {first wave, layer count}: every layer K2 reads is written exactly once
     gu = np.repeat(g, wk["ups"])
     starts = wk["starts"]
-    for b in range(nsb):
+    for b in range(blocks):
         units = np.nonzero(gu == b)[0]
         ws = np.unique(wk["wu"][units])
         assert ws[0] == tab[b, 0] and ws[-1] - ws[0] + 1 == len(ws), b
@@ -127,10 +138,11 @@ def check_whole_plan(q, n):
             written.append(int(tab[b, 1]) - 1)
         assert written == list(range(int(tab[b, 1]))), (b, written, tab[b])
     assert pl["r_layer0"] == 0 and tab[:, 1].max() == pl["t_layer0"] == q["jsplit"]
-    # (5) traveler layers: K2 (nb_integrate_symw) reads layers t_layer0 + [0, H + (n_hi and b >= n_hi)) of every row of b --
-    #     exactly the set written, once each (a chunk of padding rows only is skipped by K1 and never read by K2)
+    # (5) traveler layers: K2 (nb_integrate_symw) reads layers t_layer0 + [0, H + (n_hi and b >= n_hi)) of every row of a whole
+    #     super-block b -- exactly the set written, once each; for the rows of Z it reads the z-rows g * zc + c of all g instead:
+    #     written once each by (1z)
     tl = np.zeros((nsb, cps, H + 1), np.int32)
-    np.add.at(tl, (tb[sym], c[sym], d[sym]), 1)
+    np.add.at(tl, (tb[ringsw], c[ringsw], d[ringsw]), 1)
     for b in range(nsb):
         nt = H + (1 if (n_hi and b >= n_hi) else 0)
         assert np.all(tl[b, :, :nt] == 1) and np.all(tl[b, :, nt:] == 0), b
@@ -388,7 +400,7 @@ def test_shard_own_splits_lie_inside_the_shard(n, g):
 
 def test_model_choice_table():
     """The automatic choice at the sizes DESIGN.md quotes (256 CUs, 2.4 GHz): a change of the cost model shows up here."""
-    want = {1024: "f32pk_fused_regs1024", 9000: "f32pk_fused_jpairs", 11000: "f32pk_symw_ipl8_j1_w1024_r14t11", 13000: "f32pk_symw_ipl8_j1_w2048_r23t13_u8", 16384: "f32pk_symw_ipl16_j1_w1024_r19t8_u8", 20000: "f32pk_symw_ipl16_j1_w2048_r30t10_u8", 40002: "f32pk_symw_ipl16_j1_w2048_r16t20_u8",
+    want = {1024: "f32pk_fused_regs1024", 9000: "f32pk_fused_jpairs", 11000: "f32pk_symw_ipl8_j1_w1024_r14t10", 16384: "f32pk_symw_ipl16_j1_w1024_r19t8_u8", 20000: "f32pk_symw_ipl16_j1_w2048_r29t9_u8", 40002: "f32pk_symw_ipl16_j1_w2048_r15t19_u8",
             65536: "f32pk_symw_ipl16_j1_w2048", 262144: "f32pk_symw_ipl16_j1_w2048_r4t128", 1048576: "f32pk_symw_ipl16_j1_w2048"}
     for n, prefix in want.items():
         assert capi.plan_query(n)["variant"].startswith(prefix), (n, capi.plan_query(n)["variant"])
