@@ -49,6 +49,45 @@ def test_single_step_matches_the_fp64_oracle(variant, jsplit, n):
     assert rel_pos_err(bb, b2, 1.0) < 1e-6, name
 
 
+# A ragged N leaves a SHORT block behind the whole super-blocks of the ring: every super-block sweeps its real chunks (the traveler sums
+# go to z-rows of the spill buffer, which the integrate kernel adds for the short block's rows), it sweeps only its own.  One real row,
+# one real chunk, an almost full block (all cps chunks real), exactly one whole super-block + a short one; whole sweeps and eighths.
+@pytest.mark.parametrize("variant,jsplit,flags", [(716013, 0, 0), (716083, 2, 0), (708013, 0, capi.NB_FLAG_WHOLE_SWEEPS), (708083, 1, 0), (704043, 3, 0), (708081, 1, 0)])
+@pytest.mark.parametrize("n", [1025, 2047, 3 * 1024 + 64, 6143, 9 * 1024 + 65, 16 * 1024 + 1023])
+def test_the_short_block_of_a_ragged_n(variant, jsplit, flags, n):
+    S = 64 * (variant // 1000 % 100)
+    b, v = ic.plummer(n, seed=n)
+    bb, vv, aa, name = run(b, v, 1, force_variant=variant, jsplit=jsplit, flags=flags)
+    assert "symw" in name, name
+    q = capi.plan_query(n, force_variant=variant, jsplit=jsplit, flags=flags)
+    ch = 128 if variant % 10 == 1 else 64
+    assert q["plan"]["nsb"] == n // S and q["plan"]["zc"] == -(-(n % S) // ch) and q["plan"]["np"] == -(-n // S) * S
+    ref = oracle.accel_f64(b, 1.0)
+    assert np.abs(aa[:, :3] - ref[:, :3]).max() < TOL_ACC * np.abs(ref[:, :3]).max(), name
+    f = b[:, 3:4].astype(np.float64) * aa[:, :3].astype(np.float64)
+    assert np.all(np.abs(f.sum(0)) < 1e-6 * np.abs(f).sum(0)), name                      # every pair from both sides: the pair sums cancel
+    b2, v2, _ = oracle.run_f32(b, v, None, 1e-3, 1.0, 1)
+    assert rel_pos_err(bb, b2, 1.0) < 1e-6, name
+    again = run(b, v, 1, force_variant=variant, jsplit=jsplit, flags=flags)
+    assert again[2].tobytes() == aa.tobytes(), name                                         # deterministic
+
+
+@pytest.mark.parametrize("n", [40002, 5 * 512 + 1, 7 * 512 + 511])
+def test_the_short_block_in_f64_and_over_a_trajectory(n):
+    b, v = ic.plummer(n, seed=5)
+    with Simulation(n, precision="f64", force_variant=0 if n > 10000 else 708013) as s:
+        assert "f64_symw" in s.variant and capi.plan_query(n, precision="f64", force_variant=0 if n > 10000 else 708013)["plan"]["zc"] > 0
+        s.init(b, v)
+        s.simulate(1, 1e-3, 1.0)
+        acc = s.read(bodies=False, vel=False)[2]
+    ref = oracle.accel_f64(b, 1.0)
+    assert np.abs(acc[:, :3] - ref[:, :3]).max() < 1e-12 * np.abs(ref[:, :3]).max()
+    if n < 10000:
+        bb, vv, aa, name = run(b, v, 20, force_variant=708013)
+        b2, v2, _ = oracle.run_f32(b, v, None, 1e-3, 1.0, 20)
+        assert rel_pos_err(bb, b2, 1.0) < 2e-5, name
+
+
 # the wave ranges are cut in UNITS of a chunk-sweep (64 rotation steps): whole sweeps (NB_FLAG_WHOLE_SWEEPS, the ABI 2.0 form), or
 # half / quarter / eighth sweeps (LL = 02 / 04 / 08; LL = 01: the planner's choice, quarters at these sizes) -- a sweep shared by
 # two waves leaves its later part in the second wave's spill row, which the integrate kernel adds through the chunk's spill list
