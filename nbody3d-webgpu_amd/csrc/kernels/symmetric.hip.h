@@ -189,7 +189,7 @@ void nb_force_sym(const float4* __restrict__ bodies, SymRow* __restrict__ partia
 // struct SymWPlan: nb_plan.h
 
 template <int NG, int J>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG > 4 ? 2 : 4, NG > 4 ? 2 : (NG < 4 ? 8 : 4))))
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 4 ? 2 : 4, NG > 4 ? 2 : (NG < 4 ? 8 : 4))))
 void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ partial, const uint32_t* __restrict__ gtab, const SymWPlan pl,
                    const uint32_t n, const float eps2, SymRow* __restrict__ spill)
 {
@@ -265,57 +265,70 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             }
             // (the loop head is 32-byte aligned by -falign-loops=32: a packed instruction that straddles an 8-byte boundary issues
             // more slowly -- 12 % on this loop at one wave per SIMD, profiles/r04/README.md)
-            for (uint32_t st = s0; st < s1; ++st) {
+            // Two forms of the loop: a sweep over one of the super-block's OWN chunks needs no traveler sums (each of its pairs is met
+            // from both sides), so it drops the 4 packed instructions per group and the 6 rotations that keep them: 116 instead of
+            // 154 issue slots per step with 16 residents -- 0.88 of the time at one or two waves per SIMD (the planner counts 7/8).
+            auto steps = [&](auto both) {
+                constexpr bool BOTH = decltype(both)::value;
+                for (uint32_t st = s0; st < s1; ++st) {
 #pragma unroll
-                for (int uu = 0; uu < J; ++uu) {
-                    const nb_f2 px = nb_f2{tx[uu], tx[uu]}, py = nb_f2{ty[uu], ty[uu]}, pz = nb_f2{tz[uu], tz[uu]}, pm = nb_f2{tm[uu], tm[uu]};
+                    for (int uu = 0; uu < J; ++uu) {
+                        const nb_f2 px = nb_f2{tx[uu], tx[uu]}, py = nb_f2{ty[uu], ty[uu]}, pz = nb_f2{tz[uu], tz[uu]}, pm = nb_f2{tm[uu], tm[uu]};
 #pragma unroll
-                    for (int c0g = 0; c0g < NG; c0g += GW) {         // stage-major over groups of (up to) four
-                        nb_f2 dx[GW], dy[GW], dz[GW], d2[GW], r[GW], si[GW], sj[GW];
+                        for (int c0g = 0; c0g < NG; c0g += GW) {         // stage-major over groups of (up to) four
+                            nb_f2 dx[GW], dy[GW], dz[GW], d2[GW], r[GW], si[GW], sj[GW];
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) dx[c] = px - xi[c0g + c];                                   // :233
+                            for (int c = 0; c < GW; ++c) dx[c] = px - xi[c0g + c];                                   // :233
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) dy[c] = py - yi[c0g + c];
+                            for (int c = 0; c < GW; ++c) dy[c] = py - yi[c0g + c];
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) dz[c] = pz - zi[c0g + c];
+                            for (int c = 0; c < GW; ++c) dz[c] = pz - zi[c0g + c];
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
+                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) r[c] = d2[c] * d2[c];                                       // :235
+                            for (int c = 0; c < GW; ++c) r[c] = d2[c] * d2[c];                                       // :235
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) r[c] = r[c] * d2[c];
+                            for (int c = 0; c < GW; ++c) r[c] = r[c] * d2[c];
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
+                            for (int c = 0; c < GW; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
+                            for (int c = 0; c < GW; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
+                            if constexpr (BOTH) {
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) sj[c] = mi[c0g + c] * r[c];       // (G m_i) inv: traveler side
+                                for (int c = 0; c < GW; ++c) sj[c] = mi[c0g + c] * r[c];   // (G m_i) inv: traveler side
+                            }
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
+                            for (int c = 0; c < GW; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
+                            for (int c = 0; c < GW; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
+                            for (int c = 0; c < GW; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
+                            if constexpr (BOTH) {
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) bx[uu] = __builtin_elementwise_fma(-sj[c], dx[c], bx[uu]);   // x_i - x_t = -(x_t - x_i), exactly
+                                for (int c = 0; c < GW; ++c) bx[uu] = __builtin_elementwise_fma(-sj[c], dx[c], bx[uu]);   // x_i - x_t = -(x_t - x_i), exactly
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) by[uu] = __builtin_elementwise_fma(-sj[c], dy[c], by[uu]);
+                                for (int c = 0; c < GW; ++c) by[uu] = __builtin_elementwise_fma(-sj[c], dy[c], by[uu]);
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) bz[uu] = __builtin_elementwise_fma(-sj[c], dz[c], bz[uu]);
+                                for (int c = 0; c < GW; ++c) bz[uu] = __builtin_elementwise_fma(-sj[c], dz[c], bz[uu]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int uu = 0; uu < J; ++uu) {                     // the travelers and their sums move on by one lane
+                        tx[uu] = wave_rot1(tx[uu]); ty[uu] = wave_rot1(ty[uu]); tz[uu] = wave_rot1(tz[uu]); tm[uu] = wave_rot1(tm[uu]);
+                        if constexpr (BOTH) {
+                            bx[uu] = nb_f2{wave_rot1(bx[uu].x), wave_rot1(bx[uu].y)};
+                            by[uu] = nb_f2{wave_rot1(by[uu].x), wave_rot1(by[uu].y)};
+                            bz[uu] = nb_f2{wave_rot1(bz[uu].x), wave_rot1(bz[uu].y)};
+                        }
                     }
                 }
-#pragma unroll
-                for (int uu = 0; uu < J; ++uu) {                     // the travelers and their sums move on by one lane
-                    tx[uu] = wave_rot1(tx[uu]); ty[uu] = wave_rot1(ty[uu]); tz[uu] = wave_rot1(tz[uu]); tm[uu] = wave_rot1(tm[uu]);
-                    bx[uu] = nb_f2{wave_rot1(bx[uu].x), wave_rot1(bx[uu].y)};
-                    by[uu] = nb_f2{wave_rot1(by[uu].x), wave_rot1(by[uu].y)};
-                    bz[uu] = nb_f2{wave_rot1(bz[uu].x), wave_rot1(bz[uu].y)};
-                }
-            }
+            };
+            if (sym) steps(std::true_type{}); else steps(std::false_type{});
             if (sym) {
                 // the sums of steps [s0, s1) sit s1 lanes past their travelers' home lanes.  The part that starts the sweep owns the
                 // sweep's traveler layer; any later part goes to the wave's own spill row (K2 adds it: the spill rows of a chunk are consecutive)
@@ -429,37 +442,44 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
             ++k;
             const double4 t = ld4(bodies + tstart + (((uint32_t)lane - s0) & 63u));
             double tx = t.x, ty = t.y, tz = t.z, tm = t.w * G, bx = 0, by = 0, bz = 0;
-            for (uint32_t st = s0; st < s1; ++st) {
+            auto steps = [&](auto both) {                                // see nb_force_symw: a sweep over an own chunk keeps no traveler sums
+                constexpr bool BOTH = decltype(both)::value;
+                for (uint32_t st = s0; st < s1; ++st) {
 #pragma unroll
-                for (int c0g = 0; c0g < IPL; c0g += GW) {            // stage-major over four residents
-                    double dx[GW], dy[GW], dz[GW], d2[GW], y[GW], uu[GW];
+                    for (int c0g = 0; c0g < IPL; c0g += GW) {            // stage-major over four residents
+                        double dx[GW], dy[GW], dz[GW], d2[GW], y[GW], uu[GW];
 #pragma unroll
-                    for (int c = 0; c < GW; ++c) dx[c] = tx - xi[c0g + c];
+                        for (int c = 0; c < GW; ++c) dx[c] = tx - xi[c0g + c];
 #pragma unroll
-                    for (int c = 0; c < GW; ++c) dy[c] = ty - yi[c0g + c];
+                        for (int c = 0; c < GW; ++c) dy[c] = ty - yi[c0g + c];
 #pragma unroll
-                    for (int c = 0; c < GW; ++c) dz[c] = tz - zi[c0g + c];
+                        for (int c = 0; c < GW; ++c) dz[c] = tz - zi[c0g + c];
 #pragma unroll
-                    for (int c = 0; c < GW; ++c) d2[c] = nb_fma(dz[c], dz[c], nb_fma(dy[c], dy[c], nb_fma(dx[c], dx[c], eps2)));
+                        for (int c = 0; c < GW; ++c) d2[c] = nb_fma(dz[c], dz[c], nb_fma(dy[c], dy[c], nb_fma(dx[c], dx[c], eps2)));
 #pragma unroll
-                    for (int c = 0; c < GW; ++c) y[c] = __builtin_amdgcn_rsq(d2[c]);
+                        for (int c = 0; c < GW; ++c) y[c] = __builtin_amdgcn_rsq(d2[c]);
 #pragma unroll
-                    for (int c = 0; c < GW; ++c) {
-                        const double y2 = y[c] * y[c];
-                        const double e = nb_fma(-d2[c], y2, 1.0);
-                        const double t3 = y[c] * y2;
-                        uu[c] = nb_fma(t3 * e, 1.5, t3);
+                        for (int c = 0; c < GW; ++c) {
+                            const double y2 = y[c] * y[c];
+                            const double e = nb_fma(-d2[c], y2, 1.0);
+                            const double t3 = y[c] * y2;
+                            uu[c] = nb_fma(t3 * e, 1.5, t3);
+                        }
+#pragma unroll
+                        for (int c = 0; c < GW; ++c) {
+                            const double si = tm * uu[c];
+                            ax[c0g + c] = nb_fma(si, dx[c], ax[c0g + c]); ay[c0g + c] = nb_fma(si, dy[c], ay[c0g + c]); az[c0g + c] = nb_fma(si, dz[c], az[c0g + c]);
+                            if constexpr (BOTH) {
+                                const double sj = mi[c0g + c] * uu[c];
+                                bx = nb_fma(-sj, dx[c], bx); by = nb_fma(-sj, dy[c], by); bz = nb_fma(-sj, dz[c], bz);
+                            }
+                        }
                     }
-#pragma unroll
-                    for (int c = 0; c < GW; ++c) {
-                        const double si = tm * uu[c], sj = mi[c0g + c] * uu[c];
-                        ax[c0g + c] = nb_fma(si, dx[c], ax[c0g + c]); ay[c0g + c] = nb_fma(si, dy[c], ay[c0g + c]); az[c0g + c] = nb_fma(si, dz[c], az[c0g + c]);
-                        bx = nb_fma(-sj, dx[c], bx); by = nb_fma(-sj, dy[c], by); bz = nb_fma(-sj, dz[c], bz);
-                    }
+                    tx = wave_rot1(tx); ty = wave_rot1(ty); tz = wave_rot1(tz); tm = wave_rot1(tm);
+                    if constexpr (BOTH) { bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz); }
                 }
-                tx = wave_rot1(tx); ty = wave_rot1(ty); tz = wave_rot1(tz); tm = wave_rot1(tm);
-                bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz);
-            }
+            };
+            if (sym) steps(std::true_type{}); else steps(std::false_type{});
             if (sym) {
                 SymRowT<double>* out = (s0 != 0 ? spill + (size_t)slot * CH : zsweep ? spill + (size_t)zrow * CH : partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart)
                                        + (((uint32_t)lane - s1) & 63u);

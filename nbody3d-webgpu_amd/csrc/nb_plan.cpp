@@ -192,7 +192,7 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         const uint32_t nsb = n / S, zc = ceil_div(n % S, 64u);
         const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
         const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps + zc, total_lo = (uint64_t)(H + 1) * cps + zc;
-        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo + zc;
+        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo + zc - ((uint64_t)nsb * cps + zc) / 8u;      // (a sweep over an own chunk counts 7/8)
         // f64: 92 issue cycles per resident and step + 14 DPP; the loop runs at 96 % of that (N = 262,144: 23.7 ms, profiles/r03/sym_f64_first.txt)
         const double t_chunk = f64 ? 64.0 * (92.0 * ipl + 56.0) / 0.96 / clock : 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.95 : 0.935) / clock;
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
@@ -274,9 +274,30 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, c
         both = false;
         return g * S + (k - ring - zc) * CH;                                                // an own chunk
     };
-    // The wave ranges: equal in units (every sweep of these lists is real work; the starts are a table so that a later cost model can weight them)
+    // The wave ranges: equal in WORK.  A sweep over an own chunk runs the loop without traveler sums and takes 7/8 of another (measured 0.88
+    // at one and two waves per SIMD: profiles/r04/README.md); a block's list is [both-sides sweeps at 8][own chunks at 7].
+    struct Run { uint64_t at; uint32_t len, cost; };
+    std::vector<Run> runs;
+    for (uint32_t g = 0; g < blocks; ++g) {
+        const uint32_t total = total_of(g), own = g < nsb ? cps : zc;
+        if (total > own) runs.push_back({offset_of(g), total - own, 8u});
+        runs.push_back({(uint64_t)offset_of(g) + total - own, own, 7u});
+    }
+    uint64_t Cu = 0;
+    for (const Run& r : runs) Cu += (uint64_t)r.len * ups * r.cost;
+    if ((uint64_t)W * 8u > Cu) { W = (uint32_t)(Cu / 8u); pl.W = W; }       // a wave's share is at least the dearest unit
     std::vector<uint32_t> starts((size_t)W + 1);
-    for (uint32_t w = 0; w <= W; ++w) starts[w] = (uint32_t)((uint64_t)w * Lu / W);
+    {
+        size_t q = 0;                                          // the run the wave's first unit lies in
+        uint64_t before = 0;                                   // cost of the runs before it
+        for (uint32_t w = 0; w < W; ++w) {
+            const uint64_t target = (uint64_t)w * Cu / W;      // cost before the wave
+            while (q + 1 < runs.size() && before + (uint64_t)runs[q].len * ups * runs[q].cost <= target) { before += (uint64_t)runs[q].len * ups * runs[q].cost; ++q; }
+            starts[w] = (uint32_t)(runs[q].at * ups + (target - before) / runs[q].cost);
+        }
+        starts[0] = 0;
+        starts[W] = (uint32_t)Lu;
+    }
     auto start_of = [&](uint32_t w) { return (uint64_t)starts[w]; };
     auto wave_of = [&](uint64_t u) { return (uint32_t)(std::upper_bound(starts.begin(), starts.begin() + W, (uint32_t)u) - starts.begin()) - 1u; };
     const uint32_t nch = pl.np / CH, zrows = nsb * zc;

@@ -195,7 +195,7 @@ def test_no_packed_multiply_reads_a_reciprocal_square_root_issued_right_before_i
 
 
 def test_symmetric_pass_rotation_loop_is_the_pair_arithmetic_and_the_rotation_only():
-    """The 64-step rotation loop of the symmetric force pass must carry exactly: per packed group of residents 16 packed
+    """The rotation loops of the symmetric force pass must carry exactly: per packed group of residents 16 packed
     instructions + 2 v_rsq_f32 (f64: 19 double-precision instructions + v_rsq_f64 per resident), 10 (f64: 14) v_mov_b32_dpp
     wave_ror:1 per traveler and step -- and nothing else: no scratch access (a second loop in the same kernel once made the
     register allocator spill INTO this loop), no v_mov_b32 copies, no LDS traffic.  The measured issue rate (4.41 cycles per VALU
@@ -215,8 +215,9 @@ def test_symmetric_pass_rotation_loop_is_the_pair_arithmetic_and_the_rotation_on
             m = re.match(r"s_cbranch_\w+\s+(\S+)", l)
             if m and m.group(1) in labels and labels[m.group(1)] < i:
                 loops.append(lines[labels[m.group(1)]:i + 1])
-        rot = sorted((lp for lp in loops if any(o.startswith("v_mov_b32_dpp") for o in lp)), key=len)
-        return rot[:1]          # the rotation loop itself: the shortest loop that rotates
+        rot = [lp for lp in loops if any(o.startswith("v_mov_b32_dpp") for o in lp)]
+        # the rotation loops themselves: the loops that rotate and hold no other loop that does
+        return sorted((lp for lp in rot if not any(o is not lp and len(o) < len(lp) and o[0] in lp for o in rot)), key=len)
 
     seen = 0
     # (mangled prefix, residents' packed groups NG or residents IPL, travelers J, f64)
@@ -226,18 +227,23 @@ def test_symmetric_pass_rotation_loop_is_the_pair_arithmetic_and_the_rotation_on
         m = re.search(r"^(%s\w*):.*?$(.*?)^\.Lfunc_end" % pat, text, re.S | re.M)      # to the end of the function: an s_endpgm may sit mid-body
         assert m, pat
         loops = innermost_loops(m.group(2))
-        assert len(loops) == 1, (pat, len(loops))
-        ops = [l.split()[0] for l in loops[0] if not l.endswith(":")]
-        valu = [o for o in ops if o.startswith("v_")]
-        assert not any(o.startswith("scratch_") or o.startswith("ds_") or o.startswith("global_") or o.startswith("buffer_") for o in ops), pat
-        per_step = (14 if f64 else 10) * j
-        u = ops.count("v_mov_b32_dpp") // per_step            # rotation steps per loop iteration (hipcc unrolls the short 4-resident body by 2)
-        assert u >= 1 and ops.count("v_mov_b32_dpp") == per_step * u, (pat, ops.count("v_mov_b32_dpp"))
-        if f64:
-            assert ops.count("v_rsq_f64_e32") == ng * u and len(valu) == (ng * 20 + 14) * u, (pat, len(valu))
-        else:
-            assert ops.count("v_rsq_f32_e64") == 2 * ng * j * u and sum(o.startswith("v_pk_") for o in valu) == 16 * ng * j * u, pat
-            assert len(valu) == (18 * ng + 10) * j * u, (pat, len(valu))
+        # the wave-granular kernels have two forms of the loop: a sweep over an OWN chunk keeps no traveler sums (12 packed + 2 v_rsq
+        # per group, 4 rotations; f64: 16 + v_rsq_f64 per resident, 8 rotations); the workgroup form has the one
+        two_forms = "symw" in pat
+        assert len(loops) == (2 if two_forms else 1), (pat, len(loops))
+        for both, lp in zip((False, True) if two_forms else (True,), loops):
+            ops = [l.split()[0] for l in lp if not l.endswith(":")]
+            valu = [o for o in ops if o.startswith("v_")]
+            assert not any(o.startswith("scratch_") or o.startswith("ds_") or o.startswith("global_") or o.startswith("buffer_") for o in ops), pat
+            per_step = ((14 if both else 8) if f64 else (10 if both else 4)) * j
+            u = ops.count("v_mov_b32_dpp") // per_step            # rotation steps per loop iteration (hipcc unrolls the short 4-resident body by 2)
+            assert u >= 1 and ops.count("v_mov_b32_dpp") == per_step * u, (pat, both, ops.count("v_mov_b32_dpp"))
+            if f64:
+                assert ops.count("v_rsq_f64_e32") == ng * u and len(valu) == (ng * (20 if both else 16) + per_step) * u, (pat, both, len(valu))
+            else:
+                pk = 16 if both else 12
+                assert ops.count("v_rsq_f32_e64") == 2 * ng * j * u and sum(o.startswith("v_pk_") for o in valu) == pk * ng * j * u, (pat, both)
+                assert len(valu) == ((pk + 2) * ng + per_step // j) * j * u, (pat, both, len(valu))
         seen += 1
     assert seen == 6
 
