@@ -275,13 +275,14 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, c
         return g * S + (k - ring - zc) * CH;                                                // an own chunk
     };
     // The wave ranges: equal in WORK.  A sweep over an own chunk runs the loop without traveler sums and takes 7/8 of another (measured 0.88
-    // at one and two waves per SIMD: profiles/r04/README.md); a block's list is [both-sides sweeps at 8][own chunks at 7].
+    // at one and two waves per SIMD: profiles/r04/README.md); a block's list is [both-sides sweeps at 8][own chunks at 7] when the ranges
+    // are cut inside sweeps.
     struct Run { uint64_t at; uint32_t len, cost; };
     std::vector<Run> runs;
     for (uint32_t g = 0; g < blocks; ++g) {
         const uint32_t total = total_of(g), own = g < nsb ? cps : zc;
         if (total > own) runs.push_back({offset_of(g), total - own, 8u});
-        runs.push_back({(uint64_t)offset_of(g) + total - own, own, 7u});
+        runs.push_back({(uint64_t)offset_of(g) + total - own, own, ups > 1 ? 7u : 8u});      // whole sweeps cannot be cut finer than the difference: even cut
     }
     uint64_t Cu = 0;
     for (const Run& r : runs) Cu += (uint64_t)r.len * ups * r.cost;

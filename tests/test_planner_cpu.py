@@ -55,7 +55,7 @@ def walk_symw(q, n):
     Lu = L * ups
     starts = q["starts"].astype(np.int64)
     assert len(starts) == W + 1 and starts[0] == 0 and starts[-1] == Lu and W <= Lu and np.diff(starts).min() >= 1
-    work = np.repeat(np.where(sym, 8, 7).astype(np.int64), ups)                                  # per unit
+    work = np.repeat(np.where(sym, 8, 7 if ups > 1 else 8).astype(np.int64), ups)              # per unit (whole sweeps: an even cut)
     per_wave = np.add.reduceat(work, starts[:-1])
     assert per_wave.sum() == work.sum() and per_wave.max() - per_wave.min() <= 16, (per_wave.min(), per_wave.max())
     wu = np.searchsorted(starts, np.arange(Lu, dtype=np.int64), side="right") - 1               # the wave of every unit
