@@ -147,7 +147,7 @@ const void* kernel_of(bool f64, const Shape& sh)
             if (sh.ls != 1) return nullptr;
             if (f64) return sh.ipl == 8 && sh.x == 3 ? (const void*)&nb::nb_force_symw64<8> : nullptr;      // 8 residents, 1 traveler per lane
             if (sh.x == 4) return sh.ipl == 8 ? (const void*)&nb::nb_force_sym<4, 4, 2> : nullptr;
-            if (sh.ipl == 4) return sh.x == 3 ? (const void*)&nb::nb_force_symw<2, 1> : nullptr;      // finer chunk-sweeps for N ~ 14k-18k
+            if (sh.ipl == 4) return sh.x == 3 ? (const void*)&nb::nb_force_symw<2, 1> : nullptr;      // (an arm: whole sweeps round finer with 4 residents)
             if (sh.ipl == 8) return sh.x == 1 ? (const void*)&nb::nb_force_symw<4, 2> : sh.x == 3 ? (const void*)&nb::nb_force_symw<4, 1> : nullptr;
             if (sh.ipl == 16) return sh.x == 1 ? (const void*)&nb::nb_force_symw<8, 2> : sh.x == 3 ? (const void*)&nb::nb_force_symw<8, 1> : nullptr;
             return nullptr;
@@ -652,15 +652,22 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
     const int n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     const double clock_hz = prop.clockRate > 0 ? 1e3 * prop.clockRate : 2.4e9;     // clockRate is in kHz
     plan_handle(s, cfg, n_cu, clock_hz, (double)prop.totalGlobalMem);
-    if (s->sym && !s->sym_rank && !cfg.force_variant) {
+    if (s->sym && (!s->sym_rank || s->sym_local) && !cfg.force_variant) {
         // The planner budgets the symmetric pass's layers against the device's TOTAL memory; what is FREE right now may be less
-        // (other handles, other processes).  A whole-system handle then takes the ordered-pair kernels instead of failing in
+        // (other handles, other processes).  A whole-system handle then re-plans against the free memory instead of failing in
         // hipMalloc.  (A rank-form shard does not: its peers would still expect the reduce-scatter -- it fails loudly below.)
         size_t free_b = 0, total_b = 0;
-        const double need = 3.0 * s->esz * (double)sym_layer_rows(s) * s->sym_layers + 12.0 * s->esz * s->sym_np;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need > 0.9 * (double)free_b) {
-            cfg.flags |= NB_FLAG_NO_SYM;
-            plan_handle(s, cfg, n_cu, clock_hz, (double)prop.totalGlobalMem);
+        auto need = [&]() { return 3.0 * s->esz * (double)sym_layer_rows(s) * s->sym_layers + 12.0 * s->esz * s->sym_np; };
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && need() > 0.9 * (double)free_b) {
+            // first with a layer budget of what IS free: the ring distances then go in passes that reuse the layers (still every
+            // unordered pair once); only if even that does not fit, the ordered-pair kernels
+            nb_config fit = cfg;
+            fit.layer_budget_mib = (uint32_t)std::max(1.0, 0.6 * (double)free_b / 1048576.0);
+            plan_handle(s, fit, n_cu, clock_hz, (double)prop.totalGlobalMem);
+            if (s->sym && need() > 0.9 * (double)free_b) {
+                cfg.flags |= NB_FLAG_NO_SYM;
+                plan_handle(s, cfg, n_cu, clock_hz, (double)prop.totalGlobalMem);
+            }
         }
     }
     if (!kernel_of(s->f64, shape_of(s))) return bail(NB_ERR_INVALID, "nb_create: no kernel for shape " + s->variant);

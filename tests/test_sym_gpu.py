@@ -262,14 +262,16 @@ def test_handles_that_cannot_use_the_symmetric_pass_fall_back():
         assert "sgpr" in s.variant, s.variant
 
 
-def test_layers_that_do_not_fit_the_free_memory_fall_back_to_ordered_pairs():
+def test_layers_that_do_not_fit_the_free_memory_go_in_passes():
     """The planner budgets against the device's total memory; nb_create checks what is free: N = 7,000,000 with the budget
-    lifted plans 288 GB of layers -- more than the card has -- and the handle takes the ordered-pair kernels instead of
-    failing in hipMalloc."""
+    lifted plans 288 GB of layers in one pass -- more than the card has -- and the handle re-plans against the free memory: the ring
+    distances in passes that reuse the layers (still the symmetric pass), not a failure in hipMalloc and not the ordered-pair kernels.
+    (When not even one distance per pass fits, the planner itself falls back: layer_budget_mib=4 above.)"""
     n, budget = 7000000, 400000
-    assert capi.plan_query(n, layer_budget_mib=budget)["sym"] == 1
+    q = capi.plan_query(n, layer_budget_mib=budget)
+    assert q["sym"] == 1 and q["passes"] <= 1
     with Simulation(n, layer_budget_mib=budget) as s:
-        assert "sgpr" in s.variant, s.variant
+        assert "symwrank" in s.variant and "_p" in s.variant, s.variant
 
 
 def test_two_million_bodies_take_the_symmetric_pass():
