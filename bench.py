@@ -270,7 +270,7 @@ def sampled_rows_check(bodies64, accel, rows, G, tol):
 def also_measurements(Simulation, ic, device):
     """Secondary measurements appended to the default 1-GPU headline line (same process, same gates): the other
     single-GPU BASELINE configs and the reference's own default workload, each with its own sampled-row check
-    against an fp64 direct sum.  ~2.5 s of GPU time in all; the headline fields are computed before this runs.
+    against an fp64 direct sum.  ~3 s of GPU time in all; the headline fields are computed before this runs.
 
       config 2   N=65,536 uniform cube, fp32: the default shape, and the "LDS tile=256" kernel BASELINE names (variant 28)
       config 5   N=262,144 Plummer, fp64
@@ -278,6 +278,7 @@ def also_measurements(Simulation, ic, device):
       default    the reference's UI defaults (index.html:68-74, nbody3d.js:62-64,163-177): 2 galaxies x 20,000 + 2 = N 40,002,
                  G = dt = 1e-4, central masses 1e7 -- built by js/ic.js::galaxies under Node, digest-checked against the
                  reference generator's own output (tests/golden/galaxy40002_params.json)
+      UI range   N=13,000 / 16,384 / 20,000 Plummer spheres, fp32: mid sizes of the reference's UI range
     """
     out = []
 
@@ -355,6 +356,11 @@ def also_measurements(Simulation, ic, device):
         # not failed; a digest mismatch or a failed check does fail the line
         skipped = "node is not installed" in str(e)
         out.append({"workload": "reference default: N=40002 galaxies", "skipped" if skipped else "error": str(e), "pass": skipped, "frac": None})
+    # the reference's UI range below its default (index.html:68-74: 1,001 .. 500,010 bodies): three mid sizes where the fixed cost of a
+    # step (launch ramp, K1 -> K2 boundary, K2) weighs most -- Plummer spheres, the headline's dt and G
+    for un in (13000, 16384, 20000):
+        ub, uv = ic.plummer(un, seed=1)
+        run("reference UI range: N=%d Plummer sphere, fp32" % un, ub, uv, 1e-3, 1.0, "f32", 0, 600, 1600, 48)
     return out
 
 
