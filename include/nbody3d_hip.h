@@ -313,7 +313,9 @@ int nb_step_times2(nb_sim *s, nb_step_timing *out);
  * force sums are whatever the last force pass left; first zeroed if none ran) and returns
  * the average launch time: the memory-bound kernel measured on its own at sizes where a
  * full O(N^2) step would take minutes (N >= 4M: state no longer cache-resident).  The
- * particle state is garbage afterwards -- measurement only; not available on a fused handle. */
+ * particle state is garbage afterwards -- measurement only; not available on a fused handle.
+ * A rank-form handle (NB_FLAG_SYM_SHARD shard, or a whole system whose ring distances go in passes) runs what its step runs:
+ * the plain integrate kernel on its rows of the reduced sums. */
 int nb_integrate_pass(nb_sim *s, uint32_t reps, double *avg_ms);
 /* Runs ONLY the force pass `reps` times back to back on the positions as they stand and returns the average time per pass
  * (a rank-form handle: both phases of the force kernel + nb_sym_reduce).  The state is left untouched (the pass writes partial

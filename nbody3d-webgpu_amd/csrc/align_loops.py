@@ -14,7 +14,8 @@ are read off the backward branches, and an `s_nop 0` (32 bits, one issue slot of
 64-bit instruction of a loop that would start at 4 mod 8.  The result is assembled, linked and bundled by the Makefile exactly as
 hipcc would have done with its own output (clang -cc1as / lld / clang-offload-bundler / -fcuda-include-gpubinary).  Inserting a
 no-op only lengthens the distance between instructions: no hazard can appear that was not there, and branch offsets are
-labels.  Functions with fp64 arithmetic in their loops are left as hipcc wrote them (they alternate 32- and 64-bit encodings:
+labels; the one place where a distance is hard-coded -- the +4 / +12 addends of an `s_getpc_b64` ... `sym@rel32@lo+4` /
+`sym@rel32@hi+12` sequence -- is never split (nothing is inserted between the s_getpc_b64 and the @rel32@hi instruction).  Functions with fp64 arithmetic in their loops are left as hipcc wrote them (they alternate 32- and 64-bit encodings:
 there the no-ops cost more than they save, measured), and so is any function that would need a no-op per 12 loop instructions.  tests/test_isa_guard.py checks the built library:
 no misaligned 64-bit instruction in any loop of the packed-f32 force kernels.
 """
@@ -93,6 +94,7 @@ def process(src_lines, dis):
         # loops: backward branches of the disassembly, as ranges of body lines
         addr_to_k = {a: kk for kk, (a, _, _, _) in enumerate(d)}
         in_loop = set()
+        loops = []                                       # (first body line, last body line) of every loop
         for kk, (a, size, op, off) in enumerate(d):
             if off is None or off < 32768 or kk not in dis_index:
                 continue
@@ -103,12 +105,20 @@ def process(src_lines, dis):
             if hk is None or hk not in dis_index:
                 continue
             in_loop.update(range(dis_index[hk], dis_index[kk] + 1))
+            loops.append((dis_index[hk], dis_index[kk]))
+        # the innermost loops (those that contain no other): where a no-op is paid for on every trip
+        innermost = set()
+        for lo, hi in loops:
+            if not any((l2, h2) != (lo, hi) and lo <= l2 and h2 <= hi for l2, h2 in loops):
+                innermost.update(range(lo, hi + 1))
         out.append(src_lines[i])
         # dry run first: a no-op costs an issue slot.  Left as hipcc wrote them: functions with fp64 arithmetic in their loops (they
         # alternate 32-bit v_fmac_f64_e32 / v_rsq_f64_e32 with 64-bit VOP3 instructions: aligned by no-ops nb_force_symw64 ran 3.4 %
         # SLOWER, profiles/r04/README.md) and functions that would need a no-op per DENSITY_LIMIT loop instructions or more
-        def walk(emit):
+        def walk(emit, inner_only=False):
             parity, inserted, wide = 0, 0, 0
+            pc_rel = False          # between an s_getpc_b64 and the last instruction of its sym@rel32 sequence: the +4 / +12 addends are
+                                    # distances from the s_getpc_b64 -- a no-op put in between would silently move the computed address
             for li, ln in enumerate(body):
                 pa = re.match(r"\.p2align\s+(\d+)", ln.strip())
                 if pa:
@@ -116,21 +126,35 @@ def process(src_lines, dis):
                         parity = 0
                 elif li in size_of:
                     sz = size_of[li]
-                    if li in in_loop and sz == 8:
+                    code = ln.split(";")[0]
+                    if pc_rel and "@rel32@hi" in code:
+                        closes = True
+                    else:
+                        closes = False
+                    if li in in_loop and sz == 8 and not pc_rel:
                         wide += 1
                         if parity == 4:
                             if emit is not None:
                                 emit.append("\ts_nop 0                                  ; align_loops.py: the next 64-bit instruction on an 8-byte boundary\n")
                             parity = 0
-                            inserted += 1
+                            inserted += 1 if (not inner_only or li in innermost) else 0
                     parity = (parity + sz) % 8
+                    if code.split()[0] == "s_getpc_b64":
+                        pc_rel = True
+                    elif closes:
+                        pc_rel = False
                 if emit is not None:
                     emit.append(ln)
             return inserted, wide
         need, wide_in_loops = walk(None)
         loop_instr = sum(1 for li in in_loop if li in size_of)
         fp64 = any("_f64" in body[li].split(";")[0].split()[0] for li in in_loop if li in size_of)
-        if need and (fp64 or need * DENSITY_LIMIT > loop_instr):
+        # The density test counts a function's INNERMOST loops when the whole function fails it: a cold block of an outer loop (the
+        # LDS flush of nb_force_symw's resident sums: 96 ds_read / ds_write among 32-bit adds, run once per 4,096 rotation steps) must
+        # not leave the rotation loops next to it unaligned.
+        inner_need, _ = walk(None, inner_only=True)
+        inner_instr = sum(1 for li in innermost if li in size_of)
+        if need and (fp64 or (need * DENSITY_LIMIT > loop_instr and inner_need * DENSITY_LIMIT > inner_instr)):
             out.extend(body)
             report.append((name, len(in_loop), wide_in_loops, 0, need))
             i = j

@@ -32,6 +32,9 @@ template <typename T> struct SymRowT { T x, y, z; };   // a partial row: 12 byte
 using SymRow = SymRowT<float>;
 // struct SymPlan: nb_plan.h (the host's planner fills it)
 
+// rotation steps after which the register sums of the residents move on to their second level (nb_force_symw, nb_force_symw_rank)
+constexpr uint32_t kFlushSteps = 4096;
+
 __device__ __forceinline__ float wave_rot1(float v)
 {
     const int iv = __builtin_bit_cast(int, v);      // old = src: every lane is written, no init move
@@ -240,6 +243,15 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
                 ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
             }
         }
+        // Two-level resident sums: a wave that stays with one super-block for thousands of sweeps (N = 2,000,000: one wave per
+        // super-block, 15,632 sweeps = 1,000,448 terms per resident) would add terms of ~a / N to a running sum of ~a in ONE
+        // binary32 register -- the stagnation that puts the reference's own ascending-j loop at 1e-5 .. 5e-4 there
+        // (tests/golden/large_n_row_spread.json; this pass sat at 2e-5).  Every kFlushSteps rotation steps the register sums
+        // move on to a second level kept in the wave's own part of `red` (LDS: 48 reads, adds and writes per 4,096 steps), so
+        // no accumulator takes more than 4,096 * J terms in sequence.  A range that never gets that far (every N below ~400,000
+        // on 256 CUs) never touches LDS here and adds exactly what it added before.
+        uint32_t since = 0;
+        bool flushed = false;
         while (u < ug_end) {
             // the wave's steps [s0, s1) of sweep k
             const uint32_t q0 = u % ups;
@@ -247,6 +259,23 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             if (nun > ug_end - u) nun = ug_end - u;
             const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
             u += nun;
+            if (since >= kFlushSteps) {
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    const nb_f2 a3[3] = {ax[c], ay[c], az[c]};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        float* hi0 = &red[wi][6 * c + q][lane];
+                        float* hi1 = &red[wi][6 * c + 3 + q][lane];
+                        *hi0 = flushed ? *hi0 + a3[q].x : a3[q].x;
+                        *hi1 = flushed ? *hi1 + a3[q].y : a3[q].y;
+                    }
+                    ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
+                }
+                flushed = true;
+                since = 0;
+            }
+            since += s1 - s0;
             const bool sym = k < both_end, zsweep = k >= ring && sym;
             const uint32_t d = k / CPS;                              // ring distance - 1 (ring sweeps)
             uint32_t tb = g + 1 + d;
@@ -343,6 +372,10 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             gfin = g;
 #pragma unroll
             for (int c = 0; c < NG; ++c) {
+                if (flushed) {         // second level + what the registers hold
+                    ax[c].x += red[wi][6 * c + 0][lane]; ay[c].x += red[wi][6 * c + 1][lane]; az[c].x += red[wi][6 * c + 2][lane];
+                    ax[c].y += red[wi][6 * c + 3][lane]; ay[c].y += red[wi][6 * c + 4][lane]; az[c].y += red[wi][6 * c + 5][lane];
+                }
                 red[wi][6 * c + 0][lane] = ax[c].x; red[wi][6 * c + 1][lane] = ay[c].x; red[wi][6 * c + 2][lane] = az[c].x;
                 red[wi][6 * c + 3][lane] = ax[c].y; red[wi][6 * c + 4][lane] = ay[c].y; red[wi][6 * c + 5][lane] = az[c].y;
             }
@@ -353,6 +386,10 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
         SymRow* out = partial + (size_t)(pl.r_layer0 + gtab[2 * g + 1] - 1u) * pl.np + (size_t)g * S + lane;
 #pragma unroll
         for (int c = 0; c < NG; ++c) {
+            if (flushed) {
+                ax[c].x += red[wi][6 * c + 0][lane]; ay[c].x += red[wi][6 * c + 1][lane]; az[c].x += red[wi][6 * c + 2][lane];
+                ax[c].y += red[wi][6 * c + 3][lane]; ay[c].y += red[wi][6 * c + 4][lane]; az[c].y += red[wi][6 * c + 5][lane];
+            }
             out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
             out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
         }
@@ -555,6 +592,8 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
     uint32_t u = (uint32_t)(((uint64_t)wl * Lu) / Wp);
     const uint32_t uend = (uint32_t)(((uint64_t)(wl + 1) * Lu) / Wp);
     const nb_f2 e2 = nb_f2{eps2, eps2};
+    __shared__ float hi[4][6 * NG][64];          // second level of the resident sums (see nb_force_symw): a whole system in passes keeps a wave
+    const int wi = threadIdx.x >> 6;             // on one super-block for ~16,000 sweeps (N = 4,194,304)
     while (u < uend) {
         const uint32_t ps = u / ups;
         const uint32_t gi = rank_find(prefix, ng, ps), g = pl.g0 + gi;
@@ -580,6 +619,8 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
                 ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
             }
         }
+        uint32_t since = 0;
+        bool flushed = false;
         while (u < ug_end) {
             const uint32_t q0 = u % ups;                             // the wave's steps [s0, s1) of this sweep
             uint32_t nun = ups - q0;
@@ -594,6 +635,23 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
             if (tb >= pl.nsb) tb -= pl.nsb;
             const uint32_t tstart = sym ? tb * S + (k % CPS) * 64u : g * S + (k - ring) * 64u;
             if (tstart >= n) continue;
+            if (since >= kFlushSteps) {                              // register sums -> second level (LDS), as nb_force_symw
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    const nb_f2 a3[3] = {ax[c], ay[c], az[c]};
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        float* hi0 = &hi[wi][6 * c + q][lane];
+                        float* hi1 = &hi[wi][6 * c + 3 + q][lane];
+                        *hi0 = flushed ? *hi0 + a3[q].x : a3[q].x;
+                        *hi1 = flushed ? *hi1 + a3[q].y : a3[q].y;
+                    }
+                    ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
+                }
+                flushed = true;
+                since = 0;
+            }
+            since += s1 - s0;
             const float4 t = ld4(bodies + tstart + (((uint32_t)lane - s0) & 63u));
             float tx = t.x, ty = t.y, tz = t.z, tm = t.w;
             nb_f2 bx = nb_f2{0, 0}, by = nb_f2{0, 0}, bz = nb_f2{0, 0};
@@ -652,6 +710,10 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
         SymRow* out = partial + (size_t)(phase_b ? pl.rb_layer0 + (wl - gt[2]) : pl.r_layer0 + (wl - gt[0])) * lstride + (size_t)gi * S + lane;
 #pragma unroll
         for (int c = 0; c < NG; ++c) {
+            if (flushed) {
+                ax[c].x += hi[wi][6 * c + 0][lane]; ay[c].x += hi[wi][6 * c + 1][lane]; az[c].x += hi[wi][6 * c + 2][lane];
+                ax[c].y += hi[wi][6 * c + 3][lane]; ay[c].y += hi[wi][6 * c + 4][lane]; az[c].y += hi[wi][6 * c + 5][lane];
+            }
             out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
             out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
         }

@@ -368,6 +368,19 @@ void launch_integrate(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullpt
     T dt = (T)s->dt, G = (T)s->G;
     // the j-stream rows of the new positions; a handle whose rows are exchanged rebuilds the whole copy after the gather instead
     V4* gout = gm_active(s) && !(s->xfn || s->rccl) ? (V4*)s->gm[s->cur] : nullptr;
+    if (s->sym_rank) {
+        // A rank-form handle (a shard, or a whole system whose ring distances go in passes) has no layered integrate: its sums
+        // are reduced into sym_A by nb_sym_reduce and the PLAIN integrate kernel reads the handle's rows of it (sym_rank_phase_b_t).
+        // lay_out_symw_rank also sets `symw` (its SymWPlan is a summary for the reports): without this branch nb_integrate_symw would
+        // walk the rank table as {first wave, layers} pairs and stride compact layers by np -- reads far past `partial`.
+        V4* a = (V4*)s->acc;
+        const V4* p = (const V4*)s->sym_A + sb;
+        uint32_t one = 1;
+        V4* none = nullptr;                         // the (x, y, z, G*m) copy is rebuilt whole after the position all-gather
+        void* args[] = {&b, &v, &a, &p, &sb, &sc, &one, &dt, &none, &G};
+        launch_kernel((const void*)&nb::nb_integrate<T, 1>, dim3(ceil_div(sc, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
+        return;
+    }
     if (s->symw) {
         nb::SymWPlan pl;
         memcpy(&pl, s->sym_plan, sizeof pl);
@@ -508,17 +521,20 @@ namespace nbi {
 // Rank form of the symmetric pass, first half of a step: the force pass over the chunk lists of the handle's own super-blocks,
 // then this rank's sums for every row of the system into sym_A.
 template <typename T>
-int sym_rank_phase_a_t(nb_sim* s, hipEvent_t after_force, bool split_at_gather)
+int sym_rank_phase_a_t(nb_sim* s, hipEvent_t after_force, bool split_at_gather, nb_events* stamps = nullptr)
 {
     using V4 = typename nb::vec4<T>::type;
     const uint32_t npass = (uint32_t)s->sym_passes.size();
     for (uint32_t q = 0; q < npass; ++q) {
         s->sym_pass = q;
         if (split_at_gather && q == 0) {
-            launch_force<T>(s, 1);                        // own-row travelers: needs nothing from the other ranks
+            if (s->sym_passes[0].plan[13] == 0 || s->sym_passes[0].plan[14] == 0) stamps = nullptr;      // (WA, WB: a phase without waves launches nothing to stamp)
+            // Two launches with the wait for the all-gather between them.  Timed steps stamp each launch at its own begin and end
+            // (hipExtLaunchKernel: e[0]..e[7] and e[3]..e[4]), so that the wait for the other ranks' rows is NOT counted as force time.
+            launch_force<T>(s, 1, stamps ? stamps->e[0] : nullptr, stamps ? stamps->e[7] : nullptr);     // own-row travelers: needs nothing from the other ranks
             if (int rc = finish_gather(s)) return rc;     // the engine stream waits for their rows here
-            launch_force<T>(s, 2);
-        } else {
+            launch_force<T>(s, 2, stamps ? stamps->e[3] : nullptr, stamps ? stamps->e[4] : nullptr);
+            if (stamps) { stamps->two = true; after_force = nullptr; }
             launch_force<T>(s);
         }
         if (after_force && q + 1 == npass) NB_HIP(s, hipEventRecord(after_force, s->stream));
@@ -539,24 +555,18 @@ int sym_rank_phase_a_t(nb_sim* s, hipEvent_t after_force, bool split_at_gather)
     return NB_OK;
 }
 
-int sym_rank_phase_a(nb_sim* s, void* after_force, bool split_at_gather)
+int sym_rank_phase_a(nb_sim* s, void* after_force, bool split_at_gather, nb_events* stamps)
 {
     if (!s->sym_rank) return fail(s, NB_ERR_STATE, "sym_rank_phase_a: not a rank-form handle");
     if (int rc = ensure_gm(s)) return rc;
-    return s->f64 ? sym_rank_phase_a_t<double>(s, (hipEvent_t)after_force, split_at_gather) : sym_rank_phase_a_t<float>(s, (hipEvent_t)after_force, split_at_gather);
+    return s->f64 ? sym_rank_phase_a_t<double>(s, (hipEvent_t)after_force, split_at_gather, stamps) : sym_rank_phase_a_t<float>(s, (hipEvent_t)after_force, split_at_gather, stamps);
 }
 
 template <typename T>
 int sym_rank_phase_b_t(nb_sim* s)
 {
-    using V4 = typename nb::vec4<T>::type;
-    V4 *b = (V4*)s->bodies[s->cur], *v = (V4*)s->vel, *a = (V4*)s->acc;
-    const V4* p = (const V4*)s->sym_A + s->sb;
-    uint32_t sb = s->sb, sc = s->sc, js = 1;
-    T dt = (T)s->dt, G = (T)s->G;
-    V4* gout = nullptr;                              // the (x, y, z, G*m) copy is rebuilt whole after the position all-gather
-    void* args[] = {&b, &v, &a, &p, &sb, &sc, &js, &dt, &gout, &G};
-    NB_HIP(s, hipLaunchKernel((const void*)&nb::nb_integrate<T, 1>, dim3(ceil_div(sc, nb::kBlock)), dim3(nb::kBlock), args, 0, s->stream));
+    launch_integrate<T>(s);                          // its rank-form branch: nb_integrate<T, 1> on the handle's rows of sym_A
+    NB_HIP(s, hipGetLastError());
     return NB_OK;
 }
 
@@ -843,8 +853,9 @@ int nb_step(nb_sim* s, uint32_t nsteps)
             if (!split) { if (int rc = finish_gather(s)) return rc; }
             nb_events evr;
             const bool recr = s->timing && get_events(s, &evr) == 0;
+            // one force launch: plain records around it; split at the gather: each launch stamped at its own begin / end (evr.two)
             if (recr) NB_HIP(s, hipEventRecord(evr.e[0], s->stream));
-            if (int rc = nbi::sym_rank_phase_a(s, recr ? evr.e[7] : nullptr, split)) return rc;
+            if (int rc = nbi::sym_rank_phase_a(s, recr ? evr.e[7] : nullptr, split, recr && split ? &evr : nullptr)) return rc;
             if (recr) { NB_HIP(s, hipEventRecord(evr.e[1], s->stream)); evr.rs = true; }
             if (!s->sym_local) { if (int rc = nbi::rccl_reduce_scatter_A(s)) return rc; }
             if (recr) NB_HIP(s, hipEventRecord(evr.e[6], s->stream));
@@ -979,9 +990,10 @@ static int collect_times(nb_sim* s, nb_step_timing* t)
     for (auto& ev : s->pending) {
         float a = 0, b = 0, c = 0, d = 0, r1 = 0, r2 = 0, sp = 0;
         if (ev.rs) {
-            // rank form: e0 force e7 nb_sym_reduce e1 reduce-scatter e6 integrate e2 [all-gather e5]
+            // rank form: e0 force e7 nb_sym_reduce e1 reduce-scatter e6 integrate e2 [all-gather e5]; with the force pass split at the
+            // gather: e0 own-row sweeps e7 [wait for the other ranks' rows] e3 the rest e4 nb_sym_reduce e1 ...
             NB_HIP(s, hipEventElapsedTime(&a, ev.e[0], ev.e[7]));
-            NB_HIP(s, hipEventElapsedTime(&r1, ev.e[7], ev.e[1]));
+            NB_HIP(s, hipEventElapsedTime(&r1, ev.two ? ev.e[4] : ev.e[7], ev.e[1]));
             NB_HIP(s, hipEventElapsedTime(&r2, ev.e[1], ev.e[6]));
             ++nrs;
         } else {
@@ -1049,7 +1061,10 @@ int nb_integrate_pass(nb_sim* s, uint32_t reps, double* avg_ms)
     const double dt = s->dt > 0 ? s->dt : 1e-3;
     const double keep = s->dt;
     s->dt = dt;
-    if (s->steps_done == 0) NB_HIP(s, hipMemsetAsync(s->partial, 0, s->sym ? (size_t)3 * s->esz * sym_layer_rows(s) * s->sym_layers : 4 * s->esz * s->sc * s->jsplit, s->stream));
+    if (s->steps_done == 0) {
+        NB_HIP(s, hipMemsetAsync(s->partial, 0, s->sym ? (size_t)3 * s->esz * sym_layer_rows(s) * s->sym_layers : 4 * s->esz * s->sc * s->jsplit, s->stream));
+        if (s->sym_rank) NB_HIP(s, hipMemsetAsync(s->sym_A, 0, 4 * s->esz * s->sym_np, s->stream));      // what a rank-form handle integrates from
+    }
     hipEvent_t e0, e1;
     NB_HIP(s, hipEventCreate(&e0));
     NB_HIP(s, hipEventCreate(&e1));

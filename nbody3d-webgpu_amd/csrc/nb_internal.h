@@ -153,7 +153,9 @@ int rccl_reduce_scatter_A(nb_sim* s);
 // the two halves of a rank-form step, for nb_multi (which runs its own reduce-scatter between them)
 // force pass [+ a record of the hipEvent_t `after_force`] + nb_sym_reduce.  split_at_gather: the sweeps whose travelers are the rank's
 // own rows are launched first, then the engine stream waits for the pending all-gather, then the rest (bit-identical to one launch)
-int sym_rank_phase_a(nb_sim* s, void* after_force = nullptr, bool split_at_gather = false);
+// `stamps` (timed steps, split_at_gather only): the two force launches are stamped at their own begin / end -- e[0]..e[7] and e[3]..e[4],
+// stamps->two set -- so the wait for the gather between them is not counted as kernel time
+int sym_rank_phase_a(nb_sim* s, void* after_force = nullptr, bool split_at_gather = false, nb_events* stamps = nullptr);
 int sym_rank_phase_b(nb_sim* s);     // integrate kernel on the handle's rows of sym_A
 int rccl_exchange_wait(nb_sim* s);
 bool rccl_overlapped(const nb_sim* s);

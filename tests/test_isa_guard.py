@@ -267,3 +267,44 @@ def test_no_64_bit_instruction_of_a_loop_straddles_an_8_byte_boundary():
     assert sum(r[3] for r in hot) > 10000                                   # 64-bit instructions looked at
     bad = [(r[0][:60], hex(r[1]), r[4], r[3]) for r in hot if r[4]]
     assert not bad, bad[:5]
+
+
+def test_align_loops_never_splits_a_pc_relative_address_sequence(tmp_path):
+    """csrc/align_loops.py puts an s_nop in front of a misaligned 64-bit instruction of a loop.  The addends of an
+    `s_getpc_b64` / `s_add_u32 ..., sym@rel32@lo+4` / `s_addc_u32 ..., sym@rel32@hi+12` sequence are distances from the
+    s_getpc_b64: a no-op inside the sequence would move the computed address with no diagnostic.  Today's device code has no such
+    sequence inside a loop; this feeds the tool a loop that does and wants the three instructions left adjacent -- and the
+    misaligned 64-bit instruction AFTER the sequence still aligned."""
+    if not os.path.exists("/opt/rocm/lib/llvm/bin/clang"):
+        pytest.skip("needs the ROCm assembler")
+    src = tmp_path / "in.s"
+    src.write_text("""\t.text
+\t.amdgcn_target "amdgcn-amd-amdhsa--gfx950"
+\t.globl\tf
+\t.p2align\t8
+\t.type\tf,@function
+f:
+\ts_mov_b32 s0, 0
+.LBB0_1:
+\ts_add_u32 s0, s0, 1
+\ts_getpc_b64 s[4:5]
+\ts_add_u32 s4, s4, tbl@rel32@lo+4
+\ts_addc_u32 s5, s5, tbl@rel32@hi+12
+\tv_pk_add_f32 v[0:1], v[0:1], v[2:3]
+""" + "\ts_add_u32 s1, s1, 1\n" * 12 + """\ts_cmp_lt_u32 s0, 16
+\ts_cbranch_scc1 .LBB0_1
+\ts_endpgm
+.Lfunc_end0:
+\t.size\tf, .Lfunc_end0-f
+\t.type\ttbl,@object
+\t.data
+tbl:
+\t.long 0
+""")
+    dst = tmp_path / "out.s"
+    subprocess.check_call(["python3", os.path.join(CSRC, "align_loops.py"), str(src), str(dst)])
+    ops = [l.split(";")[0].split()[0] for l in dst.read_text().splitlines() if l.startswith("\t") and not l.strip().startswith(".")]
+    i = ops.index("s_getpc_b64")
+    assert ops[i:i + 3] == ["s_getpc_b64", "s_add_u32", "s_addc_u32"], ops
+    # s_mov (4) | head: s_add (4) s_getpc (4) s_add+literal (8) s_addc+literal (8) -> the packed add would start at 4 mod 8: one no-op, after the sequence
+    assert ops[i + 3] == "s_nop" and ops[i + 4] == "v_pk_add_f32" and ops.count("s_nop") == 1, ops

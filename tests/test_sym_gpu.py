@@ -7,6 +7,9 @@ cube and the reciprocal square root are shared, the per-pair products (G m_j) in
 padding rows, odd and even super-block counts, the workgroup form), the golden trajectories, exact momentum conservation
 of the pair sums, determinism (graph replay, restarts, repeated runs), G != 1, and that the default shape picks it.
 """
+import json
+import os
+
 import numpy as np
 import pytest
 
@@ -274,6 +277,33 @@ def test_layers_that_do_not_fit_the_free_memory_go_in_passes():
         assert "symwrank" in s.variant and "_p" in s.variant, s.variant
 
 
+def check_sampled_rows(b, acc, n, rows):
+    """Sampled rows of a multi-million-body step against an fp64 direct sum.  A row is a sum of millions of binary32 terms and its
+    error is all summation ORDER (tests/golden/large_n_row_spread.json, made by measure_large_n_row_spread.py: the terms themselves
+    5e-9, a pairwise fp32 sum 2e-7, the reference's own ascending-j loop -- the fp32 oracle -- 6e-6 .. 5.5e-4 on these very rows).
+    The engine is held, row by row, to max(2e-5, 2 x the fp32 oracle's error on that row): never looser than twice what the
+    reference's arithmetic achieves, and to the usual 2e-5 where the oracle happens to be lucky.  (Round 4 asserted a flat 5e-5 after
+    row 1 of the 2 M system came out at 2.05e-5: a resident's sums were ONE register taking a million terms in sequence; they have
+    two levels now -- kFlushSteps, kernels/symmetric.hip.h -- and the rows sit an order of magnitude inside 2e-5.)"""
+    spread = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "large_n_row_spread.json")))
+    case = [c for c in spread["cases"] if c["n"] == n][0]
+    x = b[:, :3].astype(np.float64)
+    m = b[:, 3].astype(np.float64)
+    worst = 0.0
+    for i in rows:
+        d = x - x[i]
+        r2 = (d * d).sum(1) + 1e-4
+        want = (m[:, None] * d / (r2 * np.sqrt(r2))[:, None]).sum(0)
+        rec = case["rows"][str(i)]
+        assert np.allclose(want, rec["a_f64"], rtol=1e-12, atol=0), "the fixture was made for other initial conditions"
+        err = np.abs(acc[i, :3] - want).max() / np.abs(want).max()
+        worst = max(worst, err)
+        assert err <= max(2e-5, 2.0 * rec["oracle_f32_err"]), (i, err, rec["oracle_f32_err"])
+    print("N=%d sampled rows: worst engine error %.3g (fp32 oracle on the same rows: %.3g .. %.3g)" % (
+        n, worst, min(r["oracle_f32_err"] for r in case["rows"].values()), max(r["oracle_f32_err"] for r in case["rows"].values())))
+    return worst
+
+
 def test_two_million_bodies_take_the_symmetric_pass():
     """Layers beyond the old fixed 16 GB budget (N = 2,000,000: 23.6 GB of partial sums; the default budget is a third of the
     device memory): one step, sampled rows against an fp64 direct sum, momentum of the pair sums."""
@@ -284,15 +314,8 @@ def test_two_million_bodies_take_the_symmetric_pass():
         s.init(b, v)
         s.simulate(1, 1e-3, 1.0)
         acc = s.read(bodies=False, vel=False)[2]
-    x = b[:, :3].astype(np.float64)
+    check_sampled_rows(b, acc, n, (0, 1, 999999, 1234567, n - 1))
     m = b[:, 3].astype(np.float64)
-    for i in (0, 1, 999999, 1234567, n - 1):
-        d = x - x[i]
-        r2 = (d * d).sum(1) + 1e-4
-        want = (m[:, None] * d / (r2 * np.sqrt(r2))[:, None]).sum(0)
-        # (two million f32 terms per row: the order of the partial sums moves the result by ~2e-5 of the largest component -- row 1
-        # sat at 1.9e-5 with one cut of the wave ranges and at 2.05e-5 with another; BASELINE's own bound is 1e-4 on positions)
-        assert np.abs(acc[i, :3] - want).max() <= 5e-5 * np.abs(want).max(), i
     f = m[:, None] * acc[:, :3].astype(np.float64)
     assert np.all(np.abs(f.sum(0)) < 1e-6 * np.abs(f).sum(0))
 
@@ -324,6 +347,41 @@ def test_layer_budget_passes_match_the_oracle_and_the_single_pass(n, precision, 
         assert np.isfinite(ke) and np.isfinite(pe)
 
 
+def test_integrate_pass_on_rank_form_handles_runs_their_plain_integrate_kernel():
+    """nb_integrate_pass on a rank-form handle -- a whole system whose ring distances go in passes (layer_budget_mib) and an
+    NB_FLAG_SYM_SHARD shard -- must run what those handles' steps run (nb_integrate<T, 1> on their rows of sym_A), not the layered
+    nb_integrate_symw: lay_out_symw_rank sets `symw` for its report summary, and that kernel would read the 4-words-per-block rank
+    table as {first wave, layers} pairs and stride COMPACT layers by np -- tens of GB past `partial` at N = 4 M (round 4's advisor
+    finding; reachable through the public entry point).  Here: no fault, a plausible time, and the kernel really integrates -- a
+    pass with dt > 0 over zero sums moves x by dt * v."""
+    n = 100000
+    b, v = ic.plummer(n, seed=96)
+    with Simulation(n, layer_budget_mib=48) as sim:
+        assert "symwrank" in sim.variant and "_p" in sim.variant, sim.variant
+        sim.init(b, v)
+        sim.set_params(1e-3, 1.0)
+        ms = sim.integrate_pass(3)                       # before any step: sums zeroed, 1 warm-up + 3 timed launches
+        assert 0 < ms < 1.0, ms
+        bb, vv, aa = sim.read()
+        want = b.astype(np.float64)[:, :3] + 4 * 1e-3 * v.astype(np.float64)[:, :3]
+        assert np.abs(bb[:, :3] - want).max() < 1e-5 and np.all(aa[:, :3] == 0), sim.variant
+    n, rows = 65536, 8192
+    b, v = ic.plummer(n, seed=97)
+    for r in (0, 3, 7):
+        with Simulation(n, shard=(r * rows, rows), flags=capi.NB_FLAG_SYM_SHARD) as sim:
+            assert "symwrank" in sim.variant, sim.variant
+            sim.init(b, v)
+            sim.set_params(1e-3, 1.0)
+            ms = sim.integrate_pass(3)
+            assert 0 < ms < 1.0, (r, ms)
+            bb = sim.read(vel=False, accel=False)[0]
+            own = slice(r * rows, (r + 1) * rows)
+            want = b.astype(np.float64)[own, :3] + 4 * 1e-3 * v.astype(np.float64)[own, :3]
+            assert np.abs(bb[own, :3] - want).max() < 1e-5, r
+            other = np.ones(n, bool); other[own] = False
+            assert bb[other].tobytes() == b[other].tobytes(), r        # nothing outside the shard's rows is written
+
+
 def test_four_million_bodies_keep_the_symmetric_pass():
     """N = 4,194,304: one pass would need 103 GB of traveler layers (a third of the device memory is the default budget), so the
     ring distances go in two passes over 49 GB of layers -- every unordered pair still evaluated once.  One step, sampled rows against
@@ -335,13 +393,8 @@ def test_four_million_bodies_keep_the_symmetric_pass():
         s.init(b, v)
         s.simulate(1, 1e-3, 1.0)
         acc = s.read(bodies=False, vel=False)[2]
-    x = b[:, :3].astype(np.float64)
+    check_sampled_rows(b, acc, n, (0, 1, 2097151, 3456789, n - 1))
     m = b[:, 3].astype(np.float64)
-    for i in (0, 1, 2097151, 3456789, n - 1):
-        d = x - x[i]
-        r2 = (d * d).sum(1) + 1e-4
-        want = (m[:, None] * d / (r2 * np.sqrt(r2))[:, None]).sum(0)
-        assert np.abs(acc[i, :3] - want).max() <= 2e-5 * np.abs(want).max(), i
     f = m[:, None] * acc[:, :3].astype(np.float64)
     assert np.all(np.abs(f.sum(0)) < 1e-6 * np.abs(f).sum(0))
 
