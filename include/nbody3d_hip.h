@@ -37,7 +37,11 @@ extern "C" {
 #pragma GCC visibility push(default) /* the library is built -fvisibility=hidden */
 #endif
 
-#define NB_ABI_VERSION 2u
+#define NB_ABI_VERSION 2u /* major: a client and a library must agree on it (nb_abi_version) */
+#define NB_ABI_MINOR 3u   /* additions within major 2; a client needs nb_abi_minor() >= the minor it was written against:
+                             2.1 (round 3)  nb_force_pass, nb_frame_request / nb_frame_acquire, nb_shape_info, NB_FLAG_SYM_SHARD
+                             2.2 (round 4)  nb_step_times2, nb_plan_query, NB_FLAG_WHOLE_SWEEPS, nb_config.layer_budget_mib
+                             2.3 (round 5)  nb_abi_minor, NB_FLAG_FULL_OWN_SWEEPS; nb_plan_info / nb_plan_query moved to nbody3d_hip_plan.h */
 
 typedef struct nb_sim nb_sim; /* opaque */
 
@@ -85,6 +89,10 @@ typedef enum nb_precision { NB_F32 = 0, NB_F64 = 1 } nb_precision;
 #define NB_FLAG_WHOLE_SWEEPS 256u /* tuning/A-B: the symmetric pass cuts its wave ranges at whole chunk-sweeps (64 rotation steps), as in
                                    ABI 2.0; by default systems with few sweeps per wave cut them in quarter sweeps (variant suffix
                                    "_u4"), which evens out the SIMDs' work (N = 16,384: the longest SIMD runs 4.25 sweeps instead of 5) */
+
+#define NB_FLAG_FULL_OWN_SWEEPS 512u /* tuning/A-B: the symmetric pass sweeps a super-block's own chunks against every resident row,
+                                      resident-only (each pair inside a super-block from both sides, as in ABI 2.2); by default
+                                      the f32 pass evaluates those pairs once too (triangular own-chunk sweeps) */
 
 /* nb_array: selector for nb_device_ptr */
 typedef enum nb_array { NB_BODIES = 0, NB_VEL = 1, NB_ACCEL = 2 } nb_array;
@@ -149,6 +157,7 @@ typedef struct nb_config {
 
 /* Library / ABI version; callable with no device. */
 uint32_t nb_abi_version(void);
+uint32_t nb_abi_minor(void);   /* NB_ABI_MINOR of the library */
 
 /* Number of visible HIP devices (0 when there is none; never fails). */
 int nb_device_count(void);
@@ -335,51 +344,9 @@ const char *nb_variant_name(nb_sim *s);
 int nb_shape_info(nb_sim *s, uint32_t *jsplit, uint32_t *j_per_split, uint32_t *own_split0,
                   uint32_t *own_splits);
 
-/* The launch plan nb_create WOULD build for `cfg` on a device with n_cu compute units at clock_hz -- the engine's planner
- * (kernel form, j-partitions, the symmetric pass's super-block ring, its wave ranges and layer table) run on the host
- * alone.  No device is needed or touched: with n_cu > 0 and clock_hz > 0 the call works on a machine without a GPU (the
- * planner's occupancy queries then use their built-in defaults); n_cu <= 0 or clock_hz <= 0 means "as on cfg->device".
- * For reports, for sizing runs ahead of time, and for the host-side tests of the planner (tests/test_planner_cpu.py walks
- * the plan the way the kernels do and checks that every pair is covered exactly once).  No reference analogue: the
- * reference's dispatch is the one line ceil(N / 256) of nbody3d.js:478.
- *   kind/ipl/ls/x      the force_variant digits K, II, LL, X of the chosen form
- *   jsplit..own_splits as nb_shape_info
- *   sym*               symmetric pass only: padded rows, partial-sum layers, the rank form's super-block range, and the
- *                      plan words the kernels receive (nb::SymWPlan: np, nsb, W, total_hi, total_lo, n_hi, H, r_layer0,
- *                      t_layer0, L, zc -- nsb: the whole super-blocks of the ring, zc: the real chunks of the short block a ragged
- *                      N leaves behind them; workgroup form nb::SymPlan: np, nsb, q, total_hi, total_lo, n_hi, H, r_layer0, t_layer0)
- *   tab                (caller's array of tab_cap words, may be NULL) first wave and resident layer count of every super-block's
- *                      list (a layer per workgroup of four waves ending there, one more if the last wave goes on), 2 words per
- *                      block of rows (sym_np / rows per super-block: the short block last); the W + 1 wave starts (first unit of every wave's range: equal in work, a sweep over a chunk of
- *                      padding rows counts nothing); with sym_ups > 1 followed by the spill tables -- the spill row of every wave (W words), {first
- *                      spill row, count} per traveler chunk (2 * sym_np / 64 words), then the wave numbers in spill-row order;
- *                      tab_len reports how many words there are
- *   sym_ups            work units per chunk-sweep: the wave ranges are floor/ceil-equal in units of 64 / sym_ups rotation steps */
-typedef struct nb_plan_info {
-  uint32_t struct_size; /* sizeof(nb_plan_info), set by the caller */
-  uint32_t kind, ipl, ls, x;
-  uint32_t jsplit, j_per_split, own_split0, own_splits;
-  uint32_t sym, symw, sym_rank, sym_np, sym_layers, sym_g0, sym_g1;
-  uint32_t sym_plan[11];
-  uint32_t tab_len;
-  char variant[112];
-  uint32_t sym_ups;        /* wave-granular symmetric pass: work units per chunk-sweep (1: whole sweeps; 4: quarter sweeps) */
-  uint32_t sym_spill_rows; /* rows of the spill buffer: the z-rows (a super-block's sums for a chunk of the short block), then one row set per wave that starts inside a sweep */
-  uint32_t sym_rank_plan[16]; /* rank form (sym_rank): np, nsb, total_hi, total_lo, n_hi, H, r_layer0, rb_layer0, t_layer0, g0, g1, LA, LB,
-                                 WA, WB, ups -- phase A = the sweeps whose travelers are the rank's own rows (LA sweeps, waves [0, WA):
-                                 what an overlapped step issues before it waits for the all-gather), phase B the rest.  `tab` then
-                                 holds {first A wave, A waves, first B wave, B waves} per super-block (4 * nsb words), the two
-                                 phases' prefix tables (g1 - g0 + 1 words each) and, with ups > 1, the spill lists ({offset, count}
-                                 per 64-row chunk, then the wave numbers) */
-  uint32_t sym_pass;       /* IN/OUT: which pass of the rank-form pipeline sym_rank_plan and `tab` describe (set before the call; 0 when
-                              in doubt).  A whole system whose traveler layers would not fit the layer budget runs its ring distances
-                              in sym_passes passes that reuse the layers (variant suffix "_pN") */
-  uint32_t sym_passes;     /* passes of the rank-form pipeline (1 for an ordinary rank; 0 when the handle is not in the rank form) */
-  uint32_t sym_pass_k_lo, sym_pass_k_hi, sym_pass_d0; /* the pass's window of every super-block's ring sweeps [k_lo, k_hi) and its first ring distance */
-  uint32_t sym_local;      /* the rank-form pipeline of a WHOLE system on one device: no communicator, nothing exchanged */
-} nb_plan_info;
-int nb_plan_query(const nb_config *cfg, int n_cu, double clock_hz, nb_plan_info *out, uint32_t *tab,
-                  uint32_t tab_cap);
+/* Planner introspection (the launch plan nb_create WOULD build for a configuration, with the symmetric pass's kernel-internal
+ * plan words and tables: for reports, sizing runs and the host-side planner tests) lives in nbody3d_hip_plan.h -- nothing a host
+ * that replaces nbody3d.js:179-204,470-490 needs. */
 
 /* ---- viewer frame feed ------------------------------------------------
  * The reference's render pass reads bodyBuffer and velBuffer in place every frame

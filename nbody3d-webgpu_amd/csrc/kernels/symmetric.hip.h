@@ -35,6 +35,29 @@ using SymRow = SymRowT<float>;
 // rotation steps after which the register sums of the residents move on to their second level (nb_force_symw, nb_force_symw_rank)
 constexpr uint32_t kFlushSteps = 4096;
 
+// The register sums of a wave's residents move on to their second level `hi` (the wave's own [6 * NG][64] floats of LDS: rows 6c .. 6c+2
+// the x / y / z sums of resident 2c, rows 6c+3 .. 6c+5 of resident 2c+1) and start again from zero.  `flushed` (wave-uniform): the
+// second level already holds sums -- one branch around two straight-line forms.
+template <int NG>
+__device__ __forceinline__ void flush_resident_sums(float (*hi)[64], const int lane, const bool flushed, nb_f2 (&ax)[NG], nb_f2 (&ay)[NG], nb_f2 (&az)[NG])
+{
+    if (flushed) {
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+            hi[6 * c + 0][lane] += ax[c].x; hi[6 * c + 1][lane] += ay[c].x; hi[6 * c + 2][lane] += az[c].x;
+            hi[6 * c + 3][lane] += ax[c].y; hi[6 * c + 4][lane] += ay[c].y; hi[6 * c + 5][lane] += az[c].y;
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < NG; ++c) {
+            hi[6 * c + 0][lane] = ax[c].x; hi[6 * c + 1][lane] = ay[c].x; hi[6 * c + 2][lane] = az[c].x;
+            hi[6 * c + 3][lane] = ax[c].y; hi[6 * c + 4][lane] = ay[c].y; hi[6 * c + 5][lane] = az[c].y;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NG; ++c) { ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0}; }
+}
+
 __device__ __forceinline__ float wave_rot1(float v)
 {
     const int iv = __builtin_bit_cast(int, v);      // old = src: every lane is written, no init move
@@ -260,18 +283,7 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
             u += nun;
             if (since >= kFlushSteps) {
-#pragma unroll
-                for (int c = 0; c < NG; ++c) {
-                    const nb_f2 a3[3] = {ax[c], ay[c], az[c]};
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        float* hi0 = &red[wi][6 * c + q][lane];
-                        float* hi1 = &red[wi][6 * c + 3 + q][lane];
-                        *hi0 = flushed ? *hi0 + a3[q].x : a3[q].x;
-                        *hi1 = flushed ? *hi1 + a3[q].y : a3[q].y;
-                    }
-                    ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
-                }
+                flush_resident_sums<NG>(red[wi], lane, flushed, ax, ay, az);
                 flushed = true;
                 since = 0;
             }
@@ -282,7 +294,11 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             if (tb >= pl.nsb) tb -= pl.nsb;
             const uint32_t tstart = k < ring ? tb * S + (k % CPS) * CH : zsweep ? pl.nsb * S + (k - ring) * CH : g * S + (k - both_end) * CH;
             const uint32_t zrow = g * pl.zc + (k - ring);            // (z sweeps)
+            const uint32_t own_c = k - both_end;                     // (own-chunk sweeps: the chunk = the resident row)
             ++k;
+            // (Tried in round 5 and dropped: requesting the travelers of sweep k + 1 before the rotation steps of sweep k -- the wait
+            // moved behind the loop, in front of the stores.  0.3-1 % SLOWER from N = 10,000 to 65,536 at one and two waves per SIMD,
+            // profiles/r05/ab_traveler_prefetch_head_vs_tree.txt: this round trip is not what the short lists wait for.)
             float tx[J], ty[J], tz[J], tm[J];
             nb_f2 bx[J], by[J], bz[J];
             const uint32_t src = ((uint32_t)lane - s0) & 63u;        // the traveler this lane holds after s0 rotation steps
@@ -297,53 +313,68 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             // Two forms of the loop: a sweep over one of the super-block's OWN chunks needs no traveler sums (each of its pairs is met
             // from both sides), so it drops the 4 packed instructions per group and the 6 rotations that keep them: 116 instead of
             // 154 issue slots per step with 16 residents -- 0.88 of the time at one or two waves per SIMD (the planner counts 7/8).
-            auto steps = [&](auto both) {
+            // Third form (round 5; J = 1): the TRIANGULAR sweep over own chunk c = resident row c of the same super-block.  The pairs of
+            // rows (c, r) with r > c are evaluated ONCE, both sides, while chunk c travels (its sums fold into the accumulators of row c
+            // afterwards); rows r < c were done when chunk r traveled; row c itself meets its own chunk resident-only (both ordered
+            // pairs of two bodies of one chunk come by in 64 steps).  So the loop runs the packed groups [P0, NG), P0 = c / 2 -- one
+            // instantiation per P0, the registers stay statically indexed -- and in group P0 the halves that must not count are
+            // switched off through the mass factors: c odd: row 2 P0 is skipped (both sides), row c resident-only; c even: row c
+            // resident-only, row c + 1 both sides.  16 residents: 6,400 issue cycles per step for the 16 own chunks against 8,448.
+            auto steps = [&](auto both, auto first, const bool odd) {
                 constexpr bool BOTH = decltype(both)::value;
+                constexpr int P0 = decltype(first)::value;                // >= 0: triangular sweep from packed group P0; -1: every group
+                constexpr int G0 = P0 > 0 ? P0 : 0;
+                static_assert(P0 < 0 || (BOTH && J == 1), "the triangular sweep keeps traveler sums; one traveler per lane");
+                const nb_f2 pmask = odd ? nb_f2{0.f, 1.f} : nb_f2{1.f, 1.f};
+                const nb_f2 mi0 = odd ? nb_f2{0.f, 0.f} : nb_f2{0.f, mi[G0].y};
                 for (uint32_t st = s0; st < s1; ++st) {
 #pragma unroll
                     for (int uu = 0; uu < J; ++uu) {
                         const nb_f2 px = nb_f2{tx[uu], tx[uu]}, py = nb_f2{ty[uu], ty[uu]}, pz = nb_f2{tz[uu], tz[uu]}, pm = nb_f2{tm[uu], tm[uu]};
+                        const nb_f2 pm0 = P0 >= 0 ? pm * pmask : pm;     // traveler mass as group P0 sees it
 #pragma unroll
-                        for (int c0g = 0; c0g < NG; c0g += GW) {         // stage-major over groups of (up to) four
+                        for (int c0g = G0; c0g < NG; c0g += GW) {        // stage-major over groups of (up to) four
                             nb_f2 dx[GW], dy[GW], dz[GW], d2[GW], r[GW], si[GW], sj[GW];
+#define NB_GROUPS for (int c = 0; c < GW; ++c) if (c0g + c < NG)
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) dx[c] = px - xi[c0g + c];                                   // :233
+                            NB_GROUPS dx[c] = px - xi[c0g + c];                                   // :233
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) dy[c] = py - yi[c0g + c];
+                            NB_GROUPS dy[c] = py - yi[c0g + c];
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) dz[c] = pz - zi[c0g + c];
+                            NB_GROUPS dz[c] = pz - zi[c0g + c];
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
+                            NB_GROUPS d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+                            NB_GROUPS d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+                            NB_GROUPS d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) r[c] = d2[c] * d2[c];                                       // :235
+                            NB_GROUPS r[c] = d2[c] * d2[c];                                       // :235
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) r[c] = r[c] * d2[c];
+                            NB_GROUPS r[c] = r[c] * d2[c];
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
+                            NB_GROUPS r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
+                            NB_GROUPS si[c] = (P0 >= 0 && c0g + c == P0 ? pm0 : pm) * r[c];       // (G m_t) inv: resident side, :236
                             if constexpr (BOTH) {
 #pragma unroll
-                                for (int c = 0; c < GW; ++c) sj[c] = mi[c0g + c] * r[c];   // (G m_i) inv: traveler side
+                                NB_GROUPS sj[c] = (P0 >= 0 && c0g + c == P0 ? mi0 : mi[c0g + c]) * r[c];   // (G m_i) inv: traveler side
                             }
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
+                            NB_GROUPS ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
+                            NB_GROUPS ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
 #pragma unroll
-                            for (int c = 0; c < GW; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
+                            NB_GROUPS az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
                             if constexpr (BOTH) {
 #pragma unroll
-                                for (int c = 0; c < GW; ++c) bx[uu] = __builtin_elementwise_fma(-sj[c], dx[c], bx[uu]);   // x_i - x_t = -(x_t - x_i), exactly
+                                NB_GROUPS bx[uu] = __builtin_elementwise_fma(-sj[c], dx[c], bx[uu]);   // x_i - x_t = -(x_t - x_i), exactly
 #pragma unroll
-                                for (int c = 0; c < GW; ++c) by[uu] = __builtin_elementwise_fma(-sj[c], dy[c], by[uu]);
+                                NB_GROUPS by[uu] = __builtin_elementwise_fma(-sj[c], dy[c], by[uu]);
 #pragma unroll
-                                for (int c = 0; c < GW; ++c) bz[uu] = __builtin_elementwise_fma(-sj[c], dz[c], bz[uu]);
+                                NB_GROUPS bz[uu] = __builtin_elementwise_fma(-sj[c], dz[c], bz[uu]);
                             }
+#undef NB_GROUPS
                         }
                     }
 #pragma unroll
@@ -357,7 +388,34 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
                     }
                 }
             };
-            if (sym) steps(std::true_type{}); else steps(std::false_type{});
+            using none = std::integral_constant<int, -1>;
+            if (sym) steps(std::true_type{}, none{}, false);
+            else if (J == 1 && pl.tri && g < pl.nsb) {
+                // triangular sweep over own chunk `own_c`, then its traveler sums -- sums for row own_c of THIS super-block, whose
+                // accumulators this wave holds -- go home (64 - s1 more rotations: none for a whole sweep) and into those accumulators
+                if constexpr (J == 1) {
+                    const bool odd = own_c & 1u;
+                    switch (own_c >> 1) {
+#define NB_TRI(P) case P: if constexpr (P < NG) steps(std::true_type{}, std::integral_constant<int, P>{}, odd); break;
+                        NB_TRI(0) NB_TRI(1) NB_TRI(2) NB_TRI(3) NB_TRI(4) NB_TRI(5) NB_TRI(6) NB_TRI(7)
+#undef NB_TRI
+                        default: break;
+                    }
+                    for (uint32_t st = s1; st < 64u; ++st) {
+                        bx[0] = nb_f2{wave_rot1(bx[0].x), wave_rot1(bx[0].y)};
+                        by[0] = nb_f2{wave_rot1(by[0].x), wave_rot1(by[0].y)};
+                        bz[0] = nb_f2{wave_rot1(bz[0].x), wave_rot1(bz[0].y)};
+                    }
+                    const float fx = bx[0].x + bx[0].y, fy = by[0].x + by[0].y, fz = bz[0].x + bz[0].y;
+                    switch (own_c >> 1) {
+#define NB_FOLD(P) case P: if constexpr (P < NG) { if (odd) { ax[P].y += fx; ay[P].y += fy; az[P].y += fz; } else { ax[P].x += fx; ay[P].x += fy; az[P].x += fz; } } break;
+                        NB_FOLD(0) NB_FOLD(1) NB_FOLD(2) NB_FOLD(3) NB_FOLD(4) NB_FOLD(5) NB_FOLD(6) NB_FOLD(7)
+#undef NB_FOLD
+                        default: break;
+                    }
+                }
+            }
+            else steps(std::false_type{}, none{}, false);
             if (sym) {
                 // the sums of steps [s0, s1) sit s1 lanes past their travelers' home lanes.  The part that starts the sweep owns the
                 // sweep's traveler layer; any later part goes to the wave's own spill row (K2 adds it: the spill rows of a chunk are consecutive)
@@ -636,18 +694,7 @@ void nb_force_symw_rank(const float4* __restrict__ bodies, SymRow* __restrict__ 
             const uint32_t tstart = sym ? tb * S + (k % CPS) * 64u : g * S + (k - ring) * 64u;
             if (tstart >= n) continue;
             if (since >= kFlushSteps) {                              // register sums -> second level (LDS), as nb_force_symw
-#pragma unroll
-                for (int c = 0; c < NG; ++c) {
-                    const nb_f2 a3[3] = {ax[c], ay[c], az[c]};
-#pragma unroll
-                    for (int q = 0; q < 3; ++q) {
-                        float* hi0 = &hi[wi][6 * c + q][lane];
-                        float* hi1 = &hi[wi][6 * c + 3 + q][lane];
-                        *hi0 = flushed ? *hi0 + a3[q].x : a3[q].x;
-                        *hi1 = flushed ? *hi1 + a3[q].y : a3[q].y;
-                    }
-                    ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
-                }
+                flush_resident_sums<NG>(hi[wi], lane, flushed, ax, ay, az);
                 flushed = true;
                 since = 0;
             }

@@ -12,6 +12,7 @@
 //   partial : jsplit * 4*shard_count elements (K1 output, summed by K2; none when fused)
 #include "nb_internal.h"
 #include "nb_kernels.hip.h"
+#include "../../include/nbody3d_hip_plan.h"
 
 #include <hip/hip_ext.h>
 
@@ -535,6 +536,7 @@ int sym_rank_phase_a_t(nb_sim* s, hipEvent_t after_force, bool split_at_gather, 
             if (int rc = finish_gather(s)) return rc;     // the engine stream waits for their rows here
             launch_force<T>(s, 2, stamps ? stamps->e[3] : nullptr, stamps ? stamps->e[4] : nullptr);
             if (stamps) { stamps->two = true; after_force = nullptr; }
+        } else {
             launch_force<T>(s);
         }
         if (after_force && q + 1 == npass) NB_HIP(s, hipEventRecord(after_force, s->stream));
@@ -584,6 +586,7 @@ int sym_rank_phase_b(nb_sim* s)
 extern "C" {
 
 uint32_t nb_abi_version(void) { return NB_ABI_VERSION; }
+uint32_t nb_abi_minor(void) { return NB_ABI_MINOR; }
 
 int nb_device_count(void)
 {
@@ -1160,9 +1163,10 @@ int nb_plan_query(const nb_config* cfg_in, int n_cu, double clock_hz, nb_plan_in
     out->jsplit = tmp.jsplit; out->j_per_split = tmp.j_per_split; out->own_split0 = tmp.own_split0; out->own_splits = tmp.own_splits;
     out->sym = tmp.sym; out->symw = tmp.symw; out->sym_rank = tmp.sym_rank;
     out->sym_np = tmp.sym_np; out->sym_layers = tmp.sym_layers; out->sym_g0 = tmp.sym_g0; out->sym_g1 = tmp.sym_g1;
-    static_assert(sizeof(out->sym_plan) == sizeof(tmp.sym_plan) - sizeof(uint32_t), "nb_plan_info::sym_plan holds the first eleven words of nb_sim::sym_plan; the twelfth (ups) is sym_ups");
+    static_assert(sizeof(out->sym_plan) == 11 * sizeof(uint32_t) && sizeof(tmp.sym_plan) >= 13 * sizeof(uint32_t), "nb_plan_info::sym_plan holds the first eleven words of nb_sim::sym_plan; the twelfth (ups) is sym_ups, the thirteenth sym_tri");
     memcpy(out->sym_plan, tmp.sym_plan, sizeof out->sym_plan);
     out->sym_ups = tmp.symw ? tmp.sym_plan[11] : 0;
+    out->sym_tri = tmp.symw && !tmp.sym_rank ? tmp.sym_plan[12] : 0;
     out->sym_spill_rows = tmp.sym_spill_rows;
     static_assert(sizeof(out->sym_rank_plan) == sizeof(tmp.sym_rank_plan), "nb_plan_info::sym_rank_plan mirrors nb_sim::sym_rank_plan");
     memcpy(out->sym_rank_plan, tmp.sym_rank_plan, sizeof out->sym_rank_plan);

@@ -93,7 +93,7 @@ struct nb_sim {
     // bodies / gm are allocated with sym_np >= n rows (zero-mass padding); `partial` holds sym_layers x sym_np rows.
     bool sym = false;
     uint32_t sym_np = 0, sym_layers = 0;
-    uint32_t sym_plan[12] = {0};   // nb::SymPlan / nb::SymWPlan, kept as plain words here (nb_comm.hip does not see the kernels' types)
+    uint32_t sym_plan[16] = {0};   // nb::SymPlan / nb::SymWPlan, kept as plain words here (nb_comm.hip does not see the kernels' types)
     bool symw = false;             // wave-granular form (nb_force_symw): sym_plan holds a SymWPlan, sym_tab the per-super-block table
     uint32_t* sym_tab = nullptr;   // device: {first wave, resident layers} per super-block
     std::vector<uint32_t> sym_tab_host;

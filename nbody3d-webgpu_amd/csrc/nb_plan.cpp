@@ -119,6 +119,9 @@ struct ModelKnobs {
     double sustained = 0.958;  // share of hipDeviceProp_t::clockRate the chip holds under this kernel's load
                                // (2.24-2.29 of 2.4 GHz measured, profiles/r02/rocprof_f32_default: GRBM_GUI_ACTIVE)
     double jpk_lo = 7000, jpk_hi = 12500;   // sizes at which the j-packed step is scored at all (see plan_launch)
+    // the triangular own-chunk sweep (own_sweep_cost): issue cycles per packed group, surcharge per chain missing from four, cycles per
+    // step beside the groups (rotations, mask), and a floor (share of a both-sides sweep) under which no own sweep is counted
+    double tri_group = 80.0, tri_chain = 0.25, tri_fixed = 44.0, tri_floor = 0.0;
 };
 #ifdef NB_TUNING
 // calibration build: read on every nb_create, so that one process can walk a grid of constants (tools/fit_model.py)
@@ -130,6 +133,8 @@ ModelKnobs model_knobs()
     m.hand_over = knob("NB_MODEL_HANDOVER", m.hand_over); m.lanes_scale = knob("NB_MODEL_LANES_SCALE", m.lanes_scale);
     m.boundary = knob("NB_MODEL_BOUNDARY", m.boundary); m.sustained = knob("NB_MODEL_SUSTAINED", m.sustained);
     m.jpk_lo = knob("NB_MODEL_JPK_LO", m.jpk_lo); m.jpk_hi = knob("NB_MODEL_JPK_HI", m.jpk_hi);
+    m.tri_group = knob("NB_MODEL_TRI_GROUP", m.tri_group); m.tri_chain = knob("NB_MODEL_TRI_CHAIN", m.tri_chain);
+    m.tri_fixed = knob("NB_MODEL_TRI_FIXED", m.tri_fixed); m.tri_floor = knob("NB_MODEL_TRI_FLOOR", m.tri_floor);
     return m;
 }
 #else
@@ -178,7 +183,27 @@ uint32_t sym_units(uint64_t L, uint32_t W, bool whole_only)
     return L < (uint64_t)12 * W ? 8u : L < (uint64_t)48 * W ? 4u : 1u;      // eighths below a dozen sweeps per wave (N = 16,384: 57.2 vs 58.3 us)
 }
 
-SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64, double layer_budget, bool whole_only)
+// Work of one chunk-sweep on a scale where a sweep that keeps traveler sums (both sides) counts kSweepCost: what the wave ranges are
+// made equal in (lay_out_symw) and what sym_estimate sums up.
+//   * a sweep over an own chunk, resident-only against every row (f64, two travelers per lane, NB_FLAG_FULL_OWN_SWEEPS, the short
+//     block): 7/8 (measured 0.88 at one and two waves per SIMD, profiles/r04/README.md);
+//   * the TRIANGULAR sweep over own chunk c (nb_force_symw, one traveler per lane): packed groups c / 2 .. NG - 1 of the NG = ipl / 2,
+//     80 issue cycles each + 44 for the rotations and the mask, against NG * 80 + 40; with fewer than four groups the stage-major
+//     order has fewer than four independent chains and the loop waits on its own results (charged 25 % per missing chain).
+constexpr uint32_t kSweepCost = 64;
+uint32_t own_sweep_cost(int ipl, uint32_t c, bool tri)
+{
+    if (!tri) return kSweepCost * 7 / 8;
+    const ModelKnobs mk = model_knobs();
+    const double NG = ipl / 2.0, n = NG - (double)(c / 2);
+    const double chains = n < 4.0 ? 1.0 + mk.tri_chain * (4.0 - n) : 1.0;
+    const double cyc = n * mk.tri_group * chains + mk.tri_fixed;
+    const uint32_t cost = (uint32_t)std::lround(kSweepCost * std::max(mk.tri_floor, cyc / (NG * 80.0 + 40.0)));
+    return std::max(1u, std::min(cost, kSweepCost));
+}
+bool sym_triangular(bool f64, const Shape& sh, const nb_config& cfg) { return !f64 && sh.kind == kSym && sh.x == 3 && !(cfg.flags & NB_FLAG_FULL_OWN_SWEEPS); }
+
+SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64, double layer_budget, bool whole_only, bool tri)
 {
     SymChoice best{0, 0, 1, 1e300};
     for (int ipl : {4, 8, 16}) {
@@ -192,7 +217,10 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         const uint32_t nsb = n / S, zc = ceil_div(n % S, 64u);
         const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
         const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps + zc, total_lo = (uint64_t)(H + 1) * cps + zc;
-        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo + zc - ((uint64_t)nsb * cps + zc) / 8u;      // (a sweep over an own chunk counts 7/8)
+        // (sweeps over own chunks count their share of a both-sides sweep: own_sweep_cost)
+        uint64_t own_cost = 0;
+        for (uint32_t c = 0; c < cps; ++c) own_cost += own_sweep_cost(ipl, c, tri && !f64);
+        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo + zc - ((uint64_t)nsb * (cps * kSweepCost - own_cost) + (uint64_t)zc * (kSweepCost / 8)) / kSweepCost;
         // f64: 92 issue cycles per resident and step + 14 DPP; the loop runs at 96 % of that (N = 262,144: 23.7 ms, profiles/r03/sym_f64_first.txt)
         const double t_chunk = f64 ? 64.0 * (92.0 * ipl + 56.0) / 0.96 / clock : 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.95 : 0.935) / clock;
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
@@ -277,16 +305,22 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, c
     // The wave ranges: equal in WORK.  A sweep over an own chunk runs the loop without traveler sums and takes 7/8 of another (measured 0.88
     // at one and two waves per SIMD: profiles/r04/README.md); a block's list is [both-sides sweeps at 8][own chunks at 7] when the ranges
     // are cut inside sweeps.
+    const bool tri = J == 1 && sym_triangular(f64, sh, cfg);
+    pl.tri = tri ? 1u : 0u;
     struct Run { uint64_t at; uint32_t len, cost; };
     std::vector<Run> runs;
     for (uint32_t g = 0; g < blocks; ++g) {
         const uint32_t total = total_of(g), own = g < nsb ? cps : zc;
-        if (total > own) runs.push_back({offset_of(g), total - own, 8u});
-        runs.push_back({(uint64_t)offset_of(g) + total - own, own, ups > 1 ? 7u : 8u});      // whole sweeps cannot be cut finer than the difference: even cut
+        if (total > own) runs.push_back({offset_of(g), total - own, kSweepCost});
+        if (tri && g < nsb) {
+            for (uint32_t c = 0; c < own; ++c) runs.push_back({(uint64_t)offset_of(g) + total - own + c, 1u, own_sweep_cost(sh.ipl, c, true)});     // own chunk c: groups c / 2 .. NG - 1
+        } else {
+            runs.push_back({(uint64_t)offset_of(g) + total - own, own, ups > 1 ? own_sweep_cost(sh.ipl, 0, false) : kSweepCost});      // (whole sweeps: an even cut, as in ABI 2.2)
+        }
     }
     uint64_t Cu = 0;
     for (const Run& r : runs) Cu += (uint64_t)r.len * ups * r.cost;
-    if ((uint64_t)W * 8u > Cu) { W = (uint32_t)(Cu / 8u); pl.W = W; }       // a wave's share is at least the dearest unit
+    if ((uint64_t)W * kSweepCost > Cu) { W = (uint32_t)(Cu / kSweepCost); pl.W = W; }       // a wave's share is at least the dearest unit
     std::vector<uint32_t> starts((size_t)W + 1);
     {
         size_t q = 0;                                          // the run the wave's first unit lies in
@@ -502,7 +536,7 @@ static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t
     for (const auto& ps : s->sym_passes) Lsum += ps.plan[11] + ps.plan[12];
     pl.np = rp.np; pl.nsb = nsb; pl.W = rp.WA + rp.WB; pl.total_hi = rp.total_hi; pl.total_lo = rp.total_lo; pl.n_hi = n_hi; pl.H = H;
     pl.r_layer0 = 0; pl.t_layer0 = rp.t_layer0; pl.L = Lsum; pl.ups = rp.ups;
-    pl.zc = 0;
+    pl.zc = 0; pl.tri = 0;
     memcpy(s->sym_plan, &pl, sizeof pl);
     s->sym_rank = true; s->sym_g0 = rp.g0; s->sym_g1 = rp.g1;
     s->sym = true; s->symw = true; s->sym_np = rp.np; s->sym_layers = layers;
@@ -618,7 +652,7 @@ LaunchPlan plan_launch(const PlanInput& in)
             if ((want.kind == kFused || want.kind == kDirect) && !may_fuse && !f64) want = {kPkLds, want.ipl, want.ls, 1};   // same loop, two kernels
             if (want.kind == kDirect && n > 1024u * (uint32_t)want.x) want = {kFused, 2, 64, 4};
             if (want.kind == kJpk && !may_fuse) want = {kPkSgpr, 4, 1, 4};      // whole-system f32 handles only
-            if (want.kind == kSym && want.ls > 1) { sym_ups = (uint32_t)want.ls <= 8u ? (uint32_t)want.ls : 0u; want.ls = 1; }      // K = 7: LL = 02 / 04 / 08 pins the units per sweep
+            if (want.kind == kSym && want.ls > 1) { sym_ups = (uint32_t)want.ls <= 64u ? (uint32_t)want.ls : 0u; want.ls = 1; }      // K = 7: LL = 02 .. 64 pins the units per sweep
             if (want.kind == kSym && (!whole || cfg.ext_bodies || !shape_exists(f64, want) || n <= ipb_of(want) ||       // likewise; >= 2 super-blocks,
                                       sym_layer_bytes(n, ipb_of(want), esz) > std::max(layer_budget, 0.6 * in.device_mem)))    // and layers that fit (pinned: up to 60 % of the memory)
                 want = f64 ? Shape{kScalar, 4, 1, 1} : Shape{kPkSgpr, 8, 1, 4};
@@ -742,7 +776,7 @@ LaunchPlan plan_launch(const PlanInput& in)
         // the symmetric pass (whole-system f32 handles; every unordered pair once): from N ~ 14,000 up it beats every
         // ordered-pair shape above (N = 16,384: 61.7 vs 65.7 us, 40,002: 270 vs 357 us, 262,144: 10.5 vs 14.6 ms)
         if (!pinned && whole && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
-            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, f64, layer_budget, (cfg.flags & NB_FLAG_WHOLE_SWEEPS) != 0);
+            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, f64, layer_budget, (cfg.flags & NB_FLAG_WHOLE_SWEEPS) != 0, !(cfg.flags & NB_FLAG_FULL_OWN_SWEEPS));
 #ifdef NB_TUNING
             if (getenv("NB_MODEL_TRACE"))
                 fprintf(stderr, "plan n=%u: ordered-pair estimate %.2f us, symmetric %.2f us (%d residents, %u waves per SIMD)\n", n,

@@ -39,6 +39,9 @@ struct SymWPlan {
                                 // mid-sweep stores them in its own SPILL row (one per wave), which K2 adds through the per-chunk
                                 // spill lists that follow the {first wave, count} table: {offset, count} per traveler chunk, then
                                 // the wave numbers
+    uint32_t tri;               // own-chunk sweeps in their triangular form (nb_force_symw, one traveler per lane): chunk c meets the resident
+                                // rows r > c from both sides and row c resident-only -- every pair inside a super-block once; 0: every own chunk
+                                // against every resident row, resident-only (NB_FLAG_FULL_OWN_SWEEPS, two travelers per lane, f64)
 };
 // The rank form of the pass (NB_FLAG_SYM_SHARD: the handle keeps the super-blocks [g0, g1) of its own rows resident and sweeps THEIR
 // chunk lists), in TWO phases so that the part that needs nothing from the other ranks can run while their rows are still on the
@@ -98,7 +101,7 @@ struct LaunchPlan {
     uint32_t jsplit = 1, j_per_split = 0, junits = 0, own_split0 = 0, own_splits = 0;
     bool sym = false, symw = false, sym_rank = false;
     uint32_t sym_np = 0, sym_layers = 0, sym_g0 = 0, sym_g1 = 0;
-    uint32_t sym_plan[12] = {0};         // nb::SymWPlan (symw) or nb::SymPlan, as plain words
+    uint32_t sym_plan[16] = {0};         // nb::SymWPlan (symw: 13 words) or nb::SymPlan, as plain words
     uint32_t sym_spill_rows = 0;         // wave-granular form with ups > 1: rows of the spill buffer (W x travelers per chunk)
     uint32_t sym_rank_plan[16] = {0};    // rank form: nb::SymRankPlan as plain words (sym_plan then holds the SymWPlan summary: W = WA + WB, L = LA + LB)
     // The rank-form pipeline in PASSES over the ring distances (layers reused from pass to pass, nb_sym_reduce accumulating): one

@@ -27,13 +27,15 @@ NB_FLAG_JPK_FENCED = 32
 NB_FLAG_NO_SYM = 64
 NB_FLAG_SYM_SHARD = 128
 NB_FLAG_WHOLE_SWEEPS = 256
+NB_FLAG_FULL_OWN_SWEEPS = 512
 NB_RCCL_ID_BYTES = 128
 NB_RCCL_OVERLAP = 1
 NB_MULTI_PEER, NB_MULTI_RCCL = 0, 1
 NB_NOT_READY = 7
 STATUS = {0: "NB_OK", 1: "NB_ERR_INVALID", 2: "NB_ERR_NO_DEVICE", 3: "NB_ERR_HIP",
           4: "NB_ERR_STATE", 5: "NB_ERR_NOMEM", 6: "NB_ERR_COMM", 7: "NB_NOT_READY"}
-ABI_VERSION = 2
+ABI_VERSION = 2      # NB_ABI_VERSION (major)
+ABI_MINOR = 3        # NB_ABI_MINOR this binding was written against
 
 
 class NBodyError(RuntimeError):
@@ -59,7 +61,7 @@ class nb_plan_info(C.Structure):
         ("sym_plan", C.c_uint32 * 11), ("tab_len", C.c_uint32), ("variant", C.c_char * 112),
         ("sym_ups", C.c_uint32), ("sym_spill_rows", C.c_uint32), ("sym_rank_plan", C.c_uint32 * 16),
         ("sym_pass", C.c_uint32), ("sym_passes", C.c_uint32), ("sym_pass_k_lo", C.c_uint32), ("sym_pass_k_hi", C.c_uint32),
-        ("sym_pass_d0", C.c_uint32), ("sym_local", C.c_uint32)]
+        ("sym_pass_d0", C.c_uint32), ("sym_local", C.c_uint32), ("sym_tri", C.c_uint32)]
 
 
 class nb_step_timing(C.Structure):          # include/nbody3d_hip.h
@@ -71,7 +73,7 @@ class nb_step_timing(C.Structure):          # include/nbody3d_hip.h
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p)
 EXCHANGE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
-# every symbol include/nbody3d_hip.h declares (tests check the export list)
+# every symbol include/nbody3d_hip.h and include/nbody3d_hip_plan.h declare (tests check the export list)
 SYMBOLS = ["nb_abi_version", "nb_device_count", "nb_create", "nb_destroy", "nb_upload", "nb_set_params", "nb_step",
            "nb_download", "nb_sync", "nb_last_error", "nb_device_ptr", "nb_set_exchange",
            "nb_set_exchange_overlapped", "nb_enable_timing",
@@ -80,7 +82,8 @@ SYMBOLS = ["nb_abi_version", "nb_device_count", "nb_create", "nb_destroy", "nb_u
            "nb_multi_download", "nb_multi_sync", "nb_multi_last_error", "nb_multi_variant_name",
            "nb_multi_diagnostics", "nb_multi_set_collective", "nb_multi_collective_info",
            "nb_rccl_unique_id", "nb_rccl_attach", "nb_rccl_detach", "nb_rccl_info",
-           "nb_step_times", "nb_step_times2", "nb_integrate_pass", "nb_force_pass", "nb_frame_request", "nb_frame_acquire", "nb_shape_info", "nb_plan_query"]
+           "nb_step_times", "nb_step_times2", "nb_integrate_pass", "nb_force_pass", "nb_frame_request", "nb_frame_acquire", "nb_shape_info", "nb_plan_query",
+           "nb_abi_minor"]
 
 _lib = None
 
@@ -100,6 +103,7 @@ def load_library():
     L = C.CDLL(_LIB_PATH)
     vp = C.c_void_p
     L.nb_abi_version.restype = C.c_uint32
+    L.nb_abi_minor.restype = C.c_uint32
     L.nb_device_count.restype = C.c_int
     L.nb_create.argtypes = [C.POINTER(nb_config), C.POINTER(vp)]
     L.nb_destroy.argtypes = [vp]
@@ -156,6 +160,10 @@ def abi_version():
     return load_library().nb_abi_version()
 
 
+def abi_minor():
+    return load_library().nb_abi_minor()
+
+
 def device_count():
     return load_library().nb_device_count()
 
@@ -208,6 +216,7 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
             raise NBodyError(rc, L.nb_last_error(None).decode())
     out = {k: int(getattr(info, k)) for k, _ in nb_plan_info._fields_[1:16]}
     out["variant"] = info.variant.decode()
+    out["flags"] = int(flags)
     out.update(passes=int(info.sym_passes), local=int(info.sym_local), pass_k_lo=int(info.sym_pass_k_lo), pass_k_hi=int(info.sym_pass_k_hi),
                pass_d0=int(info.sym_pass_d0))
     if info.sym:
@@ -238,6 +247,7 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
         out["ups"], out["spill_rows"] = int(info.sym_ups), int(info.sym_spill_rows)
         if info.symw:
             out["plan"]["ups"] = int(info.sym_ups)
+            out["plan"]["tri"] = int(info.sym_tri)
         if info.sym_ups > 1 and not info.sym_rank:
             # the spill rows (wave ranges cut inside sweeps): the spill row of every wave, {first row, count} per traveler chunk,
             # then the wave numbers in row order

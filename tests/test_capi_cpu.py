@@ -11,7 +11,7 @@ from nbody3d_amd import capi
 
 
 def header_symbols():
-    src = open(os.path.join(ROOT, "include", "nbody3d_hip.h")).read()
+    src = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include"))) if h.endswith(".h"))
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(nb_[a-z0-9_]+)\s*\(", src)) - {"nb_exchange_fn"})
 
@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_abi_version_and_config_layout():
-    assert capi.abi_version() == capi.ABI_VERSION == 2
+    assert capi.abi_version() == capi.ABI_VERSION == 2 and capi.abi_minor() >= capi.ABI_MINOR == 3
     # layout must match the C struct: 4*4 + 8 + 3*4 (+4 pad) + 2*8 + 3*4 + 5*4 = 88
     assert C.sizeof(capi.nb_config) == 88
 
