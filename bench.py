@@ -278,7 +278,8 @@ def also_measurements(Simulation, ic, device):
       default    the reference's UI defaults (index.html:68-74, nbody3d.js:62-64,163-177): 2 galaxies x 20,000 + 2 = N 40,002,
                  G = dt = 1e-4, central masses 1e7 -- built by js/ic.js::galaxies under Node, digest-checked against the
                  reference generator's own output (tests/golden/galaxy40002_params.json)
-      UI range   N=13,000 / 16,384 / 20,000 Plummer spheres, fp32: mid sizes of the reference's UI range
+      UI range   N=13,000 / 16,384 / 20,000 Plummer spheres, fp32: mid sizes of the reference's UI range; 2,048 / 4,096 / 8,192 / 10,000: its low half
+      weak g=1   N=370,688: the g = 1 anchor of config 4's weak-scaling series
     """
     out = []
 
@@ -361,6 +362,15 @@ def also_measurements(Simulation, ic, device):
     for un in (13000, 16384, 20000):
         ub, uv = ic.plummer(un, seed=1)
         run("reference UI range: N=%d Plummer sphere, fp32" % un, ub, uv, 1e-3, 1.0, "f32", 0, 600, 1600, 48)
+    # ... and its low half (the UI starts at 1,001 bodies per galaxy): one-launch steps, launch- and latency-bound
+    for un, usteps in ((2048, 16000), (4096, 12800), (8192, 6400), (10000, 4800)):
+        ub, uv = ic.plummer(un, seed=1)
+        run("reference UI range, low half: N=%d Plummer sphere, fp32" % un, ub, uv, 1e-3, 1.0, "f32", 0, usteps // 2, usteps, 48)
+    # config 4's weak-scaling series (constant pairs per GPU, N_g = 1,048,576 sqrt(g / 8)) has its g = 1 point on this
+    # one GPU: `bench.py --scaling weak --gpus 1` runs the same N -- here so that the curve has its anchor in every default line
+    wn = weak_n(1)
+    wb, wv = ic.plummer(wn, seed=1)
+    run("config 4 weak-scaling series, g=1 anchor: N=%d Plummer sphere, fp32 (= bench.py --scaling weak --gpus 1)" % wn, wb, wv, 1e-3, 1.0, "f32", 0, 2, 6, 4)
     return out
 
 
@@ -552,11 +562,17 @@ def main():
 
         sim.simulate(max(args.warmup - 1, 0))
         barrier()
-        sim.enable_timing(True)
+        # The timed region: EXACTLY args.steps steps between two barriers, per-kernel event timing OFF -- the regime a user gets
+        # (multi-step calls on the engine's own stream replay a captured graph), and the one every `also` entry is timed in.
         t0 = time.perf_counter()
         sim.simulate(args.steps)
         barrier()
         elapsed = time.perf_counter() - t0
+        # ... and a separate leg of the same number of steps with the kernels stamped at their own begin / end (HIP events on the
+        # engine's stream: plain launches, no graph) for roofline.avg_launch_ms and the per-part breakdown; outside the timed region
+        sim.enable_timing(True)
+        sim.simulate(args.steps)
+        barrier()
         parts = sim.step_breakdown()
         sim.enable_timing(False)
         if dist is not None:
@@ -654,12 +670,15 @@ def main():
                     tj.get("kernel_variant") == variant):
                 traffic, traffic_src = tj.get("bytes_per_launch"), "profiles/k1_hbm_traffic.json (" + tj.get("source", "") + ")"
         fused = "fused" in variant
-        kname = ("nb_step_symf" if "symf" in variant else "nb_force_symw" if "symw" in variant else "nb_force_sym" if "_sym_" in variant
+        kname = ("nb_force_symw" if "symw" in variant else "nb_force_sym" if "_sym_" in variant
                  else "nb_step_jpk" if "jpairs" in variant else "nb_step_direct" if "fused_regs" in variant else "nb_step_fused" if fused else "nb_force")
         out["roofline"] = {"kernel": kname + "<%s> (%s)" % (args.precision, variant),
                            "bound": "valu",
                            "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                            "traffic": traffic, "traffic_source": traffic_src, "avg_launch_ms": f_ms, "launches": launches,
+                           "timing": "HIP events stamped at the kernel's own begin / end on the engine's stream, over a separate leg of "
+                                     "%d steps right after the wall-timed ones (value / ms_per_step come from the wall-timed leg: graph "
+                                     "replay, no per-kernel events)" % args.steps,
                            "flops_per_pair": FLOPS_PER_PAIR,
                            "note": "compute-bound on the fp32 vector-FMA rate (157.3 TFLOP/s spec, equal to the "
                                    "dense f32 MFMA peak); not HBM and not MFMA: rsqrt-bound scalar FMA.  achieved = 20 flop x "

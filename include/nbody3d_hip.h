@@ -41,7 +41,7 @@ extern "C" {
 #define NB_ABI_MINOR 3u   /* additions within major 2; a client needs nb_abi_minor() >= the minor it was written against:
                              2.1 (round 3)  nb_force_pass, nb_frame_request / nb_frame_acquire, nb_shape_info, NB_FLAG_SYM_SHARD
                              2.2 (round 4)  nb_step_times2, nb_plan_query, NB_FLAG_WHOLE_SWEEPS, nb_config.layer_budget_mib
-                             2.3 (round 5)  nb_abi_minor, NB_FLAG_FULL_OWN_SWEEPS; nb_plan_info / nb_plan_query moved to nbody3d_hip_plan.h */
+                             2.3 (round 5)  nb_abi_minor; nb_plan_info / nb_plan_query moved to nbody3d_hip_plan.h; force_variant 7 II LL 3 takes LL up to 64 */
 
 typedef struct nb_sim nb_sim; /* opaque */
 
@@ -89,10 +89,6 @@ typedef enum nb_precision { NB_F32 = 0, NB_F64 = 1 } nb_precision;
 #define NB_FLAG_WHOLE_SWEEPS 256u /* tuning/A-B: the symmetric pass cuts its wave ranges at whole chunk-sweeps (64 rotation steps), as in
                                    ABI 2.0; by default systems with few sweeps per wave cut them in quarter sweeps (variant suffix
                                    "_u4"), which evens out the SIMDs' work (N = 16,384: the longest SIMD runs 4.25 sweeps instead of 5) */
-
-#define NB_FLAG_FULL_OWN_SWEEPS 512u /* tuning/A-B: the symmetric pass sweeps a super-block's own chunks against every resident row,
-                                      resident-only (each pair inside a super-block from both sides, as in ABI 2.2); by default
-                                      the f32 pass evaluates those pairs once too (triangular own-chunk sweeps) */
 
 /* nb_array: selector for nb_device_ptr */
 typedef enum nb_array { NB_BODIES = 0, NB_VEL = 1, NB_ACCEL = 2 } nb_array;

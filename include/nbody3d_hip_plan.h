@@ -38,8 +38,7 @@ extern "C" {
  *                      padding rows counts nothing); with sym_ups > 1 followed by the spill tables -- the spill row of every wave (W words), {first
  *                      spill row, count} per traveler chunk (2 * sym_np / 64 words), then the wave numbers in spill-row order;
  *                      tab_len reports how many words there are
- *   sym_ups            work units per chunk-sweep: the wave ranges are floor/ceil-equal in units of 64 / sym_ups rotation steps
- *   sym_tri            own-chunk sweeps in their triangular form (each pair inside a super-block once; nb::SymWPlan::tri) */
+ *   sym_ups            work units per chunk-sweep: the wave ranges are floor/ceil-equal in units of 64 / sym_ups rotation steps */
 typedef struct nb_plan_info {
   uint32_t struct_size; /* sizeof(nb_plan_info), set by the caller */
   uint32_t kind, ipl, ls, x;
@@ -62,7 +61,6 @@ typedef struct nb_plan_info {
   uint32_t sym_passes;     /* passes of the rank-form pipeline (1 for an ordinary rank; 0 when the handle is not in the rank form) */
   uint32_t sym_pass_k_lo, sym_pass_k_hi, sym_pass_d0; /* the pass's window of every super-block's ring sweeps [k_lo, k_hi) and its first ring distance */
   uint32_t sym_local;      /* the rank-form pipeline of a WHOLE system on one device: no communicator, nothing exchanged */
-  uint32_t sym_tri;        /* wave-granular symmetric pass: own-chunk sweeps are triangular (see above); 0: resident-only against every row */
 } nb_plan_info;
 int nb_plan_query(const nb_config *cfg, int n_cu, double clock_hz, nb_plan_info *out, uint32_t *tab,
                   uint32_t tab_cap);

@@ -294,7 +294,6 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             if (tb >= pl.nsb) tb -= pl.nsb;
             const uint32_t tstart = k < ring ? tb * S + (k % CPS) * CH : zsweep ? pl.nsb * S + (k - ring) * CH : g * S + (k - both_end) * CH;
             const uint32_t zrow = g * pl.zc + (k - ring);            // (z sweeps)
-            const uint32_t own_c = k - both_end;                     // (own-chunk sweeps: the chunk = the resident row)
             ++k;
             // (Tried in round 5 and dropped: requesting the travelers of sweep k + 1 before the rotation steps of sweep k -- the wait
             // moved behind the loop, in front of the stores.  0.3-1 % SLOWER from N = 10,000 to 65,536 at one and two waves per SIMD,
@@ -313,68 +312,59 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             // Two forms of the loop: a sweep over one of the super-block's OWN chunks needs no traveler sums (each of its pairs is met
             // from both sides), so it drops the 4 packed instructions per group and the 6 rotations that keep them: 116 instead of
             // 154 issue slots per step with 16 residents -- 0.88 of the time at one or two waves per SIMD (the planner counts 7/8).
-            // Third form (round 5; J = 1): the TRIANGULAR sweep over own chunk c = resident row c of the same super-block.  The pairs of
-            // rows (c, r) with r > c are evaluated ONCE, both sides, while chunk c travels (its sums fold into the accumulators of row c
-            // afterwards); rows r < c were done when chunk r traveled; row c itself meets its own chunk resident-only (both ordered
-            // pairs of two bodies of one chunk come by in 64 steps).  So the loop runs the packed groups [P0, NG), P0 = c / 2 -- one
-            // instantiation per P0, the registers stay statically indexed -- and in group P0 the halves that must not count are
-            // switched off through the mass factors: c odd: row 2 P0 is skipped (both sides), row c resident-only; c even: row c
-            // resident-only, row c + 1 both sides.  16 residents: 6,400 issue cycles per step for the 16 own chunks against 8,448.
-            auto steps = [&](auto both, auto first, const bool odd) {
+            // (Tried in round 5 and dropped -- commit 4c416e1 has the code: a THIRD, triangular form for the own chunks, chunk c against the
+            // resident rows r > c from both sides and row c resident-only, one instantiation per first packed group, traveler sums folded
+            // into the accumulators of row c: every pair inside a super-block once, 21 % fewer instructions over the 16 own chunks.
+            // Correct (216 GPU tests), but the forms with fewer than four packed groups have fewer than four independent chains and wait
+            // on their own results: 3-4 % SLOWER per step at N = 13,000 .. 20,000 with wave ranges weighted by instruction count,
+            // level with this form after re-weighting -- profiles/r05/own_chunk_triangular_*.txt.)
+            auto steps = [&](auto both) {
                 constexpr bool BOTH = decltype(both)::value;
-                constexpr int P0 = decltype(first)::value;                // >= 0: triangular sweep from packed group P0; -1: every group
-                constexpr int G0 = P0 > 0 ? P0 : 0;
-                static_assert(P0 < 0 || (BOTH && J == 1), "the triangular sweep keeps traveler sums; one traveler per lane");
-                const nb_f2 pmask = odd ? nb_f2{0.f, 1.f} : nb_f2{1.f, 1.f};
-                const nb_f2 mi0 = odd ? nb_f2{0.f, 0.f} : nb_f2{0.f, mi[G0].y};
                 for (uint32_t st = s0; st < s1; ++st) {
 #pragma unroll
                     for (int uu = 0; uu < J; ++uu) {
                         const nb_f2 px = nb_f2{tx[uu], tx[uu]}, py = nb_f2{ty[uu], ty[uu]}, pz = nb_f2{tz[uu], tz[uu]}, pm = nb_f2{tm[uu], tm[uu]};
-                        const nb_f2 pm0 = P0 >= 0 ? pm * pmask : pm;     // traveler mass as group P0 sees it
 #pragma unroll
-                        for (int c0g = G0; c0g < NG; c0g += GW) {        // stage-major over groups of (up to) four
+                        for (int c0g = 0; c0g < NG; c0g += GW) {         // stage-major over groups of (up to) four
                             nb_f2 dx[GW], dy[GW], dz[GW], d2[GW], r[GW], si[GW], sj[GW];
-#define NB_GROUPS for (int c = 0; c < GW; ++c) if (c0g + c < NG)
 #pragma unroll
-                            NB_GROUPS dx[c] = px - xi[c0g + c];                                   // :233
+                            for (int c = 0; c < GW; ++c) dx[c] = px - xi[c0g + c];                                   // :233
 #pragma unroll
-                            NB_GROUPS dy[c] = py - yi[c0g + c];
+                            for (int c = 0; c < GW; ++c) dy[c] = py - yi[c0g + c];
 #pragma unroll
-                            NB_GROUPS dz[c] = pz - zi[c0g + c];
+                            for (int c = 0; c < GW; ++c) dz[c] = pz - zi[c0g + c];
 #pragma unroll
-                            NB_GROUPS d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
+                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
 #pragma unroll
-                            NB_GROUPS d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
 #pragma unroll
-                            NB_GROUPS d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
 #pragma unroll
-                            NB_GROUPS r[c] = d2[c] * d2[c];                                       // :235
+                            for (int c = 0; c < GW; ++c) r[c] = d2[c] * d2[c];                                       // :235
 #pragma unroll
-                            NB_GROUPS r[c] = r[c] * d2[c];
+                            for (int c = 0; c < GW; ++c) r[c] = r[c] * d2[c];
 #pragma unroll
-                            NB_GROUPS r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
+                            for (int c = 0; c < GW; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
 #pragma unroll
-                            NB_GROUPS si[c] = (P0 >= 0 && c0g + c == P0 ? pm0 : pm) * r[c];       // (G m_t) inv: resident side, :236
+                            for (int c = 0; c < GW; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
                             if constexpr (BOTH) {
 #pragma unroll
-                                NB_GROUPS sj[c] = (P0 >= 0 && c0g + c == P0 ? mi0 : mi[c0g + c]) * r[c];   // (G m_i) inv: traveler side
+                                for (int c = 0; c < GW; ++c) sj[c] = mi[c0g + c] * r[c];   // (G m_i) inv: traveler side
                             }
 #pragma unroll
-                            NB_GROUPS ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
+                            for (int c = 0; c < GW; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
 #pragma unroll
-                            NB_GROUPS ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
+                            for (int c = 0; c < GW; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
 #pragma unroll
-                            NB_GROUPS az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
+                            for (int c = 0; c < GW; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
                             if constexpr (BOTH) {
 #pragma unroll
-                                NB_GROUPS bx[uu] = __builtin_elementwise_fma(-sj[c], dx[c], bx[uu]);   // x_i - x_t = -(x_t - x_i), exactly
+                                for (int c = 0; c < GW; ++c) bx[uu] = __builtin_elementwise_fma(-sj[c], dx[c], bx[uu]);   // x_i - x_t = -(x_t - x_i), exactly
 #pragma unroll
-                                NB_GROUPS by[uu] = __builtin_elementwise_fma(-sj[c], dy[c], by[uu]);
+                                for (int c = 0; c < GW; ++c) by[uu] = __builtin_elementwise_fma(-sj[c], dy[c], by[uu]);
 #pragma unroll
-                                NB_GROUPS bz[uu] = __builtin_elementwise_fma(-sj[c], dz[c], bz[uu]);
+                                for (int c = 0; c < GW; ++c) bz[uu] = __builtin_elementwise_fma(-sj[c], dz[c], bz[uu]);
                             }
-#undef NB_GROUPS
                         }
                     }
 #pragma unroll
@@ -388,34 +378,7 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
                     }
                 }
             };
-            using none = std::integral_constant<int, -1>;
-            if (sym) steps(std::true_type{}, none{}, false);
-            else if (J == 1 && pl.tri && g < pl.nsb) {
-                // triangular sweep over own chunk `own_c`, then its traveler sums -- sums for row own_c of THIS super-block, whose
-                // accumulators this wave holds -- go home (64 - s1 more rotations: none for a whole sweep) and into those accumulators
-                if constexpr (J == 1) {
-                    const bool odd = own_c & 1u;
-                    switch (own_c >> 1) {
-#define NB_TRI(P) case P: if constexpr (P < NG) steps(std::true_type{}, std::integral_constant<int, P>{}, odd); break;
-                        NB_TRI(0) NB_TRI(1) NB_TRI(2) NB_TRI(3) NB_TRI(4) NB_TRI(5) NB_TRI(6) NB_TRI(7)
-#undef NB_TRI
-                        default: break;
-                    }
-                    for (uint32_t st = s1; st < 64u; ++st) {
-                        bx[0] = nb_f2{wave_rot1(bx[0].x), wave_rot1(bx[0].y)};
-                        by[0] = nb_f2{wave_rot1(by[0].x), wave_rot1(by[0].y)};
-                        bz[0] = nb_f2{wave_rot1(bz[0].x), wave_rot1(bz[0].y)};
-                    }
-                    const float fx = bx[0].x + bx[0].y, fy = by[0].x + by[0].y, fz = bz[0].x + bz[0].y;
-                    switch (own_c >> 1) {
-#define NB_FOLD(P) case P: if constexpr (P < NG) { if (odd) { ax[P].y += fx; ay[P].y += fy; az[P].y += fz; } else { ax[P].x += fx; ay[P].x += fy; az[P].x += fz; } } break;
-                        NB_FOLD(0) NB_FOLD(1) NB_FOLD(2) NB_FOLD(3) NB_FOLD(4) NB_FOLD(5) NB_FOLD(6) NB_FOLD(7)
-#undef NB_FOLD
-                        default: break;
-                    }
-                }
-            }
-            else steps(std::false_type{}, none{}, false);
+            if (sym) steps(std::true_type{}); else steps(std::false_type{});
             if (sym) {
                 // the sums of steps [s0, s1) sit s1 lanes past their travelers' home lanes.  The part that starts the sweep owns the
                 // sweep's traveler layer; any later part goes to the wave's own spill row (K2 adds it: the spill rows of a chunk are consecutive)

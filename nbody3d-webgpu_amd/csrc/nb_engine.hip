@@ -1163,10 +1163,9 @@ int nb_plan_query(const nb_config* cfg_in, int n_cu, double clock_hz, nb_plan_in
     out->jsplit = tmp.jsplit; out->j_per_split = tmp.j_per_split; out->own_split0 = tmp.own_split0; out->own_splits = tmp.own_splits;
     out->sym = tmp.sym; out->symw = tmp.symw; out->sym_rank = tmp.sym_rank;
     out->sym_np = tmp.sym_np; out->sym_layers = tmp.sym_layers; out->sym_g0 = tmp.sym_g0; out->sym_g1 = tmp.sym_g1;
-    static_assert(sizeof(out->sym_plan) == 11 * sizeof(uint32_t) && sizeof(tmp.sym_plan) >= 13 * sizeof(uint32_t), "nb_plan_info::sym_plan holds the first eleven words of nb_sim::sym_plan; the twelfth (ups) is sym_ups, the thirteenth sym_tri");
+    static_assert(sizeof(out->sym_plan) == 11 * sizeof(uint32_t) && sizeof(tmp.sym_plan) >= 12 * sizeof(uint32_t), "nb_plan_info::sym_plan holds the first eleven words of nb_sim::sym_plan; the twelfth (ups) is sym_ups");
     memcpy(out->sym_plan, tmp.sym_plan, sizeof out->sym_plan);
     out->sym_ups = tmp.symw ? tmp.sym_plan[11] : 0;
-    out->sym_tri = tmp.symw && !tmp.sym_rank ? tmp.sym_plan[12] : 0;
     out->sym_spill_rows = tmp.sym_spill_rows;
     static_assert(sizeof(out->sym_rank_plan) == sizeof(tmp.sym_rank_plan), "nb_plan_info::sym_rank_plan mirrors nb_sim::sym_rank_plan");
     memcpy(out->sym_rank_plan, tmp.sym_rank_plan, sizeof out->sym_rank_plan);

@@ -119,9 +119,6 @@ struct ModelKnobs {
     double sustained = 0.958;  // share of hipDeviceProp_t::clockRate the chip holds under this kernel's load
                                // (2.24-2.29 of 2.4 GHz measured, profiles/r02/rocprof_f32_default: GRBM_GUI_ACTIVE)
     double jpk_lo = 7000, jpk_hi = 12500;   // sizes at which the j-packed step is scored at all (see plan_launch)
-    // the triangular own-chunk sweep (own_sweep_cost): issue cycles per packed group, surcharge per chain missing from four, cycles per
-    // step beside the groups (rotations, mask), and a floor (share of a both-sides sweep) under which no own sweep is counted
-    double tri_group = 80.0, tri_chain = 0.25, tri_fixed = 44.0, tri_floor = 0.0;
 };
 #ifdef NB_TUNING
 // calibration build: read on every nb_create, so that one process can walk a grid of constants (tools/fit_model.py)
@@ -133,8 +130,6 @@ ModelKnobs model_knobs()
     m.hand_over = knob("NB_MODEL_HANDOVER", m.hand_over); m.lanes_scale = knob("NB_MODEL_LANES_SCALE", m.lanes_scale);
     m.boundary = knob("NB_MODEL_BOUNDARY", m.boundary); m.sustained = knob("NB_MODEL_SUSTAINED", m.sustained);
     m.jpk_lo = knob("NB_MODEL_JPK_LO", m.jpk_lo); m.jpk_hi = knob("NB_MODEL_JPK_HI", m.jpk_hi);
-    m.tri_group = knob("NB_MODEL_TRI_GROUP", m.tri_group); m.tri_chain = knob("NB_MODEL_TRI_CHAIN", m.tri_chain);
-    m.tri_fixed = knob("NB_MODEL_TRI_FIXED", m.tri_fixed); m.tri_floor = knob("NB_MODEL_TRI_FLOOR", m.tri_floor);
     return m;
 }
 #else
@@ -177,33 +172,22 @@ double sym_layer_budget(const nb_config& cfg, double device_mem)
 // of them and the launch lasts as long as its longest SIMD: at N = 16,384 (4.1 sweeps per SIMD) some SIMDs run 5 -- 56 us against
 // 44 us of pair work (profiles/r04/step_parts_base.txt).  Quarter sweeps (16 rotation steps) bring that to 4.25.  A system with
 // dozens of sweeps per wave does not need them.
-uint32_t sym_units(uint64_t L, uint32_t W, bool whole_only)
+uint32_t sym_units(uint64_t L, uint32_t W, bool whole_only, bool one_wave_per_simd = false)
 {
     if (whole_only || W == 0) return 1;
-    return L < (uint64_t)12 * W ? 8u : L < (uint64_t)48 * W ? 4u : 1u;      // eighths below a dozen sweeps per wave (N = 16,384: 57.2 vs 58.3 us)
+    if (one_wave_per_simd && L < (uint64_t)2 * W) return 32u;
+    // eighths below a dozen sweeps per wave (N = 16,384: 57.2 vs 58.3 us); with ONE wave per SIMD and less than two sweeps to its name a
+    // range is cut to 2 rotation steps (above: N = 9,000, 8 residents per lane: 24.5 -> 23.75 us, N = 10,000: 27.6 -> 27.0; nothing from
+    // 12,000 up or with 16 residents: profiles/r05/ups_16_32_64_scan.txt)
+    return L < (uint64_t)12 * W ? 8u : L < (uint64_t)48 * W ? 4u : 1u;
 }
 
 // Work of one chunk-sweep on a scale where a sweep that keeps traveler sums (both sides) counts kSweepCost: what the wave ranges are
-// made equal in (lay_out_symw) and what sym_estimate sums up.
-//   * a sweep over an own chunk, resident-only against every row (f64, two travelers per lane, NB_FLAG_FULL_OWN_SWEEPS, the short
-//     block): 7/8 (measured 0.88 at one and two waves per SIMD, profiles/r04/README.md);
-//   * the TRIANGULAR sweep over own chunk c (nb_force_symw, one traveler per lane): packed groups c / 2 .. NG - 1 of the NG = ipl / 2,
-//     80 issue cycles each + 44 for the rotations and the mask, against NG * 80 + 40; with fewer than four groups the stage-major
-//     order has fewer than four independent chains and the loop waits on its own results (charged 25 % per missing chain).
-constexpr uint32_t kSweepCost = 64;
-uint32_t own_sweep_cost(int ipl, uint32_t c, bool tri)
-{
-    if (!tri) return kSweepCost * 7 / 8;
-    const ModelKnobs mk = model_knobs();
-    const double NG = ipl / 2.0, n = NG - (double)(c / 2);
-    const double chains = n < 4.0 ? 1.0 + mk.tri_chain * (4.0 - n) : 1.0;
-    const double cyc = n * mk.tri_group * chains + mk.tri_fixed;
-    const uint32_t cost = (uint32_t)std::lround(kSweepCost * std::max(mk.tri_floor, cyc / (NG * 80.0 + 40.0)));
-    return std::max(1u, std::min(cost, kSweepCost));
-}
-bool sym_triangular(bool f64, const Shape& sh, const nb_config& cfg) { return !f64 && sh.kind == kSym && sh.x == 3 && !(cfg.flags & NB_FLAG_FULL_OWN_SWEEPS); }
+// made equal in (lay_out_symw).  A sweep over an own chunk (resident-only, no traveler sums) counts 7/8 (measured 0.88 at one and two
+// waves per SIMD, profiles/r04/README.md).
+constexpr uint32_t kSweepCost = 8, kOwnSweepCost = 7;
 
-SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64, double layer_budget, bool whole_only, bool tri)
+SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64, double layer_budget, bool whole_only)
 {
     SymChoice best{0, 0, 1, 1e300};
     for (int ipl : {4, 8, 16}) {
@@ -217,10 +201,7 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         const uint32_t nsb = n / S, zc = ceil_div(n % S, 64u);
         const uint32_t H = (nsb - 1) / 2, n_hi = (nsb & 1u) ? 0u : nsb / 2;
         const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps + zc, total_lo = (uint64_t)(H + 1) * cps + zc;
-        // (sweeps over own chunks count their share of a both-sides sweep: own_sweep_cost)
-        uint64_t own_cost = 0;
-        for (uint32_t c = 0; c < cps; ++c) own_cost += own_sweep_cost(ipl, c, tri && !f64);
-        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo + zc - ((uint64_t)nsb * (cps * kSweepCost - own_cost) + (uint64_t)zc * (kSweepCost / 8)) / kSweepCost;
+        const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo + zc - ((uint64_t)nsb * cps + zc) / 8u;      // (a sweep over an own chunk counts 7/8)
         // f64: 92 issue cycles per resident and step + 14 DPP; the loop runs at 96 % of that (N = 262,144: 23.7 ms, profiles/r03/sym_f64_first.txt)
         const double t_chunk = f64 ? 64.0 * (92.0 * ipl + 56.0) / 0.96 / clock : 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.95 : 0.935) / clock;
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
@@ -229,7 +210,7 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
             if (k == 2 && per_simd < 2.0) continue;      // every wave needs a whole sweep or so of work
             // units per sweep: whole sweeps when a wave's share happens to round well (N = 11,000: 1.93 sweeps per wave, 31.3 us against
             // 32.7 with eighths), else eighths below a dozen sweeps per wave, quarters below 48 (sym_units)
-            const uint32_t ups_fine = sym_units(L, (uint32_t)simds * k, whole_only);
+            const uint32_t ups_fine = sym_units(L, (uint32_t)simds * k, whole_only, k == 1);
             for (uint32_t ups : {1u, ups_fine}) {
                 if (ups == 1 && ups_fine > 1 && (k == 2 || per_simd >= 4.0)) continue;       // one wave per SIMD and a few sweeps only: with two waves the
                                                                                              // rounding below is an average, good for fine units only
@@ -281,7 +262,7 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, c
     auto total_of = [&](uint32_t g) { return g < n_hi ? pl.total_hi : g < nsb ? pl.total_lo : zc; };
     const uint32_t kw = sym_k ? sym_k : (cfg.jsplit ? cfg.jsplit : 1u);
     uint32_t W = 4u * (uint32_t)n_cu * kw;
-    const uint32_t ups = (cfg.flags & NB_FLAG_WHOLE_SWEEPS) ? 1u : (sym_ups ? sym_ups : sym_units(pl.L, W, false));
+    const uint32_t ups = (cfg.flags & NB_FLAG_WHOLE_SWEEPS) ? 1u : (sym_ups ? sym_ups : sym_units(pl.L, W, false, kw == 1));
     pl.ups = ups;
     const uint64_t Lu = (uint64_t)pl.L * ups;                  // the list in units
     if (W > Lu) W = (uint32_t)Lu;                               // never more waves than units: every wave has work, so every resident layer the table
@@ -305,18 +286,12 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, c
     // The wave ranges: equal in WORK.  A sweep over an own chunk runs the loop without traveler sums and takes 7/8 of another (measured 0.88
     // at one and two waves per SIMD: profiles/r04/README.md); a block's list is [both-sides sweeps at 8][own chunks at 7] when the ranges
     // are cut inside sweeps.
-    const bool tri = J == 1 && sym_triangular(f64, sh, cfg);
-    pl.tri = tri ? 1u : 0u;
     struct Run { uint64_t at; uint32_t len, cost; };
     std::vector<Run> runs;
     for (uint32_t g = 0; g < blocks; ++g) {
         const uint32_t total = total_of(g), own = g < nsb ? cps : zc;
         if (total > own) runs.push_back({offset_of(g), total - own, kSweepCost});
-        if (tri && g < nsb) {
-            for (uint32_t c = 0; c < own; ++c) runs.push_back({(uint64_t)offset_of(g) + total - own + c, 1u, own_sweep_cost(sh.ipl, c, true)});     // own chunk c: groups c / 2 .. NG - 1
-        } else {
-            runs.push_back({(uint64_t)offset_of(g) + total - own, own, ups > 1 ? own_sweep_cost(sh.ipl, 0, false) : kSweepCost});      // (whole sweeps: an even cut, as in ABI 2.2)
-        }
+        runs.push_back({(uint64_t)offset_of(g) + total - own, own, ups > 1 ? kOwnSweepCost : kSweepCost});      // whole sweeps cannot be cut finer than the difference: even cut
     }
     uint64_t Cu = 0;
     for (const Run& r : runs) Cu += (uint64_t)r.len * ups * r.cost;
@@ -536,7 +511,7 @@ static void lay_out_symw_rank(LaunchPlan* s, const Shape& sh, bool f64, uint32_t
     for (const auto& ps : s->sym_passes) Lsum += ps.plan[11] + ps.plan[12];
     pl.np = rp.np; pl.nsb = nsb; pl.W = rp.WA + rp.WB; pl.total_hi = rp.total_hi; pl.total_lo = rp.total_lo; pl.n_hi = n_hi; pl.H = H;
     pl.r_layer0 = 0; pl.t_layer0 = rp.t_layer0; pl.L = Lsum; pl.ups = rp.ups;
-    pl.zc = 0; pl.tri = 0;
+    pl.zc = 0;
     memcpy(s->sym_plan, &pl, sizeof pl);
     s->sym_rank = true; s->sym_g0 = rp.g0; s->sym_g1 = rp.g1;
     s->sym = true; s->symw = true; s->sym_np = rp.np; s->sym_layers = layers;
@@ -776,7 +751,7 @@ LaunchPlan plan_launch(const PlanInput& in)
         // the symmetric pass (whole-system f32 handles; every unordered pair once): from N ~ 14,000 up it beats every
         // ordered-pair shape above (N = 16,384: 61.7 vs 65.7 us, 40,002: 270 vs 357 us, 262,144: 10.5 vs 14.6 ms)
         if (!pinned && whole && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
-            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, f64, layer_budget, (cfg.flags & NB_FLAG_WHOLE_SWEEPS) != 0, !(cfg.flags & NB_FLAG_FULL_OWN_SWEEPS));
+            const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, f64, layer_budget, (cfg.flags & NB_FLAG_WHOLE_SWEEPS) != 0);
 #ifdef NB_TUNING
             if (getenv("NB_MODEL_TRACE"))
                 fprintf(stderr, "plan n=%u: ordered-pair estimate %.2f us, symmetric %.2f us (%d residents, %u waves per SIMD)\n", n,

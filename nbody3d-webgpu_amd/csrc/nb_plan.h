@@ -39,9 +39,6 @@ struct SymWPlan {
                                 // mid-sweep stores them in its own SPILL row (one per wave), which K2 adds through the per-chunk
                                 // spill lists that follow the {first wave, count} table: {offset, count} per traveler chunk, then
                                 // the wave numbers
-    uint32_t tri;               // own-chunk sweeps in their triangular form (nb_force_symw, one traveler per lane): chunk c meets the resident
-                                // rows r > c from both sides and row c resident-only -- every pair inside a super-block once; 0: every own chunk
-                                // against every resident row, resident-only (NB_FLAG_FULL_OWN_SWEEPS, two travelers per lane, f64)
 };
 // The rank form of the pass (NB_FLAG_SYM_SHARD: the handle keeps the super-blocks [g0, g1) of its own rows resident and sweeps THEIR
 // chunk lists), in TWO phases so that the part that needs nothing from the other ranks can run while their rows are still on the

@@ -22,6 +22,7 @@
 #include <string.h>
 
 #include "../../../include/nbody3d_hip.h"
+#include "../../../include/nbody3d_hip_plan.h"
 
 /* ---- engine entry points, resolved at load() ---------------------------- */
 static void *g_lib;

@@ -177,14 +177,17 @@ class Simulation {
     return this;
   }
 
-  /** util.js:186-201 schema minus the camera block (rendering is out of scope):
-   *  {bodies, vel, accel, G: log10(G).toFixed(2)}.  dt and N are not saved upstream either. */
-  exportJSON() {
+  /** util.js:186-201 schema: {bodies, vel, accel, camera, G: log10(G).toFixed(2)}.  dt and N are not saved upstream either.
+   *  The engine has no camera (rendering is out of scope): the `camera` object of the checkpoint this state was imported
+   *  from -- or one handed in -- is passed through untouched, so a browser -> engine -> browser round trip keeps the view
+   *  (util.js:190-199 writes it, :246-256 restores it and tolerates its absence). */
+  exportJSON(camera) {
     const s = this.read();
-    return JSON.stringify({
-      bodies: Array.from(s.bodies), vel: Array.from(s.vel), accel: Array.from(s.accel),
-      G: (Math.log(this.G) / Math.LN10).toFixed(2),
-    });
+    const out = { bodies: Array.from(s.bodies), vel: Array.from(s.vel), accel: Array.from(s.accel) };
+    const cam = camera !== undefined ? camera : this.camera;
+    if (cam !== undefined && cam !== null) out.camera = cam;
+    out.G = (Math.log(this.G) / Math.LN10).toFixed(2);
+    return JSON.stringify(out);
   }
 
   /** util.js:217-263.  Unlike the reference, G takes effect on the next step (the
@@ -195,6 +198,7 @@ class Simulation {
     const state = { bodies: T.from(json.bodies), vel: T.from(json.vel), accel: json.accel ? T.from(json.accel) : null };
     if (!this._h || state.bodies.length !== 4 * this.nBodies) this.init(state); else this.restore(state);
     if (json.G !== undefined && json.G !== null) this.G = Math.pow(10, parseFloat(json.G));
+    this.camera = json.camera !== undefined ? json.camera : null;       // kept for exportJSON, never read by the engine
     return this;
   }
 

@@ -27,7 +27,6 @@ NB_FLAG_JPK_FENCED = 32
 NB_FLAG_NO_SYM = 64
 NB_FLAG_SYM_SHARD = 128
 NB_FLAG_WHOLE_SWEEPS = 256
-NB_FLAG_FULL_OWN_SWEEPS = 512
 NB_RCCL_ID_BYTES = 128
 NB_RCCL_OVERLAP = 1
 NB_MULTI_PEER, NB_MULTI_RCCL = 0, 1
@@ -61,7 +60,7 @@ class nb_plan_info(C.Structure):
         ("sym_plan", C.c_uint32 * 11), ("tab_len", C.c_uint32), ("variant", C.c_char * 112),
         ("sym_ups", C.c_uint32), ("sym_spill_rows", C.c_uint32), ("sym_rank_plan", C.c_uint32 * 16),
         ("sym_pass", C.c_uint32), ("sym_passes", C.c_uint32), ("sym_pass_k_lo", C.c_uint32), ("sym_pass_k_hi", C.c_uint32),
-        ("sym_pass_d0", C.c_uint32), ("sym_local", C.c_uint32), ("sym_tri", C.c_uint32)]
+        ("sym_pass_d0", C.c_uint32), ("sym_local", C.c_uint32)]
 
 
 class nb_step_timing(C.Structure):          # include/nbody3d_hip.h
@@ -247,7 +246,6 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
         out["ups"], out["spill_rows"] = int(info.sym_ups), int(info.sym_spill_rows)
         if info.symw:
             out["plan"]["ups"] = int(info.sym_ups)
-            out["plan"]["tri"] = int(info.sym_tri)
         if info.sym_ups > 1 and not info.sym_rank:
             # the spill rows (wave ranges cut inside sweeps): the spill row of every wave, {first row, count} per traveler chunk,
             # then the wave numbers in row order

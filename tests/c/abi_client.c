@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "nbody3d_hip.h"
+#include "nbody3d_hip_plan.h" /* planner introspection: not part of the drop-in surface, checked here because the library exports it */
 
 static float *load_f32(const char *dir, const char *name, size_t count)
 {
@@ -30,7 +31,7 @@ int main(int argc, char **argv)
     const uint32_t n = 1024;
     int fails = 0;
     printf("abi_version %u\n", nb_abi_version());
-    if (nb_abi_version() != NB_ABI_VERSION) { printf("FAIL abi version\n"); return 1; }
+    if (nb_abi_version() != NB_ABI_VERSION || nb_abi_minor() < NB_ABI_MINOR) { printf("FAIL abi version\n"); return 1; }
 
     nb_config cfg;
     memset(&cfg, 0, sizeof cfg);

@@ -88,6 +88,12 @@ if (mode === 'cpu') {
   check('reference_schema_import', Math.abs(sim3.G - 1e-4) < 1e-18 && sim3.nBodies === 1024);
   sim3.step(); const after = sim3.read();
   check('reference_schema_steps', isFinite(after.bodies[0]) && after.accel[3] === 0);
+  // ... and the camera block comes back out untouched (browser -> engine -> browser keeps the view, util.js:190-199,246-256),
+  // in the reference's key order (bodies, vel, accel, camera, G); a state that never had one exports none
+  const back = JSON.parse(sim3.exportJSON());
+  check('camera_block_passes_through', JSON.stringify(back.camera) === JSON.stringify(refJson.camera) && back.G === '-4.00' &&
+    JSON.stringify(Object.keys(back)) === JSON.stringify(['bodies', 'vel', 'accel', 'camera', 'G']), Object.keys(back));
+  check('no_camera_no_block', JSON.parse(json).camera === undefined);
   sim3.destroy();
   // wrong array length is an error, not a crash
   check('bad_length_throws', throws(function () { sim.restore({ bodies: new Float32Array(8), vel: new Float32Array(8) }); }, /expected/));

@@ -3,11 +3,15 @@ header declares, and fails loudly (no CPU fallback) when there is no device."""
 import ctypes as C
 import os
 import re
+import shutil
+import subprocess
 
 import pytest
 
 from conftest import ROOT, have_gpu
 from nbody3d_amd import capi
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "nbody3d-webgpu_amd", "csrc")
 
 
 def header_symbols():
@@ -82,3 +86,15 @@ def test_bench_multi_gpu_self_launch_fails_cleanly_without_gpus():
     assert p.returncode != 0
     assert "no GPU visible" in (p.stderr + p.stdout), (p.stderr + p.stdout)[-1500:]
     assert not any(l.startswith("{") for l in p.stdout.splitlines())
+
+
+def test_release_library_reads_no_model_knobs_from_the_environment():
+    """VERDICT round 2: choose_shape called getenv("NB_MODEL_*") on every nb_create.  The constants are compiled in now;
+    only the -DNB_TUNING calibration build (make tuning; tools/fit_model.py, fault injection) knows those names."""
+    rel = open(os.path.join(CSRC, "libnbody3d_hip.so"), "rb").read()
+    assert b"NB_MODEL_" not in rel and b"NB_TEST_FAIL" not in rel
+    tun = os.path.join(CSRC, "libnbody3d_hip_tuning.so")
+    if not os.path.exists(tun):
+        subprocess.check_call(["make", "-C", CSRC, "-s", "tuning"])
+    blob = open(tun, "rb").read()
+    assert b"NB_MODEL_BOUNDARY" in blob and b"NB_TEST_FAIL_FRAME_SLOT" in blob

@@ -165,3 +165,31 @@ def test_sharded_and_f64_handles_never_take_the_pair_kernel():
         assert "jpairs" not in s.variant and s.variant.startswith("f64"), s.variant
     with Simulation(n, force_variant=code(8), flags=capi.NB_FLAG_NO_FUSE) as s:
         assert "jpairs" not in s.variant, s.variant
+
+
+@pytest.mark.parametrize("n,jsplit", [(8192, 4), (10000, 0)])
+def test_jpk_fenced_fallback_is_bit_identical(n, jsplit):
+    """NB_FLAG_JPK_FENCED: plain partial stores + an agent-scope release on the ticket instead of write-through stores +
+    a relaxed ticket -- the conservative fallback for parts / partition modes where the sc1 sequence might not hold."""
+    b, v = ic.plummer(n, seed=76)
+    fast = run(b, v, 40, force_variant=601018, jsplit=jsplit)
+    safe = run(b, v, 40, force_variant=601018, jsplit=jsplit, flags=capi.NB_FLAG_JPK_FENCED)
+    assert "jpairs" in fast[3] and fast[3] == safe[3]
+    for x, y in zip(fast[:3], safe[:3]):
+        assert x.tobytes() == y.tobytes(), fast[3]
+
+
+def test_default_shape_at_an_auto_selected_jpk_size_with_poisoned_partials():
+    """validate the DEFAULT path itself, not only pinned variants -- N = 9,000 with no shape pin lands on
+    the j-packed step with a split across workgroups (from N ~ 10,000 the default is the symmetric pass); 400 steps through graph
+    replay with every consumed partial overwritten by NaN: finite, and bit-identical to the unpoisoned and to the fenced run."""
+    n = 9000
+    b, v = ic.plummer(n, seed=77)
+    p = run(b, v, 400, flags=capi.NB_FLAG_POISON)
+    q = run(b, v, 400)
+    r = run(b, v, 400, flags=capi.NB_FLAG_JPK_FENCED)
+    assert "jpairs" in q[3] and "_js1" != q[3][-4:], q[3]
+    for a in p[:3]:
+        assert np.isfinite(a).all(), p[3]
+    for x, y, z in zip(p[:3], q[:3], r[:3]):
+        assert x.tobytes() == y.tobytes() == z.tobytes(), q[3]

@@ -12,36 +12,7 @@ import pytest
 
 from nbody3d_amd import capi
 
-NB_FLAG_NO_SYM, NB_FLAG_SYM_SHARD, NB_FLAG_WHOLE_SWEEPS, NB_FLAG_FULL_OWN_SWEEPS = 64, 128, 256, 512
-
-
-def own_sweep_cost(ipl, c):
-    """nb_plan.cpp::own_sweep_cost for the triangular sweep over own chunk c: packed groups c // 2 .. NG - 1, 80 issue cycles each
-    (+25 % per chain missing from four) + 44 for rotations and mask, on the scale where a both-sides sweep (NG * 80 + 40) is 64."""
-    NG = ipl / 2.0
-    m = NG - c // 2
-    chains = 1.0 + 0.25 * (4.0 - m) if m < 4 else 1.0
-    return int(max(1, min(64, np.floor(64 * (m * 80.0 * chains + 44.0) / (NG * 80.0 + 40.0) + 0.5))))
-
-
-def triangular_rows(cps, c):
-    """What the kernel's triangular sweep over own chunk c evaluates (kernels/symmetric.hip.h, `steps` with P0 = c // 2): the resident
-    rows r > c from BOTH sides, row r = c resident-only, rows r < c not at all.  Returns (both-sides rows, resident-only rows)."""
-    p0, odd = c // 2, c & 1
-    both, res = [], []
-    for grp in range(p0, cps // 2):
-        for half in (0, 1):
-            r = 2 * grp + half
-            if grp == p0:
-                # the mass factors of group P0: c odd -> the x half (row 2 P0) is switched off on both sides, the y half (row c) resident-only;
-                # c even -> the x half (row c) resident-only, the y half (row c + 1) both sides
-                if odd:
-                    (res if half == 1 else []).append(r)
-                else:
-                    (res if half == 0 else both).append(r)
-            else:
-                both.append(r)
-    return both, res
+NB_FLAG_NO_SYM, NB_FLAG_SYM_SHARD, NB_FLAG_WHOLE_SWEEPS = 64, 128, 256
 
 
 def walk_symw(q, n):
@@ -84,19 +55,14 @@ def walk_symw(q, n):
     Lu = L * ups
     starts = q["starts"].astype(np.int64)
     assert len(starts) == W + 1 and starts[0] == 0 and starts[-1] == Lu and W <= Lu and np.diff(starts).min() >= 1
-    # (a sweep that keeps traveler sums counts 64; one over an own chunk 56 -- resident-only against every row -- or, in the triangular
-    # form of the f32 pass with one traveler per lane, its share of the packed groups: own_sweep_cost below = nb_plan.cpp's)
-    tri = bool(pl.get("tri", 0))
-    assert tri == (J == 1 and q["variant"].startswith("f32") and not (q.get("flags", 0) & NB_FLAG_FULL_OWN_SWEEPS))
-    own_cost = np.where((g < nsb) & tri, np.array([own_sweep_cost(q["ipl"], int(cc)) for cc in range(cps)], np.int64)[np.minimum(c, cps - 1)], 56 if ups > 1 else 64)
-    work = np.repeat(np.where(sym, 64, own_cost).astype(np.int64), ups)              # per unit (whole sweeps, old form: an even cut)
+    work = np.repeat(np.where(sym, 8, 7 if ups > 1 else 8).astype(np.int64), ups)              # per unit (whole sweeps: an even cut)
     per_wave = np.add.reduceat(work, starts[:-1])
-    assert per_wave.sum() == work.sum() and per_wave.max() - per_wave.min() <= 128, (per_wave.min(), per_wave.max())
+    assert per_wave.sum() == work.sum() and per_wave.max() - per_wave.min() <= 16, (per_wave.min(), per_wave.max())
     wu = np.searchsorted(starts, np.arange(Lu, dtype=np.int64), side="right") - 1               # the wave of every unit
     assert np.all((wu >= 0) & (wu < W))
     w = wu[::ups]                                # the wave that starts each sweep (steps from 0): it owns the sweep's traveler layer / z-row
     w_last = wu[ups - 1::ups]                    # ... and the one that ends it
-    return dict(S=S, CH=CH, cps=cps, nsb=nsb, blocks=blocks, zc=zc, H=H, n_hi=n_hi, g=g, k=k, sym=sym, ringsw=ringsw, zsw=zsw, d=d, tb=tb, c=c, tri=tri,
+    return dict(S=S, CH=CH, cps=cps, nsb=nsb, blocks=blocks, zc=zc, H=H, n_hi=n_hi, g=g, k=k, sym=sym, ringsw=ringsw, zsw=zsw, d=d, tb=tb, c=c,
                 tstart=tstart, w=w, w_last=w_last, wu=wu, starts=starts, ups=ups, pl=pl, tab=tab)
 
 
@@ -151,22 +117,10 @@ def check_whole_plan(q, n):
     zv = np.zeros((nsb, max(zc, 1)), np.int32)
     np.add.at(zv, (g[zsw], c[zsw]), 1)
     assert zsw.sum() == nsb * zc and (zc == 0 or np.all(zv == 1)) and np.all(tb[zsw] == nsb)
-    # (2) pairs INSIDE a block: its own chunks once each (Z: its zc real ones) -- resident-only against every resident row, or
-    #     (triangular form) chunk c against the rows r > c from both sides and row c resident-only: every unordered pair of rows of a
-    #     super-block exactly once, every row's own chunk resident-only exactly once
+    # (2) pairs INSIDE a block: its own chunks once each (Z: its zc real ones), resident-only
     own = np.zeros((blocks, cps), np.int32)
     np.add.at(own, (g[~sym], c[~sym]), 1)
     assert np.all(own[:nsb] == 1) and np.all(tb[~sym] == g[~sym])
-    if wk["tri"]:
-        assert wk["CH"] == 64                                  # chunk c IS resident row c
-        met = np.zeros((cps, cps), np.int32)                   # met[a, b]: times the unordered row pair {a, b} is evaluated (a <= b)
-        for cc in range(cps):
-            both_rows, res_rows = triangular_rows(cps, cc)
-            assert res_rows == [cc] and all(r > cc for r in both_rows)
-            for r in both_rows:
-                met[cc, r] += 1
-            met[cc, cc] += 1
-        assert np.all(met[np.triu_indices(cps)] == 1)
     if zc:
         assert np.all(own[nsb, :zc] == 1) and np.all(own[nsb, zc:] == 0)
     # (3) ring distances stay inside the traveler layers
@@ -226,9 +180,6 @@ def test_pinned_wave_granular_plans(variant, n, jsplit):
     whole = capi.plan_query(n, force_variant=variant, jsplit=jsplit, flags=NB_FLAG_WHOLE_SWEEPS)       # the A/B arm: whole sweeps per wave
     assert whole["ups"] == 1 and "_u" not in whole["variant"].rsplit("_r", 1)[1]
     check_whole_plan(whole, n)
-    full = capi.plan_query(n, force_variant=variant, jsplit=jsplit, flags=NB_FLAG_FULL_OWN_SWEEPS)    # the A/B arm: own chunks against every row
-    assert full["plan"]["tri"] == 0 and q["plan"]["tri"] == (1 if variant % 10 == 3 else 0)
-    check_whole_plan(full, n)
 
 
 @pytest.mark.parametrize("n", [40002, 262144])
@@ -491,3 +442,62 @@ def test_planner_under_address_and_ub_sanitizers(tmp_path):
     assert cc.returncode == 0, cc.stderr[-2000:]
     run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1"))
     assert run.returncode == 0 and "under ASan + UBSan" in run.stdout, run.stdout[-1000:] + run.stderr[-3000:]
+
+
+def _sym_plan(nsb, cps):
+    H = (nsb - 1) // 2
+    n_hi = 0 if nsb & 1 else nsb // 2
+    total_hi, total_lo = (H + 1 + (1 if n_hi else 0)) * cps, (H + 1) * cps
+    off = lambda g: g * total_hi if g <= n_hi else n_hi * total_hi + (g - n_hi) * total_lo      # noqa: E731
+    return H, n_hi, total_hi, total_lo, off
+
+
+@pytest.mark.parametrize("nsb,ranks,waves", [(2, 1, 4), (3, 1, 5), (8, 2, 7), (9, 3, 16), (16, 4, 12), (40, 8, 64), (41, 1, 100), (64, 8, 33)])
+def test_symmetric_pass_partition_covers_every_pair_of_super_blocks_exactly_once(nsb, ranks, waves):
+    """The index arithmetic of nb_force_symw / plan_launch (csrc/nb_kernels.hip.h, nb_plan.cpp), restated (tests/test_planner_cpu.py walks the planner's own output): super-blocks on a
+    ring; super-block g sweeps the chunks of the H = (nsb-1)/2 super-blocks after it (and of the antipodal one when nsb is even
+    and g < nsb/2), then its own in resident-only mode.  Rank r owns the super-blocks [r*nsb/ranks, (r+1)*nsb/ranks) and its
+    waves cut THEIR lists, laid end to end, into floor/ceil-equal ranges.  Every unordered pair of different super-blocks must be
+    swept by exactly one (rank, wave), every super-block's own block exactly once, every chunk exactly once."""
+    cps = 4
+    H, n_hi, total_hi, total_lo, off = _sym_plan(nsb, cps)
+    if nsb % ranks:
+        pytest.skip("ranks own whole super-blocks")
+    seen_pairs, seen_diag, seen_chunks = {}, {}, set()
+    for r in range(ranks):
+        g0, g1 = r * nsb // ranks, (r + 1) * nsb // ranks
+        p0, L = off(g0), off(g1) - off(g0)
+        W = min(waves, L)
+        for w in range(W):
+            p, pend = p0 + w * L // W, p0 + (w + 1) * L // W
+            while p < pend:
+                first_lo = n_hi * total_hi
+                if p < first_lo:
+                    g, total = p // total_hi, total_hi
+                    k = p - g * total_hi
+                else:
+                    g = n_hi + (p - first_lo) // total_lo
+                    total = total_lo
+                    k = (p - first_lo) - (g - n_hi) * total_lo
+                assert g0 <= g < g1                                  # a rank never touches another rank's lists
+                ring = total - cps
+                kend = min(k + (pend - p), total)
+                for kk in range(k, kend):
+                    if kk < ring:
+                        d = kk // cps
+                        tb = (g + 1 + d) % nsb
+                        assert d <= H and tb != g
+                        seen_pairs[(frozenset((g, tb)), kk % cps)] = seen_pairs.get((frozenset((g, tb)), kk % cps), 0) + 1
+                    else:
+                        seen_diag[(g, kk - ring)] = seen_diag.get((g, kk - ring), 0) + 1
+                    assert (g, kk) not in seen_chunks
+                    seen_chunks.add((g, kk))
+                p += kend - k
+    # every unordered pair {a, b}, a != b: all cps traveler chunks of one of the two, swept by the OTHER one, exactly once
+    for a in range(nsb):
+        for b in range(a + 1, nsb):
+            for c in range(cps):
+                assert seen_pairs.get((frozenset((a, b)), c), 0) == 1, (a, b, c)
+    assert len(seen_pairs) == nsb * (nsb - 1) // 2 * cps
+    assert all(v == 1 for v in seen_diag.values()) and len(seen_diag) == nsb * cps
+    assert len(seen_chunks) == n_hi * total_hi + (nsb - n_hi) * total_lo

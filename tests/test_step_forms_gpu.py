@@ -1,11 +1,7 @@
-"""GPU tests of the round-2 paths, all through the C ABI:
-
-  * the fused one-launch step (ping-pong positions) against the two-kernel step, bit for bit;
-  * every fp64 launch shape against the fp64 oracle (BASELINE.json config 5), full size included;
-  * the native RCCL collective: nb_multi in RCCL mode and nb_rccl_attach with one rank
-    (one GPU is all a test box has; the partition/offset logic is covered by the
-    virtual-shard and gloo tests), and bench.py's distributed path;
-  * the viewer frame feed; the integrate kernel on its own.
+"""GPU tests of the step FORMS, through the C ABI: the fused one-launch step (ping-pong positions: nb_step_fused / nb_step_direct,
+SURVEY.md §8 f3) against the two-kernel step, bit for bit; the ordered-pair fp64 launch shapes against the fp64 oracle (BASELINE
+config 5's arithmetic; the symmetric fp64 pass is in test_sym_gpu.py); the integrate kernel on its own; which form the planner
+picks by size; what a whole-system handle reports about its shape.
 """
 import json
 import os
@@ -15,13 +11,13 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, load_golden32, load_golden64, rel_pos_err
+from conftest import GOLDEN, ROOT, load_golden32, load_golden64, rel_pos_err
 from oracle import oracle
 from nbody3d_amd import MultiSimulation, Simulation, capi, ic
 
 pytestmark = pytest.mark.gpu
 
-TOL_ACC = 2e-5
+TOL_ACC, TOL_TIGHT = 2e-5, 2e-5
 TOL_F64 = 1e-12
 
 
@@ -161,174 +157,6 @@ def test_f64_full_size_properties():
     assert np.abs(fa[:, :3] - aa[:, :3]).max() < TOL_ACC * np.abs(aa[:, :3]).max(), fname
 
 
-# ---- native RCCL ------------------------------------------------------------------------------
-
-def test_multi_handle_rccl_mode_one_device():
-    """nb_multi in NB_MULTI_RCCL mode with one shard on the one GPU of the box: ncclCommInitAll,
-    ncclGroupStart / in-place ncclAllGather / ncclGroupEnd every step -- the calls an 8-GPU
-    node makes -- bit-identical to the peer-copy mode and to a plain handle."""
-    n, steps = 4096, 6
-    b, v = ic.plummer(n, seed=51)
-    kw = dict(force_variant=28, jsplit=4)
-    with Simulation(n, **kw) as one:
-        one.init(b, v)
-        one.simulate(steps, 1e-3, 1.0)
-        ref = one.read()
-    with MultiSimulation(n, 1, collective="rccl", **kw) as ms:
-        info = ms.collective_info()
-        assert info["mode"] == "rccl" and info["nranks"] == 1 and info["rccl_version"] > 20000, info
-        ms.init(b, v)
-        ms.simulate(steps, 1e-3, 1.0)
-        got = ms.read()
-        ms.set_collective("peer")
-        assert ms.collective_info() == {"mode": "peer", "nranks": 0, "rccl_version": 0}
-        ms.simulate(2)
-        ms.set_collective("rccl")
-        ms.simulate(2)
-        later = ms.read()
-    for x, y in zip(got, ref):
-        assert x.tobytes() == y.tobytes()
-    rb, _, _ = oracle.run_f32(b, v, None, 1e-3, 1.0, steps + 4)
-    assert rel_pos_err(later[0], rb, 1.0) < 1e-6
-
-
-def test_multi_handle_rccl_mode_refuses_shared_devices():
-    b, v = ic.plummer(1024, seed=52)
-    with MultiSimulation(1024, 2) as ms:             # two shards on the one GPU: fine for peer copies
-        with pytest.raises(Exception) as e:
-            ms.set_collective("rccl")
-        assert "own device" in str(e.value)
-        ms.init(b, v)
-        ms.simulate(3, 1e-3, 1.0)                    # still usable in peer mode
-        rb, _, _ = oracle.run_f32(b, v, None, 1e-3, 1.0, 3)
-        assert rel_pos_err(ms.read()[0], rb, 1.0) < 1e-6
-
-
-@pytest.mark.parametrize("overlap", [False, True])
-def test_rccl_attach_single_rank(overlap):
-    """nb_rccl_attach: the engine's own in-place ncclAllGather after every integrate kernel
-    (one process per GPU).  One rank here; results equal the handle without a communicator."""
-    n, steps = 8192, 5
-    b, v = ic.plummer(n, seed=53)
-    kw = dict(force_variant=308014, jsplit=4, flags=capi.NB_FLAG_NO_FUSE)
-    with Simulation(n, **kw) as one:
-        one.init(b, v)
-        one.simulate(steps, 1e-3, 1.0)
-        ref = one.read()
-    with Simulation(n, shard=(0, n), **kw) as sim:
-        uid = capi.rccl_unique_id()
-        assert len(uid) == 128 and any(uid)
-        sim.rccl_attach(uid, 1, 0, overlap=overlap)
-        nranks, rank, ver = sim.rccl_info()
-        assert (nranks, rank) == (1, 0) and ver > 20000
-        with pytest.raises(Exception):
-            sim.set_exchange(lambda *a: 0)           # hook and native collective are exclusive
-        sim.init(b, v)
-        sim.enable_timing(True)
-        sim.simulate(steps, 1e-3, 1.0)
-        f_ms, i_ms, x_ms, launches = sim.step_times()
-        got = sim.read()
-        assert launches == steps and f_ms > 0 and i_ms > 0
-        if not overlap:
-            assert x_ms > 0
-        sim.rccl_detach()
-        assert sim.rccl_info() == (0, 0, 0)
-    for x, y in zip(got, ref):
-        assert x.tobytes() == y.tobytes()
-
-
-def test_rccl_attach_checks_the_partition():
-    with Simulation(1024, shard=(256, 256)) as sim:
-        uid = capi.rccl_unique_id()
-        with pytest.raises(Exception) as e:
-            sim.rccl_attach(uid, 1, 0)               # 1 rank must own all rows
-        assert "NB_ERR_INVALID" in str(e.value)
-
-
-def _bench(*args, env=None, timeout=600):
-    e = dict(os.environ)
-    e.update(env or {})
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + list(args), capture_output=True, text=True,
-                       timeout=timeout, env=e)
-    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
-    return p, (json.loads(lines[-1]) if lines else None)
-
-
-@pytest.mark.parametrize("exchange", ["native", "torch"])
-def test_bench_distributed_path_with_one_rank(exchange):
-    """bench.py --force-dist: process group on the nccl (= RCCL) backend, sharded handle on torch's
-    stream, per-step all-gather (the engine's own ncclAllGather, or torch's through the hook)."""
-    p, out = _bench("--force-dist", "--exchange", exchange, "--nbodies", "16384", "--steps", "4", "--warmup", "1",
-                    "--no-cpu-baseline")
-    assert p.returncode == 0 and out, p.stderr[-2000:]
-    assert out["n_gpus"] == 1 and out["value"] > 0
-    assert out["exchange"]["kind"].startswith("rccl-native" if exchange == "native" else "torch"), out["exchange"]
-    if exchange == "native":
-        assert out["exchange"]["rccl_nranks"] == 1 and out["exchange"]["avg_ms"] > 0
-    assert out["check"]["pass"], out["check"]
-
-
-def test_bench_multi_gpu_launches_its_own_ranks():
-    """`python bench.py --gpus 2` with no launcher: the GPU-free parent starts the two ranks
-    itself.  On a one-GPU box they must get as far as the device count and fail there."""
-    p, out = _bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", timeout=300)
-    if capi.device_count() >= 2:
-        assert p.returncode == 0 and out and out["n_gpus"] == 2
-    else:
-        assert p.returncode != 0 and out is None
-        assert "2 ranks need 2 GPUs" in (p.stderr + p.stdout), (p.stderr + p.stdout)[-1500:]
-
-
-def test_bench_two_rank_control_flow_rehearsal():
-    """The complete multi-rank flow of bench.py -- self-started ranks, shard plan, per-rank gates,
-    replica agreement, max-over-ranks timing -- with two ranks SHARING the one GPU (exchange staged
-    through host memory over gloo: RCCL refuses two ranks on one device).  Marked REHEARSAL in the
-    line; the sharded state must equal an unsharded run."""
-    p, out = _bench("--gpus", "2", "--exchange", "host", "--nbodies", "16384", "--steps", "3", "--warmup", "2",
-                    "--no-cpu-baseline", timeout=600)
-    assert p.returncode == 0 and out, (p.stderr + p.stdout)[-2000:]
-    assert out["n_gpus"] == 2 and "REHEARSAL" in out and out["value"] > 0
-    assert out["replica_check"]["pass"] and out["shape_check"]["pass"] and out["check"]["pass"]
-    assert out["rehearsal_max_rel_diff_vs_unsharded"] < 1e-6
-    assert out["per_rank"]["rows"] == 8192 and out["exchange"]["bytes_sent_per_rank"] == 8192 * 16
-
-
-# ---- frame feed, integrate pass ----------------------------------------------------------------
-
-@pytest.mark.parametrize("precision", ["f32", "f64"])
-def test_frame_feed_values_equal_read(precision):
-    """nb_frame_request / nb_frame_acquire: the snapshot taken after step k equals read() at
-    step k (f32 bodies + length(vel.xyz), nbody3d.js:380), however many steps follow it."""
-    n = 3000
-    b, v = ic.plummer(n, seed=61)
-    dt = np.float64 if precision == "f64" else np.float32
-    with Simulation(n, precision=precision) as sim:
-        sim.init(b.astype(dt), v.astype(dt))
-        sim.set_params(1e-3, 1.0)
-        with pytest.raises(Exception) as e:
-            sim.frame(wait=False)                          # nothing requested yet
-        assert "NB_ERR_STATE" in str(e.value)
-        done = 0
-        for k in (3, 1, 4):
-            sim.simulate(k)
-            done += k
-            sim.request_frame()
-            sim.simulate(2)                                # later steps must not disturb the snapshot
-            done += 2
-            fb, fs, step = sim.frame(wait=True)
-            assert step == done - 2
-            fb, fs = fb.copy(), fs.copy()
-    with Simulation(n, precision=precision) as ref:
-        ref.init(b.astype(dt), v.astype(dt))
-        ref.simulate(done - 2, 1e-3, 1.0)
-        rb, rv, _ = ref.read()
-    assert fb.dtype == np.float32 and fs.dtype == np.float32
-    assert np.array_equal(fb, rb.astype(np.float32))
-    rv32 = rv[:, :3].astype(np.float32)
-    want = np.sqrt(rv32[:, 0] * rv32[:, 0] + rv32[:, 1] * rv32[:, 1] + rv32[:, 2] * rv32[:, 2])
-    assert np.allclose(fs, want, rtol=2e-6, atol=0)
-
-
 def test_integrate_pass_measures_the_integrator_alone():
     n = 1 << 20
     b, v = ic.uniform_cube(n, seed=63)
@@ -363,3 +191,24 @@ def test_default_launch_shape_family_by_size(n, family, classic):
             assert classic in s.variant and "sym" not in s.variant, (n, s.variant)
     with Simulation(n, shard=(0, (n // 2 + 255) // 256 * 256 if n > 512 else n)) as s:      # a rank's shard never fuses, nor pairs up symmetrically
         assert "fused" not in s.variant and "sym" not in s.variant, (n, s.variant)
+
+
+def test_shape_info_of_a_whole_system_handle():
+    with Simulation(262144) as s:
+        info = s.shape_info()
+        assert info["jsplit"] >= 1 and info["own_splits"] == 0 and "symw" in s.variant
+    with Simulation(262144, flags=capi.NB_FLAG_NO_SYM) as s:
+        info = s.shape_info()
+        assert info["jsplit"] >= 1 and info["own_splits"] == 0 and "_js%d" % info["jsplit"] in s.variant
+        assert info["j_per_split"] * info["jsplit"] >= 262144
+    with Simulation(4096) as s:
+        assert s.shape_info()["own_splits"] == 0
+
+
+@pytest.mark.parametrize("n,prec", [(1000, "f32"), (5000, "f32"), (12000, "f32"), (16384, "f32"), (40002, "f32"), (100000, "f32"), (40002, "f64")])
+def test_plan_query_is_what_create_builds(n, prec):
+    """nb_plan_query (the planner on the host alone, tests/test_planner_cpu.py) and nb_create agree on this device."""
+    q = capi.plan_query(n, precision=prec, n_cu=0, clock_hz=0)
+    with Simulation(n, precision=prec) as sim:
+        assert sim.variant == q["variant"]
+        assert sim.shape_info() == {k: q[k] for k in ("jsplit", "j_per_split", "own_split0", "own_splits")}
