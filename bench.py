@@ -616,6 +616,8 @@ def main():
                                "reduce_scatter_avg_ms": parts["reduce_scatter_ms"], "integrate_kernel_avg_ms": parts["integrate_ms"],
                                "allgather_avg_ms": parts["allgather_ms"], "exchange_avg_ms": parts["allgather_ms"] + parts["reduce_scatter_ms"],
                                "sum_of_parts_ms": total, "span_ms": parts["span_ms"], "ms_per_step": ms_step,
+                               # the parts and the span come from the event-timed leg, ms_per_step from the wall-timed one before it
+                               "sum_of_parts_over_span": total / parts["span_ms"] if parts["span_ms"] > 0 else None,
                                "sum_of_parts_over_ms_per_step": total / ms_step if ms_step > 0 else None,
                                "max_over_ranks": dict(zip(names, [float(v) for v in tmax.tolist()]))}
         if rehearsal and rank == 0:   # the sharded state must equal an unsharded run of the same number of steps

@@ -451,6 +451,11 @@ __device__ __forceinline__ double wave_rot1(double v)
     return __builtin_bit_cast(double, (long long)(((unsigned long long)rhi << 32) | rlo));
 }
 
+// (Tried in round 5 and dropped: IPL = 16 -- the 14 rotations of a step shared by twice the pairs, (16 * 92 + 56) issue cycles per 1,024
+// unordered pairs = a ceiling of 83.8 % of the fp64 vector rate against 80.8 % -- which needs 16 x 14 registers of residents, i.e. ONE
+// wave per SIMD: N = 262,144 ran 24.7 ms against 24.0 with 8 residents and two waves per SIMD (8 residents and one wave: 24.7 too;
+// profiles/r05/f64_16_residents_one_wave_per_simd_ab.txt).  The loop below already issues at its count: 80.8 % x the 2.17 of 2.4 GHz the
+// chip holds under this load = 73 %, what it measures.)
 template <int IPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __restrict__ partial, const uint32_t* __restrict__ gtab,

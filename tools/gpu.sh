@@ -1,7 +1,7 @@
 #!/bin/bash
 # One parametrised GPU pass (replaces round 2's fourteen one-off gpu_*.sh scripts).  Run through gpurun:
 #   gpurun --timeout 1100 -- 'bash tools/gpu.sh tests bench'
-# Legs, in the order given: tests [pytest args] | new (only tests/test_round3_gpu.py) | smoke | bench | sizes N... | shapes N... |
+# Legs, in the order given: tests [pytest args] | new (only the test files named in NB_NEW_TESTS) | smoke | bench | sizes N... | shapes N... |
 # prof (rocprofv3 kernel trace + PMC passes of the default bench line).  A leg that times out stops the pass:
 # no further GPU step is started after a kill.
 set -u
@@ -17,7 +17,7 @@ while [ $# -gt 0 ]; do
   leg=$1; shift
   case $leg in
     tests) step pytest_gpu 1100 python -m pytest tests -m gpu -x -q --durations=15; tail -25 gpurun_out/pytest_gpu.txt ;;
-    new)   step pytest_new 900 python -m pytest tests/test_round3_gpu.py -m gpu -x -q --durations=10; tail -25 gpurun_out/pytest_new.txt ;;
+    new)   step pytest_new 900 python -m pytest ${NB_NEW_TESTS:-tests/test_sym_gpu.py} -m gpu -x -q --durations=10; tail -25 gpurun_out/pytest_new.txt ;;
     smoke) step smoke 300 python __graft_entry__.py smoke; tail -2 gpurun_out/smoke.txt ;;
     bench) step bench 600 python bench.py; tail -1 gpurun_out/bench.txt | cut -c1-3000 ;;
     sizes) args=(); while [ $# -gt 0 ] && [[ $1 =~ ^[0-9]+$ ]]; do args+=("$1"); shift; done
