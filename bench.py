@@ -624,7 +624,7 @@ def main():
             got = sim.read(vel=False, accel=False)[0][:n]
             with Simulation(n, precision=args.precision, device=local_rank) as ref:
                 ref.init(bodies.astype(np_dtype), vel.astype(np_dtype))
-                ref.simulate(max(args.warmup, 1) + args.steps, dt, G)
+                ref.simulate(max(args.warmup, 1) + 2 * args.steps, dt, G)      # gate + warm-up, the wall-timed leg, the event-timed leg
                 want = ref.read(vel=False, accel=False)[0]
             res["rehearsal_max_rel_diff_vs_unsharded"] = float(np.abs(got[:, :3] - want[:, :3]).max() / np.abs(want[:, :3]).max())
         return res, sim
@@ -702,7 +702,7 @@ def main():
         _, pe_prev, _ = sim.diagnostics()
         sim.step()
         ke, _, _ = sim.diagnostics()
-        out["energy_drift_over_run"] = {"steps": max(args.warmup, 1) + args.steps + 1,
+        out["energy_drift_over_run"] = {"steps": max(args.warmup, 1) + 2 * args.steps + 1,
                                         "dE_rel": abs((ke + pe_prev - main_res["e_start"]) / main_res["e_start"])}
     sim.close()
     ok = main_res["shape_ok"] and main_res["replicas_ok"]

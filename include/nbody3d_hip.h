@@ -41,7 +41,7 @@ extern "C" {
 #define NB_ABI_MINOR 3u   /* additions within major 2; a client needs nb_abi_minor() >= the minor it was written against:
                              2.1 (round 3)  nb_force_pass, nb_frame_request / nb_frame_acquire, nb_shape_info, NB_FLAG_SYM_SHARD
                              2.2 (round 4)  nb_step_times2, nb_plan_query, NB_FLAG_WHOLE_SWEEPS, nb_config.layer_budget_mib
-                             2.3 (round 5)  nb_abi_minor; nb_plan_info / nb_plan_query moved to nbody3d_hip_plan.h; force_variant 7 II LL 3 takes LL up to 64 */
+                             2.3 (round 5)  nb_abi_minor, NB_MULTI_PEER_OVERLAP; nb_plan_info / nb_plan_query moved to nbody3d_hip_plan.h; force_variant 7 II LL 3 takes LL up to 64 */
 
 typedef struct nb_sim nb_sim; /* opaque */
 
@@ -275,8 +275,14 @@ const char *nb_multi_variant_name(nb_multi *m);
  *   NB_MULTI_RCCL  ncclCommInitAll over the shards' devices once, then per step
  *                  ncclGroupStart / in-place ncclAllGather on every shard's stream / ncclGroupEnd
  *                  (SURVEY.md §8(e)).  Needs every shard on its own device.
+ *   NB_MULTI_PEER_OVERLAP  (ABI 2.3; rank form of the symmetric pass with pull kernels) the all-gather pull of step n runs on a
+ *                  second stream per shard while step n + 1 sweeps the pairs whose travelers are the shard's own rows; the shard's
+ *                  stream waits for its pull only in front of the sweeps that read the other shards' rows -- what NB_RCCL_OVERLAP
+ *                  does across processes, here with real rows in flight between g shards (also g virtual shards on ONE device:
+ *                  the multi-rank check of the overlapped protocol a one-GPU box can run).  Falls back to NB_MULTI_PEER's order
+ *                  when the handle is not in the rank form or G != 1.
  * Results are bit-identical; the choice is a measured A/B. */
-typedef enum nb_multi_collective { NB_MULTI_PEER = 0, NB_MULTI_RCCL = 1 } nb_multi_collective;
+typedef enum nb_multi_collective { NB_MULTI_PEER = 0, NB_MULTI_RCCL = 1, NB_MULTI_PEER_OVERLAP = 2 } nb_multi_collective;
 int nb_multi_set_collective(nb_multi *m, int mode /* nb_multi_collective */);
 /* mode in use, communicator size (0 for NB_MULTI_PEER), RCCL version code. */
 int nb_multi_collective_info(nb_multi *m, int *mode, int *nranks, int *rccl_version);

@@ -148,7 +148,7 @@ def process(src_lines, dis):
             return inserted, wide
         need, wide_in_loops = walk(None)
         loop_instr = sum(1 for li in in_loop if li in size_of)
-        fp64 = any("_f64" in body[li].split(";")[0].split()[0] for li in in_loop if li in size_of)
+        fp64 = not os.environ.get("NB_ALIGN_F64") and any("_f64" in body[li].split(";")[0].split()[0] for li in in_loop if li in size_of)      # (NB_ALIGN_F64=1: the A/B arm that aligns them too)
         # The density test counts a function's INNERMOST loops when the whole function fails it: a cold block of an outer loop (the
         # LDS flush of nb_force_symw's resident sums: 96 ds_read / ds_write among 32-bit adds, run once per 4,096 rotation steps) must
         # not leave the rotation loops next to it unaligned.

@@ -273,6 +273,11 @@ struct nb_multi {
     hipStream_t hub = nullptr;
     hipEvent_t ev_hub[4] = {nullptr, nullptr, nullptr, nullptr};   // 0: sym_A complete, 1: sym_A consumed, 2: rows written, 3: rows gathered
     int mode = NB_MULTI_PEER;
+    // NB_MULTI_PEER_OVERLAP: the gather pull of a step runs on xs[e]; shard e's own stream waits for ev_copied[e] only in front of
+    // the sweeps that read the other shards' rows (the shard handle's exchange-wait hook, armed per step)
+    std::vector<hipStream_t> xs;
+    struct Wait { hipEvent_t ev; };
+    std::vector<Wait> waits;
     std::vector<ncclComm_t> comms;               // NB_MULTI_RCCL: one per shard (ncclCommInitAll)
     std::vector<char> pad_b, pad_v, pad_a;       // host staging for the zero-mass padding rows
     std::string err;
@@ -289,6 +294,26 @@ int mfail(nb_multi* m, int code, const std::string& msg) { if (m) m->err = msg; 
         hipError_t e_ = (call);                                                                       \
         if (e_ != hipSuccess) return mfail((m), NB_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
+
+// the shard handle's exchange-wait hook in NB_MULTI_PEER_OVERLAP: the engine stream waits for this shard's gather pull
+int multi_gather_wait(void* user, void* stream)
+{
+    const nb_multi::Wait* w = (const nb_multi::Wait*)user;
+    return hipStreamWaitEvent((hipStream_t)stream, w->ev, 0) == hipSuccess ? 0 : 1;
+}
+
+void drop_overlap(nb_multi* m)
+{
+    for (size_t k = 0; k < m->xs.size(); ++k) {
+        if (k < m->shard.size()) {
+            (void)hipSetDevice(m->shard[k]->device);
+            m->shard[k]->xwait = nullptr; m->shard[k]->xuser = nullptr; m->shard[k]->gather_pending = false;
+        }
+        if (m->xs[k]) { (void)hipStreamSynchronize(m->xs[k]); (void)hipStreamDestroy(m->xs[k]); }
+    }
+    m->xs.clear();
+    m->waits.clear();
+}
 
 void drop_comms(nb_multi* m)
 {
@@ -387,6 +412,7 @@ void nb_multi_destroy(nb_multi* m)
         (void)hipStreamSynchronize(m->shard[k]->stream);
     }
     drop_comms(m);
+    drop_overlap(m);
     for (size_t k = 0; k < m->ev_k2.size(); ++k) {
         if (k < m->shard.size()) (void)hipSetDevice(m->shard[k]->device);
         if (m->ev_k2[k]) (void)hipEventDestroy(m->ev_k2[k]);
@@ -415,10 +441,26 @@ int nb_multi_sync(nb_multi* m)
 int nb_multi_set_collective(nb_multi* m, int mode)
 {
     if (!m) return NB_ERR_INVALID;
-    if (mode != NB_MULTI_PEER && mode != NB_MULTI_RCCL) return mfail(m, NB_ERR_INVALID, "nb_multi_set_collective: unknown mode");
+    if (mode != NB_MULTI_PEER && mode != NB_MULTI_RCCL && mode != NB_MULTI_PEER_OVERLAP) return mfail(m, NB_ERR_INVALID, "nb_multi_set_collective: unknown mode");
     if (int rc = nb_multi_sync(m)) return rc;
     if (mode == m->mode) return NB_OK;
-    if (mode == NB_MULTI_PEER) { drop_comms(m); m->mode = mode; m->copied_pending = false; m->rs_pending = false; return NB_OK; }
+    if (mode == NB_MULTI_PEER) { drop_comms(m); drop_overlap(m); m->mode = mode; m->copied_pending = false; m->rs_pending = false; return NB_OK; }
+    if (mode == NB_MULTI_PEER_OVERLAP) {
+        if (!m->sym || !m->pull) return mfail(m, NB_ERR_STATE, "nb_multi_set_collective: NB_MULTI_PEER_OVERLAP needs the rank form of the symmetric pass and peer-accessible shards");
+        drop_comms(m);
+        m->xs.assign(m->g, nullptr);
+        m->waits.assign(m->g, nb_multi::Wait{nullptr});
+        for (uint32_t k = 0; k < m->g; ++k) {
+            if (hipSetDevice(m->shard[k]->device) != hipSuccess || hipStreamCreateWithFlags(&m->xs[k], hipStreamNonBlocking) != hipSuccess) {
+                (void)hipGetLastError(); drop_overlap(m);
+                return mfail(m, NB_ERR_HIP, "nb_multi_set_collective: cannot create the gather streams");
+            }
+            m->waits[k].ev = m->ev_copied[k];
+        }
+        m->mode = mode; m->copied_pending = false; m->rs_pending = false;
+        return NB_OK;
+    }
+    drop_overlap(m);
     // one communicator per shard, one shard per device (RCCL refuses two ranks on one GPU)
     std::vector<int> devs;
     for (nb_sim* s : m->shard) {
@@ -506,7 +548,7 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
                 NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_hub[3], 0));
             int rc = nb_step(s, 1);
             if (rc != NB_OK) return mfail(m, rc, s->err);
-            if (m->mode == NB_MULTI_PEER) NB_MHIP(m, hipEventRecord(m->ev_k2[d], s->stream));
+            if (m->mode != NB_MULTI_RCCL) NB_MHIP(m, hipEventRecord(m->ev_k2[d], s->stream));
         }
         if (m->sym) {
             // rank form of the symmetric pass.  (a) every shard: force pass over the pair lists of its own rows, then its sums
@@ -516,10 +558,12 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
                 NB_MHIP(m, hipSetDevice(s->device));
                 if (m->rs_pending)       // the other shards may still be reading this shard's sym_A (previous step)
                     NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_hub[1], 0));
-                // (the positions this pass reads were completed on this stream by the previous step's gather)
-                int rc = nbi::sym_rank_phase_a(s);
+                // (the positions this pass reads were completed on this stream by the previous step's gather -- or, overlapped, the
+                // gather is still running on the shard's second stream: the sweeps over the shard's own rows go first and the
+                // stream waits for the pull in front of the rest)
+                int rc = nbi::sym_rank_phase_a(s, nullptr, s->gather_pending);
                 if (rc != NB_OK) return mfail(m, rc, s->err);
-                if (m->mode == NB_MULTI_PEER) NB_MHIP(m, hipEventRecord(m->ev_a[d], s->stream));
+                if (m->mode != NB_MULTI_RCCL) NB_MHIP(m, hipEventRecord(m->ev_a[d], s->stream));
             }
             // (b) reduce-scatter: shard e ends up with the sum over all shards of the rows it owns
             if (m->mode == NB_MULTI_RCCL) {
@@ -573,7 +617,7 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
                     NB_MHIP(m, hipStreamWaitEvent(s->stream, m->ev_hub[3], 0));
                 int rc = nbi::sym_rank_phase_b(s);
                 if (rc != NB_OK) return mfail(m, rc, s->err);
-                if (m->mode == NB_MULTI_PEER) NB_MHIP(m, hipEventRecord(m->ev_k2[d], s->stream));
+                if (m->mode != NB_MULTI_RCCL) NB_MHIP(m, hipEventRecord(m->ev_k2[d], s->stream));
             }
         }
         if (m->mode == NB_MULTI_RCCL) {
@@ -598,7 +642,8 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
         for (uint32_t e = 0; e < g; ++e) {
             nb_sim* dst = m->shard[e];
             NB_MHIP(m, hipSetDevice(dst->device));
-            NB_MHIP(m, hipStreamWaitEvent(dst->stream, m->ev_hub[2], 0));        // every shard has written its new rows
+            const bool over = m->mode == NB_MULTI_PEER_OVERLAP && m->pull && (float)dst->G == 1.0f;
+            if (!over) NB_MHIP(m, hipStreamWaitEvent(dst->stream, m->ev_hub[2], 0));        // every shard has written its new rows
             if (m->pull) {               // one pull kernel instead of g - 1 copies
                 nb::PeerPtrs pp{};
                 for (uint32_t d = 0; d < g; ++d) pp.p[d] = m->shard[d]->bodies[m->shard[d]->cur];
@@ -606,8 +651,14 @@ int nb_multi_step(nb_multi* m, uint32_t nsteps)
                 uint32_t rows = m->rows, shards = g, me = e;
                 void* args[] = {&pp, &out, &rows, &shards, &me};
                 const void* fn = m->esz == 8 ? (const void*)&nb::nb_peer_gather<double> : (const void*)&nb::nb_peer_gather<float>;
-                NB_MHIP(m, hipLaunchKernel(fn, dim3((rows * shards + nb::kBlock - 1) / nb::kBlock), dim3(nb::kBlock), args, 0, dst->stream));
-                NB_MHIP(m, hipEventRecord(m->ev_copied[e], dst->stream));
+                // overlapped: on the shard's second stream (which waited for "every shard has written its rows" instead of the
+                // shard's own stream); the shard handle is told a gather is pending and waits for ev_copied[e] where it must.
+                // With G != 1 the (x, y, z, G m) copy is rebuilt from the gathered rows first thing next step: nothing to overlap
+                hipStream_t on = over ? m->xs[e] : dst->stream;
+                if (over) NB_MHIP(m, hipStreamWaitEvent(on, m->ev_hub[2], 0));
+                NB_MHIP(m, hipLaunchKernel(fn, dim3((rows * shards + nb::kBlock - 1) / nb::kBlock), dim3(nb::kBlock), args, 0, on));
+                NB_MHIP(m, hipEventRecord(m->ev_copied[e], on));
+                if (over) { dst->xwait = multi_gather_wait; dst->xuser = &m->waits[e]; dst->gather_pending = true; }
                 continue;
             }
             for (uint32_t d = 0; d < g; ++d) {

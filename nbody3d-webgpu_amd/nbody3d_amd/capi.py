@@ -29,7 +29,7 @@ NB_FLAG_SYM_SHARD = 128
 NB_FLAG_WHOLE_SWEEPS = 256
 NB_RCCL_ID_BYTES = 128
 NB_RCCL_OVERLAP = 1
-NB_MULTI_PEER, NB_MULTI_RCCL = 0, 1
+NB_MULTI_PEER, NB_MULTI_RCCL, NB_MULTI_PEER_OVERLAP = 0, 1, 2
 NB_NOT_READY = 7
 STATUS = {0: "NB_OK", 1: "NB_ERR_INVALID", 2: "NB_ERR_NO_DEVICE", 3: "NB_ERR_HIP",
           4: "NB_ERR_STATE", 5: "NB_ERR_NOMEM", 6: "NB_ERR_COMM", 7: "NB_NOT_READY"}
@@ -554,12 +554,12 @@ class MultiSimulation:
     def set_collective(self, mode):
         """'peer' (event-ordered device-to-device copies) or 'rccl' (ncclCommInitAll + grouped
         in-place ncclAllGather); bit-identical results."""
-        self._check(self._L.nb_multi_set_collective(self._h, {"peer": NB_MULTI_PEER, "rccl": NB_MULTI_RCCL}[mode]))
+        self._check(self._L.nb_multi_set_collective(self._h, {"peer": NB_MULTI_PEER, "rccl": NB_MULTI_RCCL, "peer_overlap": NB_MULTI_PEER_OVERLAP}[mode]))
 
     def collective_info(self):
         a, b, c = C.c_int(), C.c_int(), C.c_int()
         self._check(self._L.nb_multi_collective_info(self._h, C.byref(a), C.byref(b), C.byref(c)))
-        return {"mode": "rccl" if a.value == NB_MULTI_RCCL else "peer", "nranks": b.value, "rccl_version": c.value}
+        return {"mode": {NB_MULTI_RCCL: "rccl", NB_MULTI_PEER_OVERLAP: "peer_overlap"}.get(a.value, "peer"), "nranks": b.value, "rccl_version": c.value}
 
     def close(self):
         if getattr(self, "_h", None):

@@ -15,7 +15,7 @@ import pytest
 
 from conftest import load_golden32, load_golden64, rel_pos_err
 from oracle import oracle
-from nbody3d_amd import Simulation, capi, ic
+from nbody3d_amd import MultiSimulation, Simulation, capi, ic
 
 pytestmark = pytest.mark.gpu
 
@@ -520,6 +520,33 @@ def test_rank_form_overlapped_gather_is_bit_identical(n, precision):
     rb, _, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 13)
     tol = 1e-12 if precision == "f64" else TOL_TIGHT
     assert rel_pos_err(out[True][1][0], rb, 1.0) < tol
+
+
+@pytest.mark.parametrize("n,g,precision", [(16384, 2, "f32"), (24576, 3, "f32"), (32768, 4, "f32"), (65536, 8, "f32"), (16384, 4, "f64")])
+def test_overlapped_gather_between_several_shards_is_bit_identical(n, g, precision):
+    """The overlapped protocol with MORE THAN ONE rank's rows really in flight -- what a one-rank RCCL run cannot show (its in-place
+    gather moves nothing): g virtual shards of nb_multi on this one device, NB_MULTI_PEER_OVERLAP.  Shard e's gather pull of step n
+    runs on a second stream while its phase A of step n + 1 (travelers = own rows) sweeps; the shard's stream waits for the pull only
+    in front of phase B.  If phase A read a row another shard's pull was still writing -- a wrapped ring target, a resident of a
+    foreign block -- the trajectories would differ from the non-overlapped order: 20 steps, bit for bit, state read in between,
+    and against the fp64 oracle."""
+    dt_np = np.float64 if precision == "f64" else np.float32
+    b, v = ic.plummer(n, seed=98)
+    b, v = b.astype(dt_np), v.astype(dt_np)
+    out = {}
+    for mode in ("peer", "peer_overlap"):
+        with MultiSimulation(n, g, precision=precision, collective=mode) as ms:
+            assert "symwrank" in ms.variant and ms.collective_info()["mode"] == mode, (ms.variant, ms.collective_info())
+            ms.init(b, v)
+            ms.simulate(1, 1e-3, 1.0)
+            ms.simulate(9)
+            mid = ms.read()                       # a read waits for the pulls in flight
+            ms.simulate(10)
+            out[mode] = (mid, ms.read())
+    for x, y in zip(out["peer"][0] + out["peer"][1], out["peer_overlap"][0] + out["peer_overlap"][1]):
+        assert x.tobytes() == y.tobytes()
+    rb, _, ra = oracle.run_f64(b, v, None, 1e-3, 1.0, 20)
+    assert rel_pos_err(out["peer_overlap"][1][0], rb, 1.0) < (1e-12 if precision == "f64" else TOL_TIGHT)
 
 
 def test_rank_form_is_not_taken_when_the_rows_are_not_whole_super_blocks_or_without_the_flag():
