@@ -954,7 +954,12 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::ty
         static_assert((kBlock / R) <= 64 && 64 % (kBlock / R) == 0, "a workgroup's bodies stay inside one 64-row chunk");
         const uint32_t il0 = blockIdx.x * (kBlock / R);
         const uint32_t b = il0 / S;
-        const uint32_t nr = gtab[2 * b + 1];
+        // (the two table reads -- resident layers of the block, spill rows of the chunk -- are requested TOGETHER: with the second one
+        // under `if (ups > 1)` the compiler waited for the first before it issued it, one more scalar round trip in front of the rows;
+        // whole-sweep plans have no spill table: they re-read the block's own entry and ignore it)
+        const uint32_t ci0 = il0 >> ch_shift;
+        const uint32_t* const ent = gtab + (pl.ups > 1 ? 2 * (pl.np / S) + 2 * pl.W + 1 + 2 * ci0 : 2 * b);
+        const uint32_t nr = gtab[2 * b + 1], ent0 = ent[0], ent1 = ent[1];
         // traveler sums: a row of a whole super-block has one layer per ring distance; a row of the short block Z (b == pl.nsb) has
         // the z-rows instead -- one per whole super-block, row g * zc + c of the spill buffer (c: its chunk inside Z)
         const bool zb = b >= pl.nsb;
@@ -962,11 +967,7 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::ty
         uint32_t ns = 0, s_first = 0;
         const uint32_t ci = il0 >> ch_shift;
         const uint32_t zci = ci - ((pl.nsb * S) >> ch_shift);
-        if (pl.ups > 1) {
-            const uint32_t* ent = gtab + 2 * (pl.np / S) + 2 * pl.W + 1 + 2 * ci;
-            s_first = ent[0];
-            ns = ent[1];
-        }
+        if (pl.ups > 1) { s_first = ent0; ns = ent1; }
         const uint32_t total = nr + nt + ns;
         auto row = [&](uint32_t e) {
             if (e < nr) return partial + (size_t)(pl.r_layer0 + e) * pl.np + il;
@@ -974,17 +975,22 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::ty
                                        : partial + (size_t)(pl.t_layer0 + (e - nr)) * pl.np + il;
             return spill + (((size_t)(s_first + (e - nr - nt)) << ch_shift) + (il - (ci << ch_shift)));
         };
-        uint32_t e = r;
-        for (; e + 3 * R < total; e += 4 * R) {
-            const SymRowT<T> p0 = *row(e), p1 = *row(e + R), p2 = *row(e + 2 * R), p3 = *row(e + 3 * R);
-            sx += p0.x; sy += p0.y; sz += p0.z;
-            sx += p1.x; sy += p1.y; sz += p1.z;
-            sx += p2.x; sy += p2.y; sz += p2.z;
-            sx += p3.x; sy += p3.y; sz += p3.z;
-        }
-        for (; e < total; e += R) {
-            const SymRowT<T> p0 = *row(e);
-            sx += p0.x; sy += p0.y; sz += p0.z;
+        // Rows e = r, r + R, ... in ascending order, FOUR requests in flight per trip for EVERY lane: a lane whose share is not a
+        // multiple of four rows re-requests row 0 for the missing ones and adds 0 in their place.  (Round 4 ran a one-row tail loop
+        // instead: load, wait, add, next load -- with ~30 rows over 8 lanes two lanes of every body took THREE round trips in
+        // sequence where the others took one, and the whole launch waited for them: K2 4.4 -> 3.x us at N = 9,000 .. 20,000.)
+        for (uint32_t e = r; e < total; e += 4 * R) {
+            SymRowT<T> p[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t ee = e + q * R;
+                p[q] = *row(ee < total ? ee : 0u);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const bool ok = e + q * R < total;
+                sx += ok ? p[q].x : T(0); sy += ok ? p[q].y : T(0); sz += ok ? p[q].z : T(0);
+            }
         }
     }
     if constexpr (R > 1) {

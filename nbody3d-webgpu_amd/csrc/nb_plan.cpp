@@ -205,7 +205,7 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         // f64: 92 issue cycles per resident and step + 14 DPP; the loop runs at 96 % of that (N = 262,144: 23.7 ms, profiles/r03/sym_f64_first.txt)
         const double t_chunk = f64 ? 64.0 * (92.0 * ipl + 56.0) / 0.96 / clock : 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.95 : 0.935) / clock;
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
-        if (per_simd < 1.0) continue;
+        if (per_simd < 0.6) continue;                // (with ranges cut to 2 rotation steps a wave needs no whole sweep to its name: N = 7,000, 0.8 sweeps per SIMD)
         for (uint32_t k = 1; k <= 2; ++k) {
             if (k == 2 && per_simd < 2.0) continue;      // every wave needs a whole sweep or so of work
             // units per sweep: whole sweeps when a wave's share happens to round well (N = 11,000: 1.93 sweeps per wave, 31.3 us against
@@ -225,7 +225,10 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
                 // waves per SIMD: rms 1.6 %): the layers cost next to nothing since a workgroup's waves add their resident sums up in LDS;
                 // two waves of 16 residents per SIMD pay ~2 us for their second set of resident loads; a range cut inside sweeps costs
                 // ~1.5 us (the travelers of the shared sweeps are loaded twice, their sums stored twice)
-                const double t = sweeps * t_chunk + 2.3e-6 + segs * 1.66e-6 + (ups > 1 ? 1.5e-6 : 0.0) + (k == 2 && ipl == 16 ? 2.1e-6 : 0.0) + boundary
+                // (round 5, profiles/r05/sym_small_n_scan.txt: with 8 residents per lane and 32 units per sweep the estimate sat 1.2-1.6 us over
+                // the measured step from N = 8,192 to 10,000: 0.2 us for the cut there instead of 1.5; 16 residents keep the 1.5 --
+                // N = 9,500 .. 13,000 measured 0.5-1.3 us OVER the estimate without it)
+                const double t = sweeps * t_chunk + 2.3e-6 + segs * 1.66e-6 + (ups > 1 ? (ups >= 32 && ipl == 8 ? 0.2e-6 : 1.5e-6) : 0.0) + (k == 2 && ipl == 16 ? 2.1e-6 : 0.0) + boundary
                                  + layers * n * (f64 ? 24.0 : 12.0) / 20.0e12;
                 if (t < best.t) best = {ipl, k, ups, t};
                 if (ups_fine == 1) break;
@@ -750,7 +753,7 @@ LaunchPlan plan_launch(const PlanInput& in)
         if (pick) { if (!pinned) sh = pick->sh; js = pick->q; }
         // the symmetric pass (whole-system f32 handles; every unordered pair once): from N ~ 14,000 up it beats every
         // ordered-pair shape above (N = 16,384: 61.7 vs 65.7 us, 40,002: 270 vs 357 us, 262,144: 10.5 vs 14.6 ms)
-        if (!pinned && whole && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 8192) {
+        if (!pinned && whole && !cfg.ext_bodies && !(cfg.flags & (NB_FLAG_NO_SYM | NB_FLAG_LDS_ONLY)) && n >= 6144) {
             const SymChoice sc2 = sym_estimate(n, n_cu, kClock, kBoundary, f64, layer_budget, (cfg.flags & NB_FLAG_WHOLE_SWEEPS) != 0);
 #ifdef NB_TUNING
             if (getenv("NB_MODEL_TRACE"))
@@ -758,7 +761,8 @@ LaunchPlan plan_launch(const PlanInput& in)
                         1e6 * (pick ? pick->t : best_t), 1e6 * sc2.t, sc2.ipl, sc2.k);
 #endif
             // (the j-packed step runs 2.1-2.9 us behind its estimate from N = 8,192 to 12,000: profiles/r04/sym_units_scan_workgroup_reduce.txt)
-            const double ordered_t = (pick ? pick->t : best_t) + (pick && pick->sh.kind == kJpk ? 2.5e-6 : 0.0);
+            // (... and 3.0-3.2 us at 7,000 / 7,500: profiles/r05/sym_small_n_scan.txt)
+            const double ordered_t = (pick ? pick->t : best_t) + (pick && pick->sh.kind == kJpk ? 3.0e-6 : 0.0);
             if (sc2.ipl && sc2.t < 0.98 * ordered_t) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; sym_ups = sc2.ups; }     // a clear win only: both estimates are good to ~3 %
             else if (!sc2.ipl) {
                 // no resident count whose layers fit the budget (they grow with N^2: 103 GB at 4 M bodies): the rank-form pipeline on

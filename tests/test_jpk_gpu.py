@@ -180,10 +180,10 @@ def test_jpk_fenced_fallback_is_bit_identical(n, jsplit):
 
 
 def test_default_shape_at_an_auto_selected_jpk_size_with_poisoned_partials():
-    """validate the DEFAULT path itself, not only pinned variants -- N = 9,000 with no shape pin lands on
-    the j-packed step with a split across workgroups (from N ~ 10,000 the default is the symmetric pass); 400 steps through graph
+    """validate the DEFAULT path itself, not only pinned variants -- N = 7,000 with no shape pin lands on
+    the j-packed step with a split across workgroups (from N ~ 7,500 the default is the symmetric pass); 400 steps through graph
     replay with every consumed partial overwritten by NaN: finite, and bit-identical to the unpoisoned and to the fenced run."""
-    n = 9000
+    n = 7000
     b, v = ic.plummer(n, seed=77)
     p = run(b, v, 400, flags=capi.NB_FLAG_POISON)
     q = run(b, v, 400)

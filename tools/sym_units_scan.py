@@ -23,7 +23,7 @@ for n in sizes:
         if n <= 64 * ipl * 4:
             continue
         for k in (1, 2):
-            for ups in (1, 4, 8):
+            for ups in (1, 8, 32):
                 arms.append(("ipl%d k%d u%d" % (ipl, k, ups), dict(force_variant=700003 + ipl * 1000 + ups * 10, jsplit=k)))
     rows = []
     for name, kw in arms:
