@@ -761,8 +761,8 @@ LaunchPlan plan_launch(const PlanInput& in)
                         1e6 * (pick ? pick->t : best_t), 1e6 * sc2.t, sc2.ipl, sc2.k);
 #endif
             // (the j-packed step runs 2.1-2.9 us behind its estimate from N = 8,192 to 12,000: profiles/r04/sym_units_scan_workgroup_reduce.txt)
-            // (... and 3.0-3.2 us at 7,000 / 7,500: profiles/r05/sym_small_n_scan.txt)
-            const double ordered_t = (pick ? pick->t : best_t) + (pick && pick->sh.kind == kJpk ? 3.0e-6 : 0.0);
+            // (... and 3.1-3.5 us at 7,000 / 7,500: profiles/r05/sym_small_n_scan.txt)
+            const double ordered_t = (pick ? pick->t : best_t) + (pick && pick->sh.kind == kJpk ? 3.4e-6 : 0.0);
             if (sc2.ipl && sc2.t < 0.98 * ordered_t) { sh = {kSym, sc2.ipl, 1, 3}; sym_k = sc2.k; sym_ups = sc2.ups; }     // a clear win only: both estimates are good to ~3 %
             else if (!sc2.ipl) {
                 // no resident count whose layers fit the budget (they grow with N^2: 103 GB at 4 M bodies): the rank-form pipeline on

@@ -180,14 +180,16 @@ def test_jpk_fenced_fallback_is_bit_identical(n, jsplit):
 
 
 def test_default_shape_at_an_auto_selected_jpk_size_with_poisoned_partials():
-    """validate the DEFAULT path itself, not only pinned variants -- N = 7,000 with no shape pin lands on
-    the j-packed step with a split across workgroups (from N ~ 7,500 the default is the symmetric pass); 400 steps through graph
-    replay with every consumed partial overwritten by NaN: finite, and bit-identical to the unpoisoned and to the fenced run."""
-    n = 7000
+    """validate the planner's OWN choice of the j-packed step, not only pinned variants -- N = 9,000 with no shape pin
+    and the symmetric pass switched off (since round 5 the default from N ~ 7,000 is the symmetric pass; this is the ordered-pair
+    default there, what a handle that cannot pair up symmetrically gets) lands on the j-packed step with a split across workgroups;
+    400 steps through graph replay with every consumed partial overwritten by NaN: finite, and bit-identical to the unpoisoned and to
+    the fenced run."""
+    n = 9000
     b, v = ic.plummer(n, seed=77)
-    p = run(b, v, 400, flags=capi.NB_FLAG_POISON)
-    q = run(b, v, 400)
-    r = run(b, v, 400, flags=capi.NB_FLAG_JPK_FENCED)
+    p = run(b, v, 400, flags=capi.NB_FLAG_POISON | capi.NB_FLAG_NO_SYM)
+    q = run(b, v, 400, flags=capi.NB_FLAG_NO_SYM)
+    r = run(b, v, 400, flags=capi.NB_FLAG_JPK_FENCED | capi.NB_FLAG_NO_SYM)
     assert "jpairs" in q[3] and "_js1" != q[3][-4:], q[3]
     for a in p[:3]:
         assert np.isfinite(a).all(), p[3]

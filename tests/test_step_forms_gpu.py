@@ -175,7 +175,7 @@ def test_integrate_pass_measures_the_integrator_alone():
 # ---- the automatic launch shape ----------------------------------------------------------------
 
 @pytest.mark.parametrize("n,family,classic", [(512, "fused_regs", None), (1024, "fused_regs", None), (2002, "fused_lds", None), (4096, "fused_lds", None),
-                                              (6000, "fused_lds", None), (7000, "fused_jpairs", None), (8192, "symw_ipl8", "fused_jpairs"), (9000, "symw_ipl8", "fused_jpairs"), (12000, "symw", "fused_jpairs"), (14000, "symw", None),
+                                              (6000, "fused_lds", None), (7000, "symw_ipl8", "fused_jpairs"), (8192, "symw_ipl8", "fused_jpairs"), (9000, "symw_ipl8", "fused_jpairs"), (12000, "symw", "fused_jpairs"), (14000, "symw", None),
                                               (20000, "symw", "sgpr"), (32768, "symw", "sgpr"),
                                               (40002, "symw_ipl16_j1_w2048", "sgpr"), (65536, "symw_ipl16", "sgpr"), (131072, "symw_ipl16_j1_w2048", "sgpr"),
                                               (262144, "symw_ipl16_j1_w2048", "sgpr_ipl8_ws4"), (500010, "symw_ipl16", "sgpr"), (1048576, "symw_ipl16", "sgpr")])
