@@ -159,7 +159,7 @@ def test_sharded_and_f64_handles_never_take_the_pair_kernel():
         assert "jpairs" not in s.variant, s.variant
     with Simulation(n, shard=(0, 4096)) as s:                     # nor by the automatic choice (n = 8,192 is inside its range)
         assert "jpairs" not in s.variant, s.variant
-    with Simulation(n) as s:
+    with Simulation(n, flags=capi.NB_FLAG_NO_SYM) as s:           # a whole f32 system without the symmetric pass: the one-launch ordered-pair steps
         assert "jpairs" in s.variant or "fused_lds" in s.variant, s.variant
     with Simulation(n, precision="f64", force_variant=code(8)) as s:
         assert "jpairs" not in s.variant and s.variant.startswith("f64"), s.variant
