@@ -41,7 +41,8 @@ extern "C" {
 #define NB_ABI_MINOR 3u   /* additions within major 2; a client needs nb_abi_minor() >= the minor it was written against:
                              2.1 (round 3)  nb_force_pass, nb_frame_request / nb_frame_acquire, nb_shape_info, NB_FLAG_SYM_SHARD
                              2.2 (round 4)  nb_step_times2, nb_plan_query, NB_FLAG_WHOLE_SWEEPS, nb_config.layer_budget_mib
-                             2.3 (round 5)  nb_abi_minor, NB_MULTI_PEER_OVERLAP; nb_plan_info / nb_plan_query moved to nbody3d_hip_plan.h; force_variant 7 II LL 3 takes LL up to 64 */
+                             2.3 (round 5)  nb_abi_minor, NB_MULTI_PEER_OVERLAP; nb_plan_info / nb_plan_query moved to nbody3d_hip_plan.h; force_variant 7 II LL 3 takes LL up to 64;
+                                            nb_plan_query's table holds four words per wave instead of the W + 1 starts */
 
 typedef struct nb_sim nb_sim; /* opaque */
 

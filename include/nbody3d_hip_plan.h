@@ -34,8 +34,10 @@ extern "C" {
  *                      N leaves behind them; workgroup form nb::SymPlan: np, nsb, q, total_hi, total_lo, n_hi, H, r_layer0, t_layer0)
  *   tab                (caller's array of tab_cap words, may be NULL) first wave and resident layer count of every super-block's
  *                      list (a layer per workgroup of four waves ending there, one more if the last wave goes on), 2 words per
- *                      block of rows (sym_np / rows per super-block: the short block last); the W + 1 wave starts (first unit of every wave's range: equal in work, a sweep over a chunk of
- *                      padding rows counts nothing); with sym_ups > 1 followed by the spill tables -- the spill row of every wave (W words), {first
+ *                      block of rows (sym_np / rows per super-block: the short block last); then FOUR words per wave (4 * workgroup +
+ *                      wave in it) -- {first unit, end, resident layer of the super-block the range ends in, spill row}: the ranges
+ *                      partition the list of units (with two waves per SIMD consecutive ranges alternate between wave i and wave
+ *                      W / 2 + i, and the first of the two is the longer one); with sym_ups > 1 followed by the spill lists -- {first
  *                      spill row, count} per traveler chunk (2 * sym_np / 64 words), then the wave numbers in spill-row order;
  *                      tab_len reports how many words there are
  *   sym_ups            work units per chunk-sweep: the wave ranges are floor/ceil-equal in units of 64 / sym_ups rotation steps */

@@ -210,8 +210,9 @@ void nb_force_sym(const float4* __restrict__ bodies, SymRow* __restrict__ partia
 // sweeps -- one per wave, W a multiple of the chip's SIMD count -- so every SIMD gets the same work to within ONE sweep at
 // any N (the workgroup form above needs nsb * Q to land on a multiple of the CU count).  A wave whose range crosses into the
 // next super-block stores its resident sums in g's last resident layer, reloads its residents and goes on; the sums of the
-// super-block a range ENDS in are added up over the workgroup's four waves in LDS and go to layer r_layer0 + (w / 4) - (first
-// wave of g) / 4 (table `gtab`: first wave and resident layer count per super-block, built by the host).
+// super-block a range ENDS in are added up over the workgroup's four waves in LDS and go to the resident layer the wave's table
+// record names (table `gtab`, built by the host: first wave and resident layer count per super-block, then {first unit, end,
+// layer, spill row} per wave).
 // struct SymWPlan: nb_plan.h
 
 template <int NG, int J>
@@ -226,23 +227,28 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
     const int lane = threadIdx.x & 63, wi = threadIdx.x >> 6;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wi);     // the four waves of a workgroup sweep independently and meet once, at the end
     const bool active = w < pl.W;
+    NB_STAMP(0);
     __shared__ float red[4][6 * NG][64];       // the waves' last resident sums, added up per super-block before they leave the CU
     __shared__ uint32_t fin[4];
     // The wave's range, in UNITS of 64 / ups rotation steps (ups units per chunk-sweep), relative to the handle's part of the list.
     // With ups > 1 a sweep may be shared by consecutive waves: each runs its own rotation steps [s0, s1) of it, starting from
     // travelers loaded s0 lanes ahead (wave_ror:1 moves a traveler from lane l to lane l + 1, so after s steps lane l holds the
     // traveler that started in lane l - s).
-    // The wave starts are a table of the planner (W + 1 words behind the {first wave, resident layers} pair of every block of S rows).
+    // The range is a record of the planner's table (four words per wave behind the {first wave, resident layers} pair of every block of S
+    // rows): consecutive ranges need not belong to consecutive waves (nb_plan.cpp::lay_out_symw pairs an older with a younger wave).
     // A ragged N leaves a SHORT block Z of pl.zc real chunks behind the pl.nsb whole super-blocks of the ring: every super-block sweeps
     // Z's chunks after its ring sweeps (both sides: the traveler sums go to z-row g * zc + c of the spill buffer), and Z -- "super-block"
     // pl.nsb, last in the list -- sweeps only its own chunks (nb_plan.cpp::lay_out_symw).
     const uint32_t ups = pl.ups, ustep = 64u / ups, tab1 = 2u * (pl.np / S);
-    uint32_t u = active ? gtab[tab1 + w] : 0u;
-    const uint32_t uend = active ? gtab[tab1 + w + 1] : 0u;
+    const uint4 rec = active ? *(const uint4*)(gtab + tab1 + 4u * w) : uint4{0u, 0u, 0u, 0u};      // {first unit, end, resident layer, spill row}: one scalar load
+    uint32_t u = rec.x;
+    const uint32_t uend = rec.y;
     const nb_f2 e2 = nb_f2{eps2, eps2};
     const uint32_t first_lo = pl.n_hi * pl.total_hi, first_z = first_lo + (pl.nsb - pl.n_hi) * pl.total_lo;
-    const uint32_t slot = ups > 1 && active ? gtab[tab1 + pl.W + 1 + w] : 0u;      // the wave's spill row (it has at most one: the sweep its range starts inside)
+    const uint32_t slot = rec.w;               // the wave's spill row (it has at most one: the sweep its range starts inside)
     uint32_t gfin = ~0u;                       // the super-block the range ends in
+    NB_STAMP_LIGHT(1);
+    bool first_part = true;                    // (diagnostic stamps only; dead in the product build)
 
     while (u < uend) {
         // which super-block's list the unit lies in, and where
@@ -378,7 +384,9 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
                     }
                 }
             };
+            if (first_part) NB_STAMP(2);       // (drains the loads first: residents + first travelers landed)
             if (sym) steps(std::true_type{}); else steps(std::false_type{});
+            if (first_part) { NB_STAMP_LIGHT(3); first_part = false; }
             if (sym) {
                 // the sums of steps [s0, s1) sit s1 lanes past their travelers' home lanes.  The part that starts the sweep owns the
                 // sweep's traveler layer; any later part goes to the wave's own spill row (K2 adds it: the spill rows of a chunk are consecutive)
@@ -417,9 +425,11 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
     }
     // The resident sums of the super-block the range ends in: the waves of the workgroup that end in the same one (consecutive
     // waves share a super-block when there are more waves than super-blocks: N = 16,384 has 64 per super-block) add theirs up in LDS,
-    // in wave order, and store ONE row set -- layer (w / 4) - (first wave of g) / 4 -- a quarter of the resident layers K2 reads.
+    // in wave order, and store ONE row set -- the layer of their table records (the same for all of them) -- a quarter of the resident layers K2 reads.
+    NB_STAMP_LIGHT(8);
     if (lane == 0) fin[wi] = gfin;
     __syncthreads();
+    NB_STAMP_LIGHT(9);
     if (gfin == ~0u) return;
     int members = 0, mine = 0;
 #pragma unroll
@@ -428,7 +438,7 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
         members += same;
         mine += same && j < wi;
     }
-    SymRow* out = partial + (size_t)(pl.r_layer0 + (w >> 2) - (gtab[2 * gfin] >> 2)) * pl.np + (size_t)gfin * S + lane;
+    SymRow* out = partial + (size_t)(pl.r_layer0 + rec.z) * pl.np + (size_t)gfin * S + lane;
     for (int r = mine; r < 2 * NG; r += members) {       // the members share the rows out
         float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
@@ -436,6 +446,7 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
             if (fin[j] == gfin) { sx += red[j][3 * r + 0][lane]; sy += red[j][3 * r + 1][lane]; sz += red[j][3 * r + 2][lane]; }
         out[r * 64] = SymRow{sx, sy, sz};
     }
+    NB_STAMP(4);
 }
 
 // The fp64 form (BASELINE config 5): non-packed, IPL residents per lane, one traveler per lane.  Per unordered pair: 3 adds,
@@ -469,10 +480,11 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
     __shared__ double red[4][3 * IPL][64];     // see nb_force_symw: the last resident sums of the workgroup's waves meet here
     __shared__ uint32_t fin[4];
     const uint32_t ups = pl.ups, ustep = 64u / ups, tab1 = 2u * (pl.np / S);          // wave ranges in units of 64 / ups rotation steps, starts from the table; the short block Z: see nb_force_symw
-    uint32_t u = active ? gtab[tab1 + w] : 0u;
-    const uint32_t uend = active ? gtab[tab1 + w + 1] : 0u;
+    const uint4 rec = active ? *(const uint4*)(gtab + tab1 + 4u * w) : uint4{0u, 0u, 0u, 0u};      // see nb_force_symw
+    uint32_t u = rec.x;
+    const uint32_t uend = rec.y;
     const uint32_t first_lo = pl.n_hi * pl.total_hi, first_z = first_lo + (pl.nsb - pl.n_hi) * pl.total_lo;
-    const uint32_t slot = ups > 1 && active ? gtab[tab1 + pl.W + 1 + w] : 0u;
+    const uint32_t slot = rec.w;
     uint32_t gfin = ~0u;
     while (u < uend) {
         const uint32_t p = u / ups;
@@ -569,7 +581,7 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
         members += same;
         mine += same && j < wi;
     }
-    SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + (w >> 2) - (gtab[2 * gfin] >> 2)) * pl.np + (size_t)gfin * S + lane;
+    SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + rec.z) * pl.np + (size_t)gfin * S + lane;
     for (int r = mine; r < IPL; r += members) {
         double sx = 0, sy = 0, sz = 0;
 #pragma unroll
@@ -932,7 +944,7 @@ __global__ __launch_bounds__(kBlock) void nb_peer_gather(const PeerPtrs src, typ
 
 // K2 for the wave-granular form: resident layers gtab[2g+1] (workgroups whose waves ended in g's list, + the wave that went on), then the traveler layers, then (wave
 // ranges cut inside sweeps, pl.ups > 1) the spill rows of the waves that ran a later part of a sweep over the body's chunk:
-// {first spill row, count} per chunk of CH rows at gtab[2 np / S + 2 W + 1 + 2 chunk] (a chunk's spill rows are consecutive, in wave order: the
+// {first spill row, count} per chunk of CH rows at gtab[2 np / S + 4 W + 2 chunk] (a chunk's spill rows are consecutive, in list order: the
 // row addresses hang on ONE table load, like the layers').  Fixed order.  The body's own state is requested before the sums.
 template <typename T, int R>
 __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::type* __restrict__ bodies, typename vec4<T>::type* __restrict__ vel,
@@ -958,7 +970,7 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::ty
         // under `if (ups > 1)` the compiler waited for the first before it issued it, one more scalar round trip in front of the rows;
         // whole-sweep plans have no spill table: they re-read the block's own entry and ignore it)
         const uint32_t ci0 = il0 >> ch_shift;
-        const uint32_t* const ent = gtab + (pl.ups > 1 ? 2 * (pl.np / S) + 2 * pl.W + 1 + 2 * ci0 : 2 * b);
+        const uint32_t* const ent = gtab + (pl.ups > 1 ? 2 * (pl.np / S) + 4 * pl.W + 2 * ci0 : 2 * b);
         const uint32_t nr = gtab[2 * b + 1], ent0 = ent[0], ent1 = ent[1];
         // traveler sums: a row of a whole super-block has one layer per ring distance; a row of the short block Z (b == pl.nsb) has
         // the z-rows instead -- one per whole super-block, row g * zc + c of the spill buffer (c: its chunk inside Z)

@@ -585,6 +585,26 @@ int sym_rank_phase_b(nb_sim* s)
 
 extern "C" {
 
+#ifdef NB_STAMPS
+/* Diagnostic build only (`make stamps`): the per-wave s_memtime stamps of the last launch that carries them (kernels/common.hip.h,
+ * NB_STAMP): 16 words per wave, `waves` waves.  tools/stamps_symw.py. */
+__attribute__((visibility("default"))) int nb_debug_stamps(uint64_t* out, uint32_t waves)
+{
+    static unsigned long long* buf = nullptr;
+    constexpr size_t kWaves = 16384;
+    if (!buf) {
+        if (hipMalloc((void**)&buf, kWaves * 16 * sizeof(unsigned long long)) != hipSuccess) return NB_ERR_HIP;
+        (void)hipMemset(buf, 0, kWaves * 16 * sizeof(unsigned long long));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(nb::nb_stamp_buf), &buf, sizeof buf) != hipSuccess) return NB_ERR_HIP;
+    }
+    if (out && waves) {
+        if (waves > kWaves) waves = kWaves;
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, buf, (size_t)waves * 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return NB_ERR_HIP;
+    }
+    return NB_OK;
+}
+#endif
+
 uint32_t nb_abi_version(void) { return NB_ABI_VERSION; }
 uint32_t nb_abi_minor(void) { return NB_ABI_MINOR; }
 

@@ -119,6 +119,7 @@ struct ModelKnobs {
     double sustained = 0.958;  // share of hipDeviceProp_t::clockRate the chip holds under this kernel's load
                                // (2.24-2.29 of 2.4 GHz measured, profiles/r02/rocprof_f32_default: GRBM_GUI_ACTIVE)
     double jpk_lo = 7000, jpk_hi = 12500;   // sizes at which the j-packed step is scored at all (see plan_launch)
+    double old_share = 0.0;    // two waves per SIMD: share of a pair of ranges given to the OLDER wave of a SIMD (0: kOldShareF32 / F64; 0.5: equal ranges in list order)
 };
 #ifdef NB_TUNING
 // calibration build: read on every nb_create, so that one process can walk a grid of constants (tools/fit_model.py)
@@ -130,6 +131,7 @@ ModelKnobs model_knobs()
     m.hand_over = knob("NB_MODEL_HANDOVER", m.hand_over); m.lanes_scale = knob("NB_MODEL_LANES_SCALE", m.lanes_scale);
     m.boundary = knob("NB_MODEL_BOUNDARY", m.boundary); m.sustained = knob("NB_MODEL_SUSTAINED", m.sustained);
     m.jpk_lo = knob("NB_MODEL_JPK_LO", m.jpk_lo); m.jpk_hi = knob("NB_MODEL_JPK_HI", m.jpk_hi);
+    m.old_share = knob("NB_MODEL_OLD_SHARE", m.old_share);
     return m;
 }
 #else
@@ -186,6 +188,10 @@ uint32_t sym_units(uint64_t L, uint32_t W, bool whole_only, bool one_wave_per_si
 // made equal in (lay_out_symw).  A sweep over an own chunk (resident-only, no traveler sums) counts 7/8 (measured 0.88 at one and two
 // waves per SIMD, profiles/r04/README.md).
 constexpr uint32_t kSweepCost = 8, kOwnSweepCost = 7;
+// Two waves per SIMD: the share of a pair of consecutive ranges that goes to the OLDER wave of the SIMD (lay_out_symw).  Measured with the
+// arms timed in turns (profiles/r05/old_share_paired_interleaved.txt): f32 +1.0 .. +1.7 % per step from N = 40,002 to 1,048,576 at 0.90-0.93
+// (0.95 falls off below 65,536), f64 +3.0 .. +4.2 % at 0.85 (0.9: +1.3 %).
+constexpr double kOldShareF32 = 0.92, kOldShareF64 = 0.85;
 
 SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64, double layer_budget, bool whole_only)
 {
@@ -299,65 +305,96 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, c
     uint64_t Cu = 0;
     for (const Run& r : runs) Cu += (uint64_t)r.len * ups * r.cost;
     if ((uint64_t)W * kSweepCost > Cu) { W = (uint32_t)(Cu / kSweepCost); pl.W = W; }       // a wave's share is at least the dearest unit
-    std::vector<uint32_t> starts((size_t)W + 1);
+    // POSITIONS and WAVES.  The list is cut into W consecutive ranges ("positions", in list order); position p is run by the physical
+    // wave phys[p] (= 4 * workgroup + wave in it).  With one wave per SIMD the two are the same.  With TWO waves per SIMD the first half of
+    // the workgroups (one per CU: dispatched first) puts the OLDER wave on every SIMD, the second half the younger one, and the older
+    // wave wins the issue arbitration whenever both are ready: with equal ranges the first half of the waves finishes at ~53 % of the
+    // launch and the younger half then runs alone, at the one-wave-per-SIMD rate (N = 40,002: 130 / 244 us, profiles/r05/
+    // stamps_symw.txt; s_setprio does not change who wins).  So the older wave of a SIMD gets the share of the pair work at which the
+    // two END together (kOldShareF32 / kOldShareF64 -- the younger wave only fills the issue slots the older one leaves), and
+    // the ranges are PAIRED: positions 2i and 2i + 1 belong to waves i and W / 2 + i, so that a super-block's list is still covered
+    // by about the same number of workgroups as with equal ranges (its resident layers: one per workgroup that ends a range in it).
+    const double old_share = kw == 2 && W == 8u * (uint32_t)n_cu && Cu >= (uint64_t)W * 8u * kSweepCost ? (model_knobs().old_share > 0 ? model_knobs().old_share : f64 ? kOldShareF64 : kOldShareF32) : 0.5;
+    const bool paired = old_share != 0.5;
+    std::vector<uint32_t> starts((size_t)W + 1), phys(W);
     {
-        size_t q = 0;                                          // the run the wave's first unit lies in
+        size_t q = 0;                                          // the run the position's first unit lies in
         uint64_t before = 0;                                   // cost of the runs before it
-        for (uint32_t w = 0; w < W; ++w) {
-            const uint64_t target = (uint64_t)w * Cu / W;      // cost before the wave
+        for (uint32_t p = 0; p < W; ++p) {
+            phys[p] = paired ? (p & 1u ? W / 2 + p / 2 : p / 2) : p;
+            uint64_t target = (uint64_t)p * Cu / W;            // cost before the position
+            if (paired) {
+                const uint64_t lo = (uint64_t)(p / 2) * Cu / (W / 2), hi = (uint64_t)(p / 2 + 1) * Cu / (W / 2);
+                target = p & 1u ? lo + (uint64_t)(old_share * (double)(hi - lo)) : lo;
+            }
             while (q + 1 < runs.size() && before + (uint64_t)runs[q].len * ups * runs[q].cost <= target) { before += (uint64_t)runs[q].len * ups * runs[q].cost; ++q; }
-            starts[w] = (uint32_t)(runs[q].at * ups + (target - before) / runs[q].cost);
+            starts[p] = (uint32_t)(runs[q].at * ups + (target - before) / runs[q].cost);
         }
         starts[0] = 0;
         starts[W] = (uint32_t)Lu;
+        for (uint32_t p = 1; p <= W; ++p)
+            if (starts[p] <= starts[p - 1]) starts[p] = starts[p - 1] + 1;      // (never an empty range: W <= Cu / kSweepCost leaves room)
+        starts[W] = (uint32_t)Lu;
     }
-    auto start_of = [&](uint32_t w) { return (uint64_t)starts[w]; };
-    auto wave_of = [&](uint64_t u) { return (uint32_t)(std::upper_bound(starts.begin(), starts.begin() + W, (uint32_t)u) - starts.begin()) - 1u; };
+    auto start_of = [&](uint32_t p) { return (uint64_t)starts[p]; };
+    auto pos_of = [&](uint64_t u) { return (uint32_t)(std::upper_bound(starts.begin(), starts.begin() + W, (uint32_t)u) - starts.begin()) - 1u; };
     const uint32_t nch = pl.np / CH, zrows = nsb * zc;
-    // the table: {first wave, resident layers} per block of S rows (Z last), the W + 1 wave starts, then (ups > 1) the spill tables
-    const size_t starts0 = 2 * (size_t)blocks;
-    s->sym_tab_host.assign(starts0 + W + 1 + (ups > 1 ? (size_t)W + 2 * (size_t)nch : 0), 0);
-    std::copy(starts.begin(), starts.end(), s->sym_tab_host.begin() + starts0);
+    // the table: {first position's wave, resident layers} per block of S rows (Z last); FOUR words per physical wave -- {first unit, end,
+    // resident layer of the super-block the range ends in, spill row}: one 16-byte scalar load; then (ups > 1) the spill lists
+    const size_t waves0 = 2 * (size_t)blocks, spill0 = waves0 + 4 * (size_t)W;
+    s->sym_tab_host.assign(spill0 + (ups > 1 ? 2 * (size_t)nch : 0), 0);
+    for (uint32_t p = 0; p < W; ++p) {
+        uint32_t* rec = &s->sym_tab_host[waves0 + 4 * (size_t)phys[p]];
+        rec[0] = starts[p]; rec[1] = starts[p + 1];
+    }
     uint32_t max_r = 1;
     for (uint32_t g = 0; g < blocks; ++g) {
         const uint64_t off = (uint64_t)offset_of(g) * ups, end = off + (uint64_t)total_of(g) * ups;
-        const uint32_t first = wave_of(off), last = wave_of(end - 1);
+        const uint32_t first = pos_of(off), last = pos_of(end - 1);
         // resident layers of g: the waves whose range ENDS in g's list add their sums up per workgroup of four (in LDS) -- one layer
-        // per workgroup, (w / 4) - (first / 4) -- and the last wave, if its range goes on into g + 1, stores its part on its own
+        // per workgroup, numbered in list order -- and the last position, if its range goes on into g + 1, stores its part on its own
         const uint32_t goes_on = start_of(last + 1) > end ? 1u : 0u;
-        const uint32_t ending = last - first + 1 - goes_on;
-        const uint32_t layers = (ending ? ((first + ending - 1) >> 2) - (first >> 2) + 1u : 0u) + goes_on;
-        s->sym_tab_host[2 * g] = first; s->sym_tab_host[2 * g + 1] = layers;
+        uint32_t layers = 0;
+        std::vector<uint32_t> wg_seen;                          // (a handful of workgroups per super-block)
+        for (uint32_t p = first; p + goes_on <= last; ++p) {
+            const uint32_t wg = phys[p] >> 2;
+            size_t at = 0;
+            while (at < wg_seen.size() && wg_seen[at] != wg) ++at;
+            if (at == wg_seen.size()) wg_seen.push_back(wg);
+            s->sym_tab_host[waves0 + 4 * (size_t)phys[p] + 2] = (uint32_t)at;
+        }
+        layers = (uint32_t)wg_seen.size() + goes_on;
+        s->sym_tab_host[2 * g] = phys[first]; s->sym_tab_host[2 * g + 1] = layers;
         if (layers > max_r) max_r = layers;
     }
     // The spill buffer: the z-rows (whole super-block g's sums for chunk c of Z: row g * zc + c), then the spill rows of the waves.
     s->sym_spill_rows = zrows * CH;
     if (ups > 1) {
         // spill rows: a wave whose range starts inside a sweep keeps that sweep's traveler sums in a spill row of its own; K2 adds
-        // them to the rows of the sweep's traveler chunk.  The rows are numbered chunk by chunk (waves ascending inside a chunk), so K2
-        // reads rows [first, first + count) of its chunk: W words (the spill row of every wave), then {first, count} per chunk, then the
-        // wave numbers in row order (for the tests).
+        // them to the rows of the sweep's traveler chunk.  The rows are numbered chunk by chunk (list order inside a chunk), so K2
+        // reads rows [first, first + count) of its chunk: {first, count} per chunk, then the wave numbers in row order (for the tests);
+        // a wave's own row is word 3 of its record.
         struct Spill { uint32_t chunk, wave; };
         std::vector<Spill> sp;
-        for (uint32_t w = 0; w < pl.W; ++w) {
-            const uint64_t u = start_of(w);
+        for (uint32_t p = 0; p < pl.W; ++p) {
+            const uint64_t u = start_of(p);
             if (u % ups == 0) continue;                                         // starts a sweep
             uint32_t g, k, total;
             sweep_at((uint32_t)(u / ups), g, k, total);
             bool both;
             const uint32_t tstart = traveler_of(g, k, total, both);
             if (!both) continue;                                                // a sweep over an own chunk: no traveler sums
-            sp.push_back({tstart / CH, w});
+            sp.push_back({tstart / CH, phys[p]});
         }
-        std::stable_sort(sp.begin(), sp.end(), [](const Spill& a, const Spill& b) { return a.chunk < b.chunk; });      // waves stay ascending inside a chunk
-        const size_t slot0 = starts0 + W + 1, base = slot0 + pl.W, ids0 = base + 2 * (size_t)nch;
+        std::stable_sort(sp.begin(), sp.end(), [](const Spill& a, const Spill& b) { return a.chunk < b.chunk; });      // list order stays inside a chunk
+        const size_t ids0 = spill0 + 2 * (size_t)nch;
         s->sym_tab_host.resize(ids0 + sp.size(), 0);
         for (size_t e = 0; e < sp.size(); ++e) {
-            uint32_t* ent = &s->sym_tab_host[base + 2 * (size_t)sp[e].chunk];
+            uint32_t* ent = &s->sym_tab_host[spill0 + 2 * (size_t)sp[e].chunk];
             if (ent[1] == 0) ent[0] = zrows + (uint32_t)e;
             ++ent[1];
             s->sym_tab_host[ids0 + e] = sp[e].wave;
-            s->sym_tab_host[slot0 + sp[e].wave] = zrows + (uint32_t)e;
+            s->sym_tab_host[waves0 + 4 * (size_t)sp[e].wave + 3] = zrows + (uint32_t)e;
         }
         s->sym_spill_rows = (zrows + std::max<uint32_t>(1u, (uint32_t)sp.size())) * CH;
     }

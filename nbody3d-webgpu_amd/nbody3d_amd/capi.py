@@ -241,21 +241,25 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
                 nsb = out["plan"]["np"] // (64 * int(info.ipl))
             out["tab"] = tab[:2 * nsb].reshape(-1, 2)
             if info.symw:
+                # four words per physical wave: {first unit, end, resident layer of the super-block the range ends in, spill row}.  The ranges
+                # partition the list; "order" lists the waves in list order ("positions"), "starts" the first unit of every position + the list's end
                 W = out["plan"]["W"]
-                out["starts"] = tab[2 * nsb:2 * nsb + W + 1]              # first unit of every wave's range, then the list's end
+                out["waves"] = tab[2 * nsb:2 * nsb + 4 * W].reshape(-1, 4)
+                out["order"] = np.argsort(out["waves"][:, 0], kind="stable")
+                out["starts"] = np.concatenate([out["waves"][out["order"], 0], out["waves"][out["order"][-1:], 1]])
         out["ups"], out["spill_rows"] = int(info.sym_ups), int(info.sym_spill_rows)
         if info.symw:
             out["plan"]["ups"] = int(info.sym_ups)
         if info.sym_ups > 1 and not info.sym_rank:
-            # the spill rows (wave ranges cut inside sweeps): the spill row of every wave, {first row, count} per traveler chunk,
-            # then the wave numbers in row order
+            # the spill rows (wave ranges cut inside sweeps): {first row, count} per traveler chunk, then the wave numbers in row order
+            # (a wave's own row is word 3 of its record)
             ch = 128 if info.x == 1 else 64
             nch = out["plan"]["np"] // ch
             W = out["plan"]["W"]
-            base = 2 * nsb + W + 1
-            out["spill_slot"] = tab[base:base + W]
-            out["spill_tab"] = tab[base + W:base + W + 2 * nch].reshape(-1, 2)
-            out["spill_ids"] = tab[base + W + 2 * nch:]
+            base = 2 * nsb + 4 * W
+            out["spill_slot"] = out["waves"][:, 3]
+            out["spill_tab"] = tab[base:base + 2 * nch].reshape(-1, 2)
+            out["spill_ids"] = tab[base + 2 * nch:]
     return out
 
 

@@ -50,20 +50,36 @@ def walk_symw(q, n):
     c = np.where(ringsw, k % cps, np.where(zsw, k - ring, k - both_end))
     tstart = tb * S + c * CH
     assert np.all(tstart < n)                      # no sweep over padding only
-    # the waves: W ranges of the L * ups units, equal in WORK to about one unit -- a sweep over an own chunk (no traveler sums) counts 7,
-    # any other 8 -- none of them empty; their starts are a table of the plan
+    # the waves: W ranges ("positions", in list order) of the L * ups units, none of them empty, each run by ONE physical wave (a record of
+    # the plan's table: {first unit, end, resident layer, spill row}).  One wave per SIMD: position = wave, the ranges equal in WORK to about
+    # one unit -- a sweep over an own chunk (no traveler sums) counts 7, any other 8.  Two waves per SIMD: positions 2i / 2i + 1 belong to
+    # waves i and W / 2 + i -- the OLDER and the younger wave of a SIMD -- and the older one has 0.92 (f64: 0.85) of the pair's work
     Lu = L * ups
     starts = q["starts"].astype(np.int64)
+    order = q["order"].astype(np.int64)
+    assert sorted(order.tolist()) == list(range(W)) and np.array_equal(q["waves"][order, 1], starts[1:])      # a partition, record ends included
     assert len(starts) == W + 1 and starts[0] == 0 and starts[-1] == Lu and W <= Lu and np.diff(starts).min() >= 1
     work = np.repeat(np.where(sym, 8, 7 if ups > 1 else 8).astype(np.int64), ups)              # per unit (whole sweeps: an even cut)
-    per_wave = np.add.reduceat(work, starts[:-1])
-    assert per_wave.sum() == work.sum() and per_wave.max() - per_wave.min() <= 16, (per_wave.min(), per_wave.max())
-    wu = np.searchsorted(starts, np.arange(Lu, dtype=np.int64), side="right") - 1               # the wave of every unit
-    assert np.all((wu >= 0) & (wu < W))
+    per_pos = np.add.reduceat(work, starts[:-1])
+    assert per_pos.sum() == work.sum()
+    paired = not np.array_equal(order, np.arange(W))
+    if paired:
+        assert W % 8 == 0 and np.array_equal(order[0::2], np.arange(W // 2)) and np.array_equal(order[1::2], W // 2 + np.arange(W // 2))
+        old, young = per_pos[0::2], per_pos[1::2]
+        assert old.max() - old.min() <= 24 and young.max() - young.min() <= 24, (old.min(), old.max(), young.min(), young.max())
+        share = old.sum() / per_pos.sum()
+        assert abs(share - (0.85 if q["variant"].startswith("f64") else 0.92)) < 0.02, share
+        pair = old + young
+        assert pair.max() - pair.min() <= 16
+    else:
+        assert per_pos.max() - per_pos.min() <= 16, (per_pos.min(), per_pos.max())
+    pos_u = np.searchsorted(starts, np.arange(Lu, dtype=np.int64), side="right") - 1            # the position of every unit
+    assert np.all((pos_u >= 0) & (pos_u < W))
+    wu = order[pos_u]                            # ... and its wave
     w = wu[::ups]                                # the wave that starts each sweep (steps from 0): it owns the sweep's traveler layer / z-row
     w_last = wu[ups - 1::ups]                    # ... and the one that ends it
     return dict(S=S, CH=CH, cps=cps, nsb=nsb, blocks=blocks, zc=zc, H=H, n_hi=n_hi, g=g, k=k, sym=sym, ringsw=ringsw, zsw=zsw, d=d, tb=tb, c=c,
-                tstart=tstart, w=w, w_last=w_last, wu=wu, starts=starts, ups=ups, pl=pl, tab=tab)
+                tstart=tstart, w=w, w_last=w_last, wu=wu, pos_u=pos_u, order=order, starts=starts, ups=ups, pl=pl, tab=tab)
 
 
 def check_spill_lists(q, n, wk):
@@ -79,13 +95,13 @@ def check_spill_lists(q, n, wk):
     assert all(int(slot[int(wv)]) == zrows + e for e, wv in enumerate(ids))        # spill row zrows + e belongs to wave ids[e]: rows run chunk by chunk
     assert st.shape[0] == wk["pl"]["np"] // CH
     want = {}
-    for wv in range(W):
-        u0 = int(starts[wv])
+    for p in range(W):                            # in list order
+        u0 = int(starts[p])
         if u0 % ups == 0:
             continue
         sw = u0 // ups
         if wk["sym"][sw]:
-            want.setdefault(int(wk["tstart"][sw]) // CH, []).append(wv)
+            want.setdefault(int(wk["tstart"][sw]) // CH, []).append(int(wk["order"][p]))
     got = {}
     for ci in range(st.shape[0]):
         off, cnt = int(st[ci, 0]) - zrows, int(st[ci, 1])
@@ -93,8 +109,7 @@ def check_spill_lists(q, n, wk):
             got[ci] = [int(x) for x in ids[off:off + cnt]]
     assert got == want
     assert sum(len(v) for v in want.values()) == len(ids)
-    # a sweep is shared by consecutive waves: the first owns the layer, each of the others spills exactly once
-    assert all(v == sorted(v) for v in got.values())
+    # a sweep is shared by consecutive positions: the first owns the layer, each of the others spills exactly once (rows in list order)
 
 
 def check_whole_plan(q, n):
@@ -125,18 +140,22 @@ def check_whole_plan(q, n):
         assert np.all(own[nsb, :zc] == 1) and np.all(own[nsb, zc:] == 0)
     # (3) ring distances stay inside the traveler layers
     assert np.all(d[ringsw] < H + (g[ringsw] < n_hi)) and pl["t_layer0"] + H + (1 if n_hi else 0) == q["sym_layers"]
-    # (4) resident layers.  The waves whose range ENDS in b's list add their sums up per workgroup of four (LDS) and write layer
-    #     r_layer0 + w // 4 - first // 4; the last wave of the list, if its range goes on into b + 1, writes its part to b's last
+    # (4) resident layers.  The waves whose range ENDS in b's list add their sums up per workgroup of four (LDS) and write the layer
+    #     their table records name; the last position of the list, if its range goes on into b + 1, writes its part to b's last
     #     layer.  The table = {first wave, layer count}: every layer K2 reads is written exactly once
     gu = np.repeat(g, wk["ups"])
-    starts = wk["starts"]
+    starts, order, waves = wk["starts"], wk["order"], q["waves"]
     for b in range(blocks):
         units = np.nonzero(gu == b)[0]
-        ws = np.unique(wk["wu"][units])
-        assert ws[0] == tab[b, 0] and ws[-1] - ws[0] + 1 == len(ws), b
-        goes_on = starts[ws[-1] + 1] > units[-1] + 1
-        ending = ws[:-1] if goes_on else ws
-        written = sorted(set(int(x) // 4 - int(ws[0]) // 4 for x in ending))
+        ps = np.unique(wk["pos_u"][units])
+        assert order[ps[0]] == tab[b, 0] and ps[-1] - ps[0] + 1 == len(ps), b
+        goes_on = starts[ps[-1] + 1] > units[-1] + 1
+        ending = ps[:-1] if goes_on else ps
+        layer_of_wg = {}
+        for pp in ending:
+            wv = int(order[pp])
+            assert layer_of_wg.setdefault(wv // 4, int(waves[wv, 2])) == int(waves[wv, 2]), (b, wv)      # one row set per workgroup
+        written = sorted(layer_of_wg.values())
         if goes_on:
             written.append(int(tab[b, 1]) - 1)
         assert written == list(range(int(tab[b, 1]))), (b, written, tab[b])
@@ -403,8 +422,8 @@ def test_shard_own_splits_lie_inside_the_shard(n, g):
 
 def test_model_choice_table():
     """The automatic choice at the sizes DESIGN.md quotes (256 CUs, 2.4 GHz): a change of the cost model shows up here."""
-    want = {1024: "f32pk_fused_regs1024", 6500: "f32pk_fused_lds2048", 7000: "f32pk_symw_ipl8_j1_w1024_r22t6_u32", 8192: "f32pk_symw_ipl8_j1_w1024_r19t8_u32", 9000: "f32pk_symw_ipl8_j1_w1024_r16t8_u32", 11000: "f32pk_symw_ipl16_j1_w1012_r27t5", 13000: "f32pk_symw_ipl16_j1_w1024_r25t6_u32", 16384: "f32pk_symw_ipl16_j1_w1024_r19t8_u8", 20000: "f32pk_symw_ipl16_j1_w1024_r16t9_u8", 40002: "f32pk_symw_ipl16_j1_w2048_r15t19_u8",
-            65536: "f32pk_symw_ipl16_j1_w2048", 262144: "f32pk_symw_ipl16_j1_w2048_r4t128", 1048576: "f32pk_symw_ipl16_j1_w2048"}
+    want = {1024: "f32pk_fused_regs1024", 6500: "f32pk_fused_lds2048", 7000: "f32pk_symw_ipl8_j1_w1024_r22t6_u32", 8192: "f32pk_symw_ipl8_j1_w1024_r19t8_u32", 9000: "f32pk_symw_ipl8_j1_w1024_r16t8_u32", 11000: "f32pk_symw_ipl16_j1_w1012_r27t5", 13000: "f32pk_symw_ipl16_j1_w1024_r25t6_u32", 16384: "f32pk_symw_ipl16_j1_w1024_r19t8_u8", 20000: "f32pk_symw_ipl16_j1_w1024_r16t9_u8", 40002: "f32pk_symw_ipl16_j1_w2048_r17t19_u8",
+            65536: "f32pk_symw_ipl16_j1_w2048", 262144: "f32pk_symw_ipl16_j1_w2048_r5t128", 1048576: "f32pk_symw_ipl16_j1_w2048"}
     for n, prefix in want.items():
         assert capi.plan_query(n)["variant"].startswith(prefix), (n, capi.plan_query(n)["variant"])
     assert capi.plan_query(262144, precision="f64")["variant"].startswith("f64_symw_ipl8_j1_w2048")
