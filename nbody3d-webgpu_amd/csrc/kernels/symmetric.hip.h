@@ -214,16 +214,52 @@ void nb_force_sym(const float4* __restrict__ bodies, SymRow* __restrict__ partia
 // record names (table `gtab`, built by the host: first wave and resident layer count per super-block, then {first unit, end,
 // layer, spill row} per wave).
 // struct SymWPlan: nb_plan.h
+//
+// The plan reaches the force kernels as SIX scalar parameters behind the four pointers, the table pointer first: the first 14 dwords of
+// the kernel arguments are preloaded into SGPRs by the hardware (-amdgpu-kernarg-preload-count; a struct passed by value ends the
+// preloaded part), so the wave's table record -- the first thing a wave needs -- is requested in the wave's first instructions instead
+// of behind a round trip for the arguments (-0.4 .. -0.8 % per step from N = 7,000 to 13,000, nothing above:
+// profiles/r05/ab_arguments_preloaded_prev_vs_tree.txt -- the argument block is a cheap read).  The other
+// plan words follow from these (nb_plan.cpp::lay_out_symw): the ring's half width, the list lengths, the padded row count.
+struct SymWK { uint32_t np, nsb, W, total_hi, total_lo, n_hi, zc, ups, r_layer0, t_layer0; };
+#define SYMW_PLAN_PARAMS const uint32_t W_, const uint32_t ups_, const uint32_t nsb_, const uint32_t zc_, const uint32_t r_layer0_, const uint32_t t_layer0_
+// The wave's table record ({first unit, end, resident layer, spill row}: 16 bytes at `rec_at`) and the kernel's arguments behind the
+// preloaded 14 dwords (TAIL dwords at byte 56 of the argument block: the softening, in f64 also G), requested TOGETHER -- left to the
+// compiler the arguments' load sinks behind the wait for the record, a second cold round trip in front of the residents' loads.
+typedef uint32_t nb_u4 __attribute__((ext_vector_type(4)));
+template <int TAIL>
+__device__ __forceinline__ void symw_record_and_tail(const uint32_t* rec_at, nb_u4& rec, uint32_t (&tail)[TAIL])
+{
+    static_assert(TAIL == 1 || TAIL == 4, "f32: eps2; f64: G, eps2");
+    constexpr int kTailOffset = 4 * 8 + 6 * 4;       // four pointers and the six words of SYMW_PLAN_PARAMS in front of it
+    if constexpr (TAIL == 1) {
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dword %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(rec), "=&s"(tail[0]) : "s"(rec_at), "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(kTailOffset) : "memory");
+    } else {
+        nb_u4 t;
+        asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, %4\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(rec), "=&s"(t) : "s"(rec_at), "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(kTailOffset) : "memory");
+        tail[0] = t.x; tail[1] = t.y; tail[2] = t.z; tail[3] = t.w;
+    }
+}
+
+__device__ __forceinline__ SymWK symw_plan_words(uint32_t S, uint32_t cps, uint32_t W, uint32_t ups, uint32_t nsb, uint32_t zc, uint32_t r_layer0, uint32_t t_layer0)
+{
+    const uint32_t H = (nsb - 1u) >> 1, n_hi = (nsb & 1u) ? 0u : nsb >> 1;
+    const uint32_t total_lo = (H + 1u) * cps + zc, total_hi = total_lo + (n_hi ? cps : 0u);
+    return SymWK{(nsb + (zc ? 1u : 0u)) * S, nsb, W, total_hi, total_lo, n_hi, zc, ups, r_layer0, t_layer0};
+}
 
 template <int NG, int J>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 4 ? 2 : 4, NG > 4 ? 2 : (NG < 4 ? 8 : 4))))
-void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ partial, const uint32_t* __restrict__ gtab, const SymWPlan pl,
-                   const uint32_t n, const float eps2, SymRow* __restrict__ spill)
+void nb_force_symw(const uint32_t* __restrict__ gtab, const float4* __restrict__ bodies, SymRow* __restrict__ partial, SymRow* __restrict__ spill,
+                   SYMW_PLAN_PARAMS, const float eps2_arg /* read by hand, with the table record: symw_record_and_tail */)
 {
     constexpr uint32_t S = 128u * NG;          // rows per super-block = one wave's residents
     constexpr int GW = NG < 4 ? NG : 4;        // packed groups evaluated stage-major together
     constexpr uint32_t CH = 64u * J;           // travelers per chunk
     constexpr uint32_t CPS = S / CH;           // chunks per super-block
+    const SymWK pl = symw_plan_words(S, CPS, W_, ups_, nsb_, zc_, r_layer0_, t_layer0_);
     const int lane = threadIdx.x & 63, wi = threadIdx.x >> 6;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wi);     // the four waves of a workgroup sweep independently and meet once, at the end
     const bool active = w < pl.W;
@@ -239,10 +275,14 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
     // A ragged N leaves a SHORT block Z of pl.zc real chunks behind the pl.nsb whole super-blocks of the ring: every super-block sweeps
     // Z's chunks after its ring sweeps (both sides: the traveler sums go to z-row g * zc + c of the spill buffer), and Z -- "super-block"
     // pl.nsb, last in the list -- sweeps only its own chunks (nb_plan.cpp::lay_out_symw).
-    const uint32_t ups = pl.ups, ustep = 64u / ups, tab1 = 2u * (pl.np / S);
-    const uint4 rec = active ? *(const uint4*)(gtab + tab1 + 4u * w) : uint4{0u, 0u, 0u, 0u};      // {first unit, end, resident layer, spill row}: one scalar load
-    uint32_t u = rec.x;
-    const uint32_t uend = rec.y;
+    const uint32_t ups = pl.ups, ush = (uint32_t)__builtin_ctz(ups), ustep = 64u >> ush,      // (ups is a power of two)
+                   tab1 = 2u * (pl.np / S);
+    nb_u4 rec;                                 // {first unit, end, resident layer, spill row}: one scalar load
+    uint32_t tail[1];
+    symw_record_and_tail(gtab + tab1 + 4u * (active ? w : 0u), rec, tail);
+    const float eps2 = __builtin_bit_cast(float, tail[0]);
+    uint32_t u = active ? rec.x : 0u;
+    const uint32_t uend = active ? rec.y : 0u;
     const nb_f2 e2 = nb_f2{eps2, eps2};
     const uint32_t first_lo = pl.n_hi * pl.total_hi, first_z = first_lo + (pl.nsb - pl.n_hi) * pl.total_lo;
     const uint32_t slot = rec.w;               // the wave's spill row (it has at most one: the sweep its range starts inside)
@@ -252,7 +292,7 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
 
     while (u < uend) {
         // which super-block's list the unit lies in, and where
-        const uint32_t p = u / ups;                                  // the sweep
+        const uint32_t p = u >> ush;                                  // the sweep
         uint32_t g, k, total;
         if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
         else if (p < first_z) { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
@@ -283,7 +323,7 @@ void nb_force_symw(const float4* __restrict__ bodies, SymRow* __restrict__ parti
         bool flushed = false;
         while (u < ug_end) {
             // the wave's steps [s0, s1) of sweep k
-            const uint32_t q0 = u % ups;
+            const uint32_t q0 = u & (ups - 1u);
             uint32_t nun = ups - q0;
             if (nun > ug_end - u) nun = ug_end - u;
             const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
@@ -469,25 +509,30 @@ __device__ __forceinline__ double wave_rot1(double v)
 // chip holds under this load = 73 %, what it measures.)
 template <int IPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __restrict__ partial, const uint32_t* __restrict__ gtab,
-                     const SymWPlan pl, const uint32_t n, const double G, const double eps2, SymRowT<double>* __restrict__ spill)
+void nb_force_symw64(const uint32_t* __restrict__ gtab, const double4* __restrict__ bodies, SymRowT<double>* __restrict__ partial, SymRowT<double>* __restrict__ spill,
+                     SYMW_PLAN_PARAMS, const double G_arg, const double eps2_arg /* both read by hand: symw_record_and_tail */)
 {
     constexpr uint32_t S = 64u * IPL, CH = 64u, CPS = S / CH;
+    const SymWK pl = symw_plan_words(S, CPS, W_, ups_, nsb_, zc_, r_layer0_, t_layer0_);
     constexpr int GW = 4;                      // residents evaluated stage-major together
     const int lane = threadIdx.x & 63, wi = threadIdx.x >> 6;
     const uint32_t w = __builtin_amdgcn_readfirstlane(blockIdx.x * 4u + wi);
     const bool active = w < pl.W;
     __shared__ double red[4][3 * IPL][64];     // see nb_force_symw: the last resident sums of the workgroup's waves meet here
     __shared__ uint32_t fin[4];
-    const uint32_t ups = pl.ups, ustep = 64u / ups, tab1 = 2u * (pl.np / S);          // wave ranges in units of 64 / ups rotation steps, starts from the table; the short block Z: see nb_force_symw
-    const uint4 rec = active ? *(const uint4*)(gtab + tab1 + 4u * w) : uint4{0u, 0u, 0u, 0u};      // see nb_force_symw
-    uint32_t u = rec.x;
-    const uint32_t uend = rec.y;
+    const uint32_t ups = pl.ups, ush = (uint32_t)__builtin_ctz(ups), ustep = 64u >> ush,      // (ups is a power of two)
+                   tab1 = 2u * (pl.np / S);          // wave ranges in units of 64 / ups rotation steps, starts from the table; the short block Z: see nb_force_symw
+    nb_u4 rec;
+    uint32_t tail[4];
+    symw_record_and_tail(gtab + tab1 + 4u * (active ? w : 0u), rec, tail);
+    const double G = __builtin_bit_cast(double, (unsigned long long)tail[1] << 32 | tail[0]), eps2 = __builtin_bit_cast(double, (unsigned long long)tail[3] << 32 | tail[2]);
+    uint32_t u = active ? rec.x : 0u;
+    const uint32_t uend = active ? rec.y : 0u;
     const uint32_t first_lo = pl.n_hi * pl.total_hi, first_z = first_lo + (pl.nsb - pl.n_hi) * pl.total_lo;
     const uint32_t slot = rec.w;
     uint32_t gfin = ~0u;
     while (u < uend) {
-        const uint32_t p = u / ups;
+        const uint32_t p = u >> ush;
         uint32_t g, k, total;
         if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
         else if (p < first_z) { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
@@ -503,7 +548,7 @@ void nb_force_symw64(const double4* __restrict__ bodies, SymRowT<double>* __rest
             ax[c] = 0; ay[c] = 0; az[c] = 0;
         }
         while (u < ug_end) {
-            const uint32_t q0 = u % ups;
+            const uint32_t q0 = u & (ups - 1u);
             uint32_t nun = ups - q0;
             if (nun > ug_end - u) nun = ug_end - u;
             const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
@@ -944,16 +989,25 @@ __global__ __launch_bounds__(kBlock) void nb_peer_gather(const PeerPtrs src, typ
 
 // K2 for the wave-granular form: resident layers gtab[2g+1] (workgroups whose waves ended in g's list, + the wave that went on), then the traveler layers, then (wave
 // ranges cut inside sweeps, pl.ups > 1) the spill rows of the waves that ran a later part of a sweep over the body's chunk:
-// {first spill row, count} per chunk of CH rows at gtab[2 np / S + 4 W + 2 chunk] (a chunk's spill rows are consecutive, in list order: the
+// {first spill row, count} per chunk of CH rows at gtab[spill_off + 2 chunk] (spill_off = 2 np / S + 4 W) (a chunk's spill rows are consecutive, in list order: the
 // row addresses hang on ONE table load, like the layers').  Fixed order.  The body's own state is requested before the sums.
+// The arguments: the table pointer, the shifts and the spill lists' offset lie inside the 14 dwords the hardware preloads into SGPRs, so
+// the two table reads go out in the wave's first instructions, together with the rest of the arguments (round 5: the plan struct by
+// value and `S` behind it put the table read behind a round trip for the arguments, and a software division in front of it).
 template <typename T, int R>
-__global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::type* __restrict__ bodies, typename vec4<T>::type* __restrict__ vel,
-                                                           typename vec4<T>::type* __restrict__ acc, const SymRowT<T>* __restrict__ partial,
-                                                           const uint32_t* __restrict__ gtab, uint32_t n, const SymWPlan pl, uint32_t S, T dt,
-                                                           typename vec4<T>::type* __restrict__ gout, T G, const SymRowT<T>* __restrict__ spill,
-                                                           uint32_t ch_shift /* log2 of the travelers per chunk */)
+__global__ __launch_bounds__(kBlock) void nb_integrate_symw(const uint32_t* __restrict__ gtab, const SymRowT<T>* __restrict__ partial,
+                                                           typename vec4<T>::type* __restrict__ bodies, typename vec4<T>::type* __restrict__ vel,
+                                                           typename vec4<T>::type* __restrict__ acc,
+                                                           const uint32_t n, const uint32_t shifts /* log2 S | log2 (travelers per chunk) << 8 */,
+                                                           const uint32_t np, const uint32_t spill_off /* word offset of the spill lists in gtab; 0: whole sweeps */,
+                                                           const SymRowT<T>* __restrict__ spill_arg /* read by hand below */, typename vec4<T>::type* __restrict__ gout, const T dt, const T G,
+                                                           const uint32_t t_layer0, const uint32_t r_layer0, const uint32_t nsb, const uint32_t n_hi,
+                                                           const uint32_t H, const uint32_t zc)
 {
     using V4 = typename vec4<T>::type;
+    const struct { uint32_t np, nsb, n_hi, H, r_layer0, t_layer0, zc; } pl{np, nsb, n_hi, H, r_layer0, t_layer0, zc};
+    const uint32_t s_shift = shifts & 0xffu, ch_shift = shifts >> 8;
+    constexpr int kSpillArgOffset = 5 * 8 + 4 * 4;      // byte offset of `spill_arg` in the kernel arguments: five pointers and four words in front of it
     const uint32_t gid = blockIdx.x * kBlock + threadIdx.x;
     const uint32_t il = gid / R, r = gid % R;
     const bool valid = il < n;
@@ -965,21 +1019,28 @@ __global__ __launch_bounds__(kBlock) void nb_integrate_symw(typename vec4<T>::ty
         // entries are the same for the whole workgroup -- scalar loads
         static_assert((kBlock / R) <= 64 && 64 % (kBlock / R) == 0, "a workgroup's bodies stay inside one 64-row chunk");
         const uint32_t il0 = blockIdx.x * (kBlock / R);
-        const uint32_t b = il0 / S;
+        const uint32_t b = il0 >> s_shift;
         // (the two table reads -- resident layers of the block, spill rows of the chunk -- are requested TOGETHER: with the second one
         // under `if (ups > 1)` the compiler waited for the first before it issued it, one more scalar round trip in front of the rows;
         // whole-sweep plans have no spill table: they re-read the block's own entry and ignore it)
         const uint32_t ci0 = il0 >> ch_shift;
-        const uint32_t* const ent = gtab + (pl.ups > 1 ? 2 * (pl.np / S) + 4 * pl.W + 2 * ci0 : 2 * b);
-        const uint32_t nr = gtab[2 * b + 1], ent0 = ent[0], ent1 = ent[1];
+        // (as explicit instructions: the compiler split two plain loads into three single-word loads, each behind the wait for the one
+        // before, and sank the load of the `spill` argument -- the first one behind the preloaded part, used under conditions only --
+        // behind that wait: it is requested here, from its place in the kernel arguments, together with the table entries)
+        unsigned long long blk, ent, spill_bits;
+        asm volatile("s_load_dwordx2 %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dwordx2 %2, %5, %6\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(blk), "=&s"(ent), "=&s"(spill_bits)
+                     : "s"(gtab + 2 * b), "s"(gtab + (spill_off ? spill_off + 2 * ci0 : 2 * b)), "s"(__builtin_amdgcn_kernarg_segment_ptr()), "n"(kSpillArgOffset) : "memory");
+        const SymRowT<T>* const spill = (const SymRowT<T>*)spill_bits;
+        const uint32_t nr = (uint32_t)(blk >> 32), ent0 = (uint32_t)ent, ent1 = (uint32_t)(ent >> 32);
         // traveler sums: a row of a whole super-block has one layer per ring distance; a row of the short block Z (b == pl.nsb) has
         // the z-rows instead -- one per whole super-block, row g * zc + c of the spill buffer (c: its chunk inside Z)
         const bool zb = b >= pl.nsb;
         const uint32_t nt = zb ? pl.nsb : pl.H + ((pl.n_hi && b >= pl.n_hi) ? 1u : 0u);
         uint32_t ns = 0, s_first = 0;
         const uint32_t ci = il0 >> ch_shift;
-        const uint32_t zci = ci - ((pl.nsb * S) >> ch_shift);
-        if (pl.ups > 1) { s_first = ent0; ns = ent1; }
+        const uint32_t zci = ci - (pl.nsb << (s_shift - ch_shift));
+        if (spill_off) { s_first = ent0; ns = ent1; }
         const uint32_t total = nr + nt + ns;
         auto row = [&](uint32_t e) {
             if (e < nr) return partial + (size_t)(pl.r_layer0 + e) * pl.np + il;

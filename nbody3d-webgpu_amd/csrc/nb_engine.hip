@@ -274,15 +274,15 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
         const void* b = jstream(s, s->cur);                // f32: rows (x, y, z, G*m); f64: (x, y, z, m) and G
         void* p = s->partial;
         const uint32_t* tab = s->sym_tab;
-        uint32_t n = s->n;
         void* sp = s->sym_spill;                           // one row set per wave (wave ranges cut inside sweeps); null with whole sweeps
+        // (the order of kernels/symmetric.hip.h SYMW_PLAN_PARAMS: the table pointer and the plan words inside the preloaded 14 dwords)
         if (s->f64) {
             double G = s->G, e2 = s->eps2;
-            void* args[] = {&b, &p, &tab, &pl, &n, &G, &e2, &sp};
+            void* args[] = {&tab, &b, &p, &sp, &pl.W, &pl.ups, &pl.nsb, &pl.zc, &pl.r_layer0, &pl.t_layer0, &G, &e2};
             launch_kernel(kernel_of(true, sh), dim3(ceil_div(pl.W, 4u)), dim3(256), args, s->stream, t0, t1);
         } else {
             float e2 = (float)s->eps2;
-            void* args[] = {&b, &p, &tab, &pl, &n, &e2, &sp};
+            void* args[] = {&tab, &b, &p, &sp, &pl.W, &pl.ups, &pl.nsb, &pl.zc, &pl.r_layer0, &pl.t_layer0, &e2};
             launch_kernel(kernel_of(false, sh), dim3(ceil_div(pl.W, 4u)), dim3(256), args, s->stream, t0, t1);
         }
         return;
@@ -389,8 +389,10 @@ void launch_integrate(nb_sim* s, hipEvent_t t0 = nullptr, hipEvent_t t1 = nullpt
         const nb::SymRowT<T>* pp = (const nb::SymRowT<T>*)s->partial;
         const uint32_t* tab = s->sym_tab;
         uint32_t n = s->n, S = ipb_of(shape_of(s)), ch_shift = s->ws == 3 ? 6u : 7u;      // travelers per chunk: X = 3 one per lane (64), X = 1 two (128)
+        uint32_t shifts = (uint32_t)__builtin_ctz(S) | ch_shift << 8;                       // (S is a power of two: 64 * residents per lane)
+        uint32_t spill_off = pl.ups > 1 ? 2u * (pl.np / S) + 4u * pl.W : 0u;                // the spill lists behind the wave records (lay_out_symw)
         const void* sp = s->sym_spill;
-        void* args[] = {&b, &v, &aa, &pp, &tab, &n, &pl, &S, &dt, &gout, &G, &sp, &ch_shift};
+        void* args[] = {&tab, &pp, &b, &v, &aa, &n, &shifts, &pl.np, &spill_off, &sp, &gout, &dt, &G, &pl.t_layer0, &pl.r_layer0, &pl.nsb, &pl.n_hi, &pl.H, &pl.zc};
         launch_kernel((const void*)&nb::nb_integrate_symw<T, 8>, dim3(ceil_div(n * 8u, nb::kBlock)), dim3(nb::kBlock), args, s->stream, t0, t1);
         return;
     }
