@@ -56,3 +56,8 @@ for n in sizes:
         xcc = (t[:, 7] >> 32) & 0xf
         print("   start / end (us after the first wave's start) by eighth of the wave numbers: " + "  ".join("%.2f/%.2f" % (start[oct_ == o].mean(), end[oct_ == o].mean()) for o in range(8)))
         print("   ... by XCD: " + "  ".join("x%d %.2f/%.2f" % (x, start[xcc == x].mean(), end[xcc == x].mean()) for x in sorted(set(xcc.tolist()))), flush=True)
+        # the clock every XCD ran at (shader cycles per 10 ns tick over the wave's life), the time its waves were alive, and whether workgroup b ran on XCD b % 8
+        ghz = (t[:, 4] - t[:, 0]) / np.maximum(1, (real1 - real0)) / 10.0
+        life = (real1 - real0) / 100.0
+        print("   ... clock GHz / wave life us by XCD: " + "  ".join("x%d %.3f/%.2f" % (x, np.median(ghz[xcc == x]), life[xcc == x].mean()) for x in sorted(set(xcc.tolist())))
+              + "   workgroup b on XCD b %% 8: %.1f %%" % (100.0 * np.mean(xcc == (widx // 4) % 8)), flush=True)
