@@ -174,13 +174,16 @@ double sym_layer_budget(const nb_config& cfg, double device_mem)
 // of them and the launch lasts as long as its longest SIMD: at N = 16,384 (4.1 sweeps per SIMD) some SIMDs run 5 -- 56 us against
 // 44 us of pair work (profiles/r04/step_parts_base.txt).  Quarter sweeps (16 rotation steps) bring that to 4.25.  A system with
 // dozens of sweeps per wave does not need them.
-uint32_t sym_units(uint64_t L, uint32_t W, bool whole_only, bool one_wave_per_simd = false)
+uint32_t sym_units(uint64_t L, uint32_t W, bool whole_only, bool whole_system = false)
 {
     if (whole_only || W == 0) return 1;
-    if (one_wave_per_simd && L < (uint64_t)2 * W) return 32u;
-    // eighths below a dozen sweeps per wave (N = 16,384: 57.2 vs 58.3 us); with ONE wave per SIMD and less than two sweeps to its name a
-    // range is cut to 2 rotation steps (above: N = 9,000, 8 residents per lane: 24.5 -> 23.75 us, N = 10,000: 27.6 -> 27.0; nothing from
-    // 12,000 up or with 16 residents: profiles/r05/ups_16_32_64_scan.txt)
+    // The whole-system form cuts a range to 2 rotation steps when a wave has fewer than five sweeps to its name: with eighths a wave's
+    // share rounds to +-1 of 8 .. 40 units.  Round 5 first took it for one-wave plans below two sweeps per wave (N = 9,000, 8 residents per
+    // lane: 24.5 -> 23.75 us); with the four-word wave records it pays at every resident count and at two waves per SIMD up to N ~ 32,768
+    // (14,000: 42.1 -> 41.0 us, 18,000: 61.9 -> 60.4, 22,000: 86.0 -> 84.2, 28,000: 130.7 -> 129.7, 32,768: 170.9 -> 170.2; level from
+    // 40,002: profiles/r05/sym_units_scan_u32_mid_sizes.txt).  The rank form keeps eighths (its phases were fitted with them).
+    if (whole_system && L < (uint64_t)5 * W) return 32u;
+    // eighths below a dozen sweeps per wave (N = 16,384: 57.2 vs 58.3 us), quarters below 48
     return L < (uint64_t)12 * W ? 8u : L < (uint64_t)48 * W ? 4u : 1u;
 }
 
@@ -209,14 +212,14 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
         const uint64_t total_hi = (uint64_t)(H + 1 + (n_hi ? 1u : 0u)) * cps + zc, total_lo = (uint64_t)(H + 1) * cps + zc;
         const uint64_t L = n_hi * total_hi + (nsb - n_hi) * total_lo + zc - ((uint64_t)nsb * cps + zc) / 8u;      // (a sweep over an own chunk counts 7/8)
         // f64: 92 issue cycles per resident and step + 14 DPP; the loop runs at 96 % of that (N = 262,144: 23.7 ms, profiles/r03/sym_f64_first.txt)
-        const double t_chunk = f64 ? 64.0 * (92.0 * ipl + 56.0) / 0.96 / clock : 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.95 : 0.935) / clock;
+        const double t_chunk = f64 ? 64.0 * (92.0 * ipl + 56.0) / 0.96 / clock : 64.0 * (80.0 * NG + 40.0) / (NG == 8 ? 0.97 : 0.935) / clock;      // (16 residents: 0.95 until round 5's scan of N = 14,000 .. 28,000, profiles/r05/sym_units_scan_u32_mid_sizes.txt)
         const double simds = 4.0 * n_cu, per_simd = (double)L / simds;
         if (per_simd < 0.6) continue;                // (with ranges cut to 2 rotation steps a wave needs no whole sweep to its name: N = 7,000, 0.8 sweeps per SIMD)
         for (uint32_t k = 1; k <= 2; ++k) {
             if (k == 2 && per_simd < 2.0) continue;      // every wave needs a whole sweep or so of work
             // units per sweep: whole sweeps when a wave's share happens to round well (N = 11,000: 1.93 sweeps per wave, 31.3 us against
             // 32.7 with eighths), else eighths below a dozen sweeps per wave, quarters below 48 (sym_units)
-            const uint32_t ups_fine = sym_units(L, (uint32_t)simds * k, whole_only, k == 1);
+            const uint32_t ups_fine = sym_units(L, (uint32_t)simds * k, whole_only, true);
             for (uint32_t ups : {1u, ups_fine}) {
                 if (ups == 1 && ups_fine > 1 && (k == 2 || per_simd >= 4.0)) continue;       // one wave per SIMD and a few sweeps only: with two waves the
                                                                                              // rounding below is an average, good for fine units only
@@ -232,10 +235,14 @@ SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool
                 // two waves of 16 residents per SIMD pay ~2 us for their second set of resident loads; a range cut inside sweeps costs
                 // ~1.5 us (the travelers of the shared sweeps are loaded twice, their sums stored twice)
                 // (round 5, profiles/r05/sym_small_n_scan.txt: with 8 residents per lane and 32 units per sweep the estimate sat 1.2-1.6 us over
-                // the measured step from N = 8,192 to 10,000: 0.2 us for the cut there instead of 1.5; 16 residents keep the 1.5 --
-                // N = 9,500 .. 13,000 measured 0.5-1.3 us OVER the estimate without it)
-                const double t = sweeps * t_chunk + 2.3e-6 + segs * 1.66e-6 + (ups > 1 ? (ups >= 32 && ipl == 8 ? 0.2e-6 : 1.5e-6) : 0.0) + (k == 2 && ipl == 16 ? 2.1e-6 : 0.0) + boundary
+                // the measured step from N = 8,192 to 10,000: 0.2 us for the cut there instead of 1.5; 16 residents and 32 units: 1.0 us, with the
+                // loop at 0.97 of its issue count instead of 0.95 -- within 1 us from N = 9,000 to 32,768 except 20,000 / 24,000 (2.5 under),
+                // profiles/r05/sym_units_scan_u32_mid_sizes.txt)
+                const double t = sweeps * t_chunk + 2.3e-6 + segs * 1.66e-6 + (ups > 1 ? (ups >= 32 ? (ipl == 8 ? 0.2e-6 : 1.0e-6) : 1.5e-6) : 0.0) + (k == 2 ? (ipl == 16 ? 2.1e-6 : 0.6e-6) : 0.0) + boundary
                                  + layers * n * (f64 ? 24.0 : 12.0) / 20.0e12;
+#ifdef NB_TUNING
+                if (getenv("NB_MODEL_TRACE")) fprintf(stderr, "  sym_estimate n=%u: %d residents, %u waves per SIMD, %u units per sweep: %.2f us\n", n, ipl, k, ups, 1e6 * t);
+#endif
                 if (t < best.t) best = {ipl, k, ups, t};
                 if (ups_fine == 1) break;
             }
@@ -271,7 +278,7 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, c
     auto total_of = [&](uint32_t g) { return g < n_hi ? pl.total_hi : g < nsb ? pl.total_lo : zc; };
     const uint32_t kw = sym_k ? sym_k : (cfg.jsplit ? cfg.jsplit : 1u);
     uint32_t W = 4u * (uint32_t)n_cu * kw;
-    const uint32_t ups = (cfg.flags & NB_FLAG_WHOLE_SWEEPS) ? 1u : (sym_ups ? sym_ups : sym_units(pl.L, W, false, kw == 1));
+    const uint32_t ups = (cfg.flags & NB_FLAG_WHOLE_SWEEPS) ? 1u : (sym_ups ? sym_ups : sym_units(pl.L, W, false, true));
     pl.ups = ups;
     const uint64_t Lu = (uint64_t)pl.L * ups;                  // the list in units
     if (W > Lu) W = (uint32_t)Lu;                               // never more waves than units: every wave has work, so every resident layer the table

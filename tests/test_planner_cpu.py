@@ -422,8 +422,8 @@ def test_shard_own_splits_lie_inside_the_shard(n, g):
 
 def test_model_choice_table():
     """The automatic choice at the sizes DESIGN.md quotes (256 CUs, 2.4 GHz): a change of the cost model shows up here."""
-    want = {1024: "f32pk_fused_regs1024", 6500: "f32pk_fused_lds2048", 7000: "f32pk_symw_ipl8_j1_w1024_r22t6_u32", 8192: "f32pk_symw_ipl8_j1_w1024_r19t8_u32", 9000: "f32pk_symw_ipl8_j1_w1024_r16t8_u32", 11000: "f32pk_symw_ipl16_j1_w1012_r27t5", 13000: "f32pk_symw_ipl16_j1_w1024_r25t6_u32", 16384: "f32pk_symw_ipl16_j1_w1024_r19t8_u8", 20000: "f32pk_symw_ipl16_j1_w1024_r16t9_u8", 40002: "f32pk_symw_ipl16_j1_w2048_r17t19_u8",
-            65536: "f32pk_symw_ipl16_j1_w2048", 262144: "f32pk_symw_ipl16_j1_w2048_r5t128", 1048576: "f32pk_symw_ipl16_j1_w2048"}
+    want = {1024: "f32pk_fused_regs1024_ipl2_ls64", 6500: "f32pk_fused_lds2048_ipl2_ls32", 7000: "f32pk_symw_ipl8_j1_w1024_r22t6_u32", 8192: "f32pk_symw_ipl8_j1_w1024_r19t8_u32", 9000: "f32pk_symw_ipl8_j1_w1024_r16t8_u32", 10000: "f32pk_symw_ipl16_j1_w1024_r30t4_u32", 11000: "f32pk_symw_ipl16_j1_w1012_r27t5",
+            13000: "f32pk_symw_ipl16_j1_w1024_r25t6_u32", 16384: "f32pk_symw_ipl16_j1_w1024_r19t8_u32", 20000: "f32pk_symw_ipl16_j1_w2048_r31t9_u32", 40002: "f32pk_symw_ipl16_j1_w2048_r17t19_u8", 65536: "f32pk_symw_ipl16_j1_w2048", 262144: "f32pk_symw_ipl16_j1_w2048_r5t128", 1048576: "f32pk_symw_ipl16_j1_w2048"}
     for n, prefix in want.items():
         assert capi.plan_query(n)["variant"].startswith(prefix), (n, capi.plan_query(n)["variant"])
     assert capi.plan_query(262144, precision="f64")["variant"].startswith("f64_symw_ipl8_j1_w2048")
