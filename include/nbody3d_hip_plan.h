@@ -37,7 +37,9 @@ extern "C" {
  *                      block of rows (sym_np / rows per super-block: the short block last); then FOUR words per wave (4 * workgroup +
  *                      wave in it) -- {first unit, end, resident layer of the super-block the range ends in, spill row}: the ranges
  *                      partition the list of units (with two waves per SIMD consecutive ranges alternate between wave i and wave
- *                      W / 2 + i, and the first of the two is the longer one); with sym_ups > 1 followed by the spill lists -- {first
+ *                      W / 2 + i, and the first of the two is the longer one; with whole sweeps its record ends a few sweeps short of
+ *                      the next range: those are the queued pieces, {first unit, resident layer | sweeps << 16} each, behind the
+ *                      records, which every wave draws from when its own part is done); with sym_ups > 1 followed by the spill lists -- {first
  *                      spill row, count} per traveler chunk (2 * sym_np / 64 words), then the wave numbers in spill-row order;
  *                      tab_len reports how many words there are
  *   sym_ups            work units per chunk-sweep: the wave ranges are floor/ceil-equal in units of 64 / sym_ups rotation steps */

@@ -253,7 +253,8 @@ __device__ __forceinline__ SymWK symw_plan_words(uint32_t S, uint32_t cps, uint3
 template <int NG, int J>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NG >= 4 ? 2 : 4, NG > 4 ? 2 : (NG < 4 ? 8 : 4))))
 void nb_force_symw(const uint32_t* __restrict__ gtab, const float4* __restrict__ bodies, SymRow* __restrict__ partial, SymRow* __restrict__ spill,
-                   SYMW_PLAN_PARAMS, const float eps2_arg /* read by hand, with the table record: symw_record_and_tail */)
+                   SYMW_PLAN_PARAMS, const float eps2_arg /* read by hand, with the table record: symw_record_and_tail */,
+                   uint32_t* __restrict__ queue, const uint32_t npieces, const uint32_t pieces_off)
 {
     constexpr uint32_t S = 128u * NG;          // rows per super-block = one wave's residents
     constexpr int GW = NG < 4 ? NG : 4;        // packed groups evaluated stage-major together
@@ -281,15 +282,17 @@ void nb_force_symw(const uint32_t* __restrict__ gtab, const float4* __restrict__
     uint32_t tail[1];
     symw_record_and_tail(gtab + tab1 + 4u * (active ? w : 0u), rec, tail);
     const float eps2 = __builtin_bit_cast(float, tail[0]);
-    uint32_t u = active ? rec.x : 0u;
-    const uint32_t uend = active ? rec.y : 0u;
     const nb_f2 e2 = nb_f2{eps2, eps2};
     const uint32_t first_lo = pl.n_hi * pl.total_hi, first_z = first_lo + (pl.nsb - pl.n_hi) * pl.total_lo;
     const uint32_t slot = rec.w;               // the wave's spill row (it has at most one: the sweep its range starts inside)
-    uint32_t gfin = ~0u;                       // the super-block the range ends in
     NB_STAMP_LIGHT(1);
     bool first_part = true;                    // (diagnostic stamps only; dead in the product build)
 
+    // The units [u, uend) of the list.  piece_layer == ~0u: the wave's own range -- the sums of the super-block it ends in are left in
+    // `red` for the workgroup's meeting below, and that super-block is returned; else a piece drawn from the queue (whole sweeps inside ONE
+    // super-block's list), whose resident sums go straight to the resident layer the planner gave it.
+    auto run = [&](uint32_t u, const uint32_t uend, const uint32_t piece_layer) -> uint32_t {
+    uint32_t gfin = ~0u;                       // the super-block the range ends in
     while (u < uend) {
         // which super-block's list the unit lies in, and where
         const uint32_t p = u >> ush;                                  // the sweep
@@ -436,6 +439,19 @@ void nb_force_symw(const uint32_t* __restrict__ gtab, const float4* __restrict__
                 for (int uu = 0; uu < J; ++uu) out[uu * 64] = SymRow{bx[uu].x + bx[uu].y, by[uu].x + by[uu].y, bz[uu].x + bz[uu].y};
             }
         }
+        if (u >= uend && piece_layer != ~0u) {
+            SymRow* out = partial + (size_t)(pl.r_layer0 + piece_layer) * pl.np + (size_t)g * S + lane;
+#pragma unroll
+            for (int c = 0; c < NG; ++c) {
+                if (flushed) {         // (a long piece of a very large system: second level + what the registers hold)
+                    ax[c].x += red[wi][6 * c + 0][lane]; ay[c].x += red[wi][6 * c + 1][lane]; az[c].x += red[wi][6 * c + 2][lane];
+                    ax[c].y += red[wi][6 * c + 3][lane]; ay[c].y += red[wi][6 * c + 4][lane]; az[c].y += red[wi][6 * c + 5][lane];
+                }
+                out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
+                out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
+            }
+            return g;
+        }
         if (u >= uend) {
             // the range ends here: the sums meet those of the workgroup's other waves in LDS (below)
             gfin = g;
@@ -463,6 +479,9 @@ void nb_force_symw(const uint32_t* __restrict__ gtab, const float4* __restrict__
             out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
         }
     }
+    return gfin;
+    };
+    const uint32_t gfin = run(active ? rec.x : 0u, active ? rec.y : 0u, ~0u);
     // The resident sums of the super-block the range ends in: the waves of the workgroup that end in the same one (consecutive
     // waves share a super-block when there are more waves than super-blocks: N = 16,384 has 64 per super-block) add theirs up in LDS,
     // in wave order, and store ONE row set -- the layer of their table records (the same for all of them) -- a quarter of the resident layers K2 reads.
@@ -470,7 +489,7 @@ void nb_force_symw(const uint32_t* __restrict__ gtab, const float4* __restrict__
     if (lane == 0) fin[wi] = gfin;
     __syncthreads();
     NB_STAMP_LIGHT(9);
-    if (gfin == ~0u) return;
+    if (gfin != ~0u) {
     int members = 0, mine = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -485,6 +504,21 @@ void nb_force_symw(const uint32_t* __restrict__ gtab, const float4* __restrict__
         for (int j = 0; j < 4; ++j)
             if (fin[j] == gfin) { sx += red[j][3 * r + 0][lane]; sy += red[j][3 * r + 1][lane]; sz += red[j][3 * r + 2][lane]; }
         out[r * 64] = SymRow{sx, sy, sz};
+    }
+    }
+    // The queue (two waves per SIMD, whole sweeps; nb_plan.cpp::lay_out_symw): the last sweeps of every older wave's range are nobody's
+    // own -- a wave that is done draws them one at a time, so the XCDs that hold a higher clock (or started earlier) take more of them
+    // and the launch no longer waits for its slowest XCD.  A queued sweep's sums have a layer of their own: which wave ran it does not
+    // show in the results.
+    if (npieces) {
+        for (;;) {
+            uint32_t id = 0;
+            if (lane == 0) id = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            id = __builtin_amdgcn_readfirstlane(id);
+            if (id >= npieces) break;
+            const uint32_t pu = gtab[pieces_off + 2u * id], ll = gtab[pieces_off + 2u * id + 1u];      // {first unit, resident layer | sweeps << 16}
+            (void)run(pu, pu + (ll >> 16), ll & 0xffffu);
+        }
     }
     NB_STAMP(4);
 }
@@ -510,7 +544,8 @@ __device__ __forceinline__ double wave_rot1(double v)
 template <int IPL>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 void nb_force_symw64(const uint32_t* __restrict__ gtab, const double4* __restrict__ bodies, SymRowT<double>* __restrict__ partial, SymRowT<double>* __restrict__ spill,
-                     SYMW_PLAN_PARAMS, const double G_arg, const double eps2_arg /* both read by hand: symw_record_and_tail */)
+                     SYMW_PLAN_PARAMS, const double G_arg, const double eps2_arg /* both read by hand: symw_record_and_tail */,
+                     uint32_t* __restrict__ queue, const uint32_t npieces, const uint32_t pieces_off)
 {
     constexpr uint32_t S = 64u * IPL, CH = 64u, CPS = S / CH;
     const SymWK pl = symw_plan_words(S, CPS, W_, ups_, nsb_, zc_, r_layer0_, t_layer0_);
@@ -526,10 +561,9 @@ void nb_force_symw64(const uint32_t* __restrict__ gtab, const double4* __restric
     uint32_t tail[4];
     symw_record_and_tail(gtab + tab1 + 4u * (active ? w : 0u), rec, tail);
     const double G = __builtin_bit_cast(double, (unsigned long long)tail[1] << 32 | tail[0]), eps2 = __builtin_bit_cast(double, (unsigned long long)tail[3] << 32 | tail[2]);
-    uint32_t u = active ? rec.x : 0u;
-    const uint32_t uend = active ? rec.y : 0u;
     const uint32_t first_lo = pl.n_hi * pl.total_hi, first_z = first_lo + (pl.nsb - pl.n_hi) * pl.total_lo;
     const uint32_t slot = rec.w;
+    auto run = [&](uint32_t u, const uint32_t uend, const uint32_t piece_layer) -> uint32_t {      // see nb_force_symw: the wave's own range, or a piece drawn from the queue
     uint32_t gfin = ~0u;
     while (u < uend) {
         const uint32_t p = u >> ush;
@@ -606,6 +640,12 @@ void nb_force_symw64(const uint32_t* __restrict__ gtab, const double4* __restric
                 *out = SymRowT<double>{bx, by, bz};
             }
         }
+        if (u >= uend && piece_layer != ~0u) {
+            SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + piece_layer) * pl.np + (size_t)g * S + lane;
+#pragma unroll
+            for (int c = 0; c < IPL; ++c) out[c * 64] = SymRowT<double>{ax[c], ay[c], az[c]};
+            return g;
+        }
         if (u >= uend) {
             gfin = g;
 #pragma unroll
@@ -616,9 +656,12 @@ void nb_force_symw64(const uint32_t* __restrict__ gtab, const double4* __restric
 #pragma unroll
         for (int c = 0; c < IPL; ++c) out[c * 64] = SymRowT<double>{ax[c], ay[c], az[c]};
     }
+    return gfin;
+    };
+    const uint32_t gfin = run(active ? rec.x : 0u, active ? rec.y : 0u, ~0u);
     if (lane == 0) fin[wi] = gfin;
     __syncthreads();
-    if (gfin == ~0u) return;
+    if (gfin != ~0u) {
     int members = 0, mine = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -633,6 +676,17 @@ void nb_force_symw64(const uint32_t* __restrict__ gtab, const double4* __restric
         for (int j = 0; j < 4; ++j)
             if (fin[j] == gfin) { sx += red[j][3 * r + 0][lane]; sy += red[j][3 * r + 1][lane]; sz += red[j][3 * r + 2][lane]; }
         out[r * 64] = SymRowT<double>{sx, sy, sz};
+    }
+    }
+    if (npieces) {                             // the queue: see nb_force_symw
+        for (;;) {
+            uint32_t id = 0;
+            if (lane == 0) id = __hip_atomic_fetch_add(queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            id = __builtin_amdgcn_readfirstlane(id);
+            if (id >= npieces) break;
+            const uint32_t pu = gtab[pieces_off + 2u * id], ll = gtab[pieces_off + 2u * id + 1u];
+            (void)run(pu, pu + (ll >> 16), ll & 0xffffu);
+        }
     }
 }
 

@@ -187,6 +187,7 @@ void plan_handle(nb_sim* s, const nb_config& cfg, int n_cu, double clock_hz, dou
     s->sym_local = p.sym_local;
     s->sym_tab_host = std::move(p.sym_tab_host);
     s->sym_spill_rows = p.sym_spill_rows;
+    s->sym_pieces = p.sym_pieces;
     s->variant = std::move(p.variant);
 }
 
@@ -276,13 +277,16 @@ void launch_force(nb_sim* s, int part = 0, hipEvent_t t0 = nullptr, hipEvent_t t
         const uint32_t* tab = s->sym_tab;
         void* sp = s->sym_spill;                           // one row set per wave (wave ranges cut inside sweeps); null with whole sweeps
         // (the order of kernels/symmetric.hip.h SYMW_PLAN_PARAMS: the table pointer and the plan words inside the preloaded 14 dwords)
+        uint32_t* queue = s->sym_queue;
+        uint32_t npieces = s->sym_pieces, pieces_off = 2u * (pl.np / ipb_of(sh)) + 4u * pl.W;      // the queued sweeps behind the wave records (lay_out_symw)
+        if (npieces) (void)hipMemsetAsync(queue, 0, sizeof(uint32_t), s->stream);                  // the queue's draw counter
         if (s->f64) {
             double G = s->G, e2 = s->eps2;
-            void* args[] = {&tab, &b, &p, &sp, &pl.W, &pl.ups, &pl.nsb, &pl.zc, &pl.r_layer0, &pl.t_layer0, &G, &e2};
+            void* args[] = {&tab, &b, &p, &sp, &pl.W, &pl.ups, &pl.nsb, &pl.zc, &pl.r_layer0, &pl.t_layer0, &G, &e2, &queue, &npieces, &pieces_off};
             launch_kernel(kernel_of(true, sh), dim3(ceil_div(pl.W, 4u)), dim3(256), args, s->stream, t0, t1);
         } else {
             float e2 = (float)s->eps2;
-            void* args[] = {&tab, &b, &p, &sp, &pl.W, &pl.ups, &pl.nsb, &pl.zc, &pl.r_layer0, &pl.t_layer0, &e2};
+            void* args[] = {&tab, &b, &p, &sp, &pl.W, &pl.ups, &pl.nsb, &pl.zc, &pl.r_layer0, &pl.t_layer0, &e2, &queue, &npieces, &pieces_off};
             launch_kernel(kernel_of(false, sh), dim3(ceil_div(pl.W, 4u)), dim3(256), args, s->stream, t0, t1);
         }
         return;
@@ -735,6 +739,10 @@ int nb_create(const nb_config* cfg_in, nb_sim** out)
             NB_HIPC(hipMalloc(&s->sym_spill, (size_t)3 * s->esz * s->sym_spill_rows));
             NB_HIPC(hipMemset(s->sym_spill, 0, (size_t)3 * s->esz * s->sym_spill_rows));
         }
+        if (s->symw && s->sym_pieces) {
+            NB_HIPC(hipMalloc((void**)&s->sym_queue, 64));
+            NB_HIPC(hipMemset(s->sym_queue, 0, 64));
+        }
         if (s->symw) {
             NB_HIPC(hipMalloc((void**)&s->sym_tab, sizeof(uint32_t) * s->sym_tab_host.size()));
             NB_HIPC(hipMemcpy(s->sym_tab, s->sym_tab_host.data(), sizeof(uint32_t) * s->sym_tab_host.size(), hipMemcpyHostToDevice));
@@ -795,6 +803,7 @@ void nb_destroy(nb_sim* s)
     if (s->tickets) (void)hipFree(s->tickets);
     if (s->sym_tab) (void)hipFree(s->sym_tab);
     if (s->sym_spill) (void)hipFree(s->sym_spill);
+    if (s->sym_queue) (void)hipFree(s->sym_queue);
     if (s->sym_A) (void)hipFree(s->sym_A);
     if (s->diag) (void)hipFree(s->diag);
     if (s->zero_row) (void)hipFree(s->zero_row);

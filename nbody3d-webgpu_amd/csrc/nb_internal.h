@@ -99,6 +99,8 @@ struct nb_sim {
     std::vector<uint32_t> sym_tab_host;
     void* sym_spill = nullptr;     // ups > 1: one spill row set per wave (traveler sums of the sweep a wave's range starts inside)
     uint32_t sym_spill_rows = 0;
+    uint32_t sym_pieces = 0;       // sweeps in the shared queue of nb_force_symw (nb_plan.cpp::lay_out_symw)
+    uint32_t* sym_queue = nullptr; // device: the queue's draw counter, zeroed in front of every force launch
     // rank form (NB_FLAG_SYM_SHARD: a shard handle whose cross-rank reduction the engine's native exchange provides): the
     // handle's own rows are the resident super-blocks [sym_g0, sym_g1); sym_A[np] = this rank's sums for EVERY row, reduce-
     // scattered across the ranks before the integrate kernel reads the rank's own rows of it

@@ -119,6 +119,7 @@ struct ModelKnobs {
     double sustained = 0.958;  // share of hipDeviceProp_t::clockRate the chip holds under this kernel's load
                                // (2.24-2.29 of 2.4 GHz measured, profiles/r02/rocprof_f32_default: GRBM_GUI_ACTIVE)
     double jpk_lo = 7000, jpk_hi = 12500;   // sizes at which the j-packed step is scored at all (see plan_launch)
+    double tail = -1.0;        // two waves per SIMD, whole sweeps: part of an older wave's range left to the shared queue (< 0: kTailShare; 0: none) -- lay_out_symw
     double old_share = 0.0;    // two waves per SIMD: share of a pair of ranges given to the OLDER wave of a SIMD (0: kOldShareF32 / F64; 0.5: equal ranges in list order)
 };
 #ifdef NB_TUNING
@@ -131,7 +132,7 @@ ModelKnobs model_knobs()
     m.hand_over = knob("NB_MODEL_HANDOVER", m.hand_over); m.lanes_scale = knob("NB_MODEL_LANES_SCALE", m.lanes_scale);
     m.boundary = knob("NB_MODEL_BOUNDARY", m.boundary); m.sustained = knob("NB_MODEL_SUSTAINED", m.sustained);
     m.jpk_lo = knob("NB_MODEL_JPK_LO", m.jpk_lo); m.jpk_hi = knob("NB_MODEL_JPK_HI", m.jpk_hi);
-    m.old_share = knob("NB_MODEL_OLD_SHARE", m.old_share);
+    m.old_share = knob("NB_MODEL_OLD_SHARE", m.old_share); m.tail = knob("NB_MODEL_TAIL", m.tail);
     return m;
 }
 #else
@@ -195,6 +196,12 @@ constexpr uint32_t kSweepCost = 8, kOwnSweepCost = 7;
 // arms timed in turns (profiles/r05/old_share_paired_interleaved.txt): f32 +1.0 .. +1.7 % per step from N = 40,002 to 1,048,576 at 0.90-0.93
 // (0.95 falls off below 65,536), f64 +3.0 .. +4.2 % at 0.85 (0.9: +1.3 %).
 constexpr double kOldShareF32 = 0.92, kOldShareF64 = 0.85;
+// ... and, with whole sweeps (large systems), the last part of every older wave's range is not the wave's own: its sweeps go to a QUEUE
+// that every wave draws from once its own range is done (one atomic per sweep).  The XCDs of a chip do not hold the same clock
+// (1.4-2.4 % apart under this kernel, which ones differs from box to box: profiles/r05/README.md §6) and start one after the other; the
+// launch used to last as long as its slowest XCD.  Every queued sweep stores its resident sums in a layer of its own, so the sums -- and
+// their order in K2 -- do not depend on which wave ran it: the results stay bit-reproducible.
+constexpr double kTailShare = 0.035;      // (a piece's layer and length share a table word: fewer than 65,536 of either)
 
 SymChoice sym_estimate(uint32_t n, int n_cu, double clock, double boundary, bool f64, double layer_budget, bool whole_only)
 {
@@ -345,35 +352,79 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, c
     }
     auto start_of = [&](uint32_t p) { return (uint64_t)starts[p]; };
     auto pos_of = [&](uint64_t u) { return (uint32_t)(std::upper_bound(starts.begin(), starts.begin() + W, (uint32_t)u) - starts.begin()) - 1u; };
+    // the queued tails (paired ranges of whole sweeps only): own_end[p] = where position p's OWN part ends
+    std::vector<uint32_t> own_end(starts.begin() + 1, starts.end());
+    struct Piece { uint32_t at, len; };
+    std::vector<Piece> pieces;                                  // the queued pieces (whole sweeps), in queue order
+    {
+        const double tail = model_knobs().tail < 0 ? kTailShare : model_knobs().tail;
+        if (paired && ups == 1 && tail > 0) {
+            // a tail is cut into pieces of a third of what is left of it (17 sweeps: 6, 4, 3, 2, 1, 1): the queue hands out every wave's
+            // first piece, then every wave's second ... -- long pieces while there is much to do, single sweeps at the end, when the
+            // length of a piece is what the waves' ends differ by.  A piece stays inside one super-block's list (its resident sums
+            // have one layer): one that would cross a list's end is two.
+            std::vector<std::vector<Piece>> by_rank;
+            for (uint32_t p = 0; p < W; p += 2) {
+                const uint32_t len = starts[p + 1] - starts[p];
+                uint32_t t = std::min(len - 1u, (uint32_t)(tail * len + 0.5));
+                own_end[p] = starts[p + 1] - t;
+                uint32_t at = own_end[p];
+                for (size_t j = 0; t > 0; ++j) {
+                    uint32_t sz = (t + 2u) / 3u;
+                    uint32_t g, k, total;
+                    sweep_at(at, g, k, total);
+                    sz = std::min(sz, total - k);                // to the end of g's list at most
+                    if (by_rank.size() <= j) by_rank.resize(j + 1);
+                    by_rank[j].push_back({at, sz});
+                    at += sz; t -= sz;
+                }
+            }
+            for (const auto& r : by_rank) pieces.insert(pieces.end(), r.begin(), r.end());
+        }
+    }
     const uint32_t nch = pl.np / CH, zrows = nsb * zc;
-    // the table: {first position's wave, resident layers} per block of S rows (Z last); FOUR words per physical wave -- {first unit, end,
-    // resident layer of the super-block the range ends in, spill row}: one 16-byte scalar load; then (ups > 1) the spill lists
+    // the table: {first position's wave, resident layers} per block of S rows (Z last); FOUR words per physical wave -- {first unit, end of
+    // its own part, resident layer of the super-block that part ends in, spill row}: one 16-byte scalar load; then (ups > 1) the spill
+    // lists, or (queued tails) {first unit, resident layer | sweeps << 16} per queued piece
     const size_t waves0 = 2 * (size_t)blocks, spill0 = waves0 + 4 * (size_t)W;
-    s->sym_tab_host.assign(spill0 + (ups > 1 ? 2 * (size_t)nch : 0), 0);
+    s->sym_tab_host.assign(spill0 + (ups > 1 ? 2 * (size_t)nch : 2 * pieces.size()), 0);
     for (uint32_t p = 0; p < W; ++p) {
         uint32_t* rec = &s->sym_tab_host[waves0 + 4 * (size_t)phys[p]];
-        rec[0] = starts[p]; rec[1] = starts[p + 1];
+        rec[0] = starts[p]; rec[1] = own_end[p];
     }
+    std::vector<uint32_t> piece_at;                            // (sorted: which queued pieces lie in a super-block's list)
+    for (const Piece& pc : pieces) piece_at.push_back(pc.at);
+    std::sort(piece_at.begin(), piece_at.end());
+    std::vector<uint32_t> piece_layer(Lu && !pieces.empty() ? (size_t)Lu : 0, 0);      // first unit of a piece -> its resident layer
     uint32_t max_r = 1;
     for (uint32_t g = 0; g < blocks; ++g) {
         const uint64_t off = (uint64_t)offset_of(g) * ups, end = off + (uint64_t)total_of(g) * ups;
         const uint32_t first = pos_of(off), last = pos_of(end - 1);
-        // resident layers of g: the waves whose range ENDS in g's list add their sums up per workgroup of four (in LDS) -- one layer
-        // per workgroup, numbered in list order -- and the last position, if its range goes on into g + 1, stores its part on its own
-        const uint32_t goes_on = start_of(last + 1) > end ? 1u : 0u;
+        // resident layers of g: the waves whose own part ENDS in g's list add their sums up per workgroup of four (in LDS) -- one layer
+        // per workgroup, numbered in list order -- then one layer per queued sweep of g's list, and the last position, if its own part
+        // goes on into g + 1, stores its part on its own (g's LAST layer)
+        const uint32_t goes_on = own_end[last] > end ? 1u : 0u;
         uint32_t layers = 0;
         std::vector<uint32_t> wg_seen;                          // (a handful of workgroups per super-block)
         for (uint32_t p = first; p + goes_on <= last; ++p) {
+            if (std::min<uint64_t>(own_end[p], end) <= std::max<uint64_t>(starts[p], off)) continue;      // only queued sweeps of this position lie in g
             const uint32_t wg = phys[p] >> 2;
             size_t at = 0;
             while (at < wg_seen.size() && wg_seen[at] != wg) ++at;
             if (at == wg_seen.size()) wg_seen.push_back(wg);
             s->sym_tab_host[waves0 + 4 * (size_t)phys[p] + 2] = (uint32_t)at;
         }
-        layers = (uint32_t)wg_seen.size() + goes_on;
+        layers = (uint32_t)wg_seen.size();
+        for (auto it = std::lower_bound(piece_at.begin(), piece_at.end(), (uint32_t)off); it != piece_at.end() && *it < end; ++it) piece_layer[*it] = layers++;
+        layers += goes_on;
         s->sym_tab_host[2 * g] = phys[first]; s->sym_tab_host[2 * g + 1] = layers;
         if (layers > max_r) max_r = layers;
     }
+    for (size_t e = 0; e < pieces.size(); ++e) {                // {first unit, resident layer | sweeps << 16}
+        s->sym_tab_host[spill0 + 2 * e] = pieces[e].at;
+        s->sym_tab_host[spill0 + 2 * e + 1] = piece_layer[pieces[e].at] | pieces[e].len << 16;
+    }
+    s->sym_pieces = (uint32_t)pieces.size();
     // The spill buffer: the z-rows (whole super-block g's sums for chunk c of Z: row g * zc + c), then the spill rows of the waves.
     s->sym_spill_rows = zrows * CH;
     if (ups > 1) {

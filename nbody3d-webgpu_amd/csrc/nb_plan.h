@@ -100,6 +100,7 @@ struct LaunchPlan {
     uint32_t sym_np = 0, sym_layers = 0, sym_g0 = 0, sym_g1 = 0;
     uint32_t sym_plan[16] = {0};         // nb::SymWPlan (symw: 13 words) or nb::SymPlan, as plain words
     uint32_t sym_spill_rows = 0;         // wave-granular form with ups > 1: rows of the spill buffer (W x travelers per chunk)
+    uint32_t sym_pieces = 0;             // whole-system form, two waves per SIMD, whole sweeps: sweeps left to the shared queue ({unit, layer} pairs behind the wave records)
     uint32_t sym_rank_plan[16] = {0};    // rank form: nb::SymRankPlan as plain words (sym_plan then holds the SymWPlan summary: W = WA + WB, L = LA + LB)
     // The rank-form pipeline in PASSES over the ring distances (layers reused from pass to pass, nb_sym_reduce accumulating): one
     // pass for an ordinary rank; several for a whole system whose traveler layers would not fit the layer budget (sym_local: no

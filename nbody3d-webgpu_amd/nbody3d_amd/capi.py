@@ -246,7 +246,10 @@ def plan_query(n, precision="f32", shard=None, force_variant=0, jsplit=0, flags=
                 W = out["plan"]["W"]
                 out["waves"] = tab[2 * nsb:2 * nsb + 4 * W].reshape(-1, 4)
                 out["order"] = np.argsort(out["waves"][:, 0], kind="stable")
-                out["starts"] = np.concatenate([out["waves"][out["order"], 0], out["waves"][out["order"][-1:], 1]])
+                out["starts"] = np.concatenate([out["waves"][out["order"], 0], [out["plan"]["L"] * int(info.sym_ups)]]).astype(np.uint32)
+                # (a wave's record ends where its OWN part ends: with whole sweeps and two waves per SIMD the last sweeps of an older
+                # wave's range are left to a queue -- {first unit, resident layer | sweeps << 16} per queued piece, in queue order, behind the records)
+                out["pieces"] = tab[2 * nsb + 4 * W:].reshape(-1, 2) if int(info.sym_ups) == 1 else np.zeros((0, 2), np.uint32)
         out["ups"], out["spill_rows"] = int(info.sym_ups), int(info.sym_spill_rows)
         if info.symw:
             out["plan"]["ups"] = int(info.sym_ups)

@@ -47,7 +47,7 @@ int main(int argc, char **argv)
         pi.struct_size = sizeof pi;
         uint32_t tab[512];
         int prc = nb_plan_query(&big, 256, 2.4e9, &pi, tab, 512);
-        int ok = prc == NB_OK && pi.sym == 1 && pi.symw == 1 && pi.sym_np == 262144 && pi.tab_len == 512 + 4 * 2048 /* {first wave, resident layers} per super-block + {first unit, end, resident layer, spill row} per wave */ && tab[0] == 0 && tab[1] >= 1 &&
+        int ok = prc == NB_OK && pi.sym == 1 && pi.symw == 1 && pi.sym_np == 262144 && pi.tab_len >= 512 + 4 * 2048 && (pi.tab_len - 512 - 4 * 2048) % 2 == 0 /* {first wave, resident layers} per super-block + {first unit, end, resident layer, spill row} per wave + {first unit, layer | sweeps << 16} per queued piece */ && tab[0] == 0 && tab[1] >= 1 &&
                  strncmp(pi.variant, "f32pk_symw_ipl16_j1_w2048", 25) == 0;
         printf("%s plan query without a device: %s, %u layers\n", ok ? "ok" : "FAIL", pi.variant, pi.sym_layers);
         if (!ok) fails++;

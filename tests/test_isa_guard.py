@@ -229,9 +229,10 @@ def test_symmetric_pass_rotation_loop_is_the_pair_arithmetic_and_the_rotation_on
         loops = innermost_loops(m.group(2))
         # the wave-granular kernels have two forms of the loop: a sweep over an OWN chunk keeps no traveler sums (12 packed + 2 v_rsq
         # per group, 4 rotations; f64: 16 + v_rsq_f64 per resident, 8 rotations); the workgroup form has the one
+        # ... and each of them twice: once for the wave's own range, once for the pieces it draws from the queue afterwards
         two_forms = "symw" in pat
-        assert len(loops) == (2 if two_forms else 1), (pat, len(loops))
-        for both, lp in zip((False, True) if two_forms else (True,), loops):
+        assert len(loops) == (4 if two_forms else 1), (pat, len(loops))
+        for both, lp in zip((False, False, True, True) if two_forms else (True,), loops):
             ops = [l.split()[0] for l in lp if not l.endswith(":")]
             valu = [o for o in ops if o.startswith("v_")]
             assert not any(o.startswith("scratch_") or o.startswith("ds_") or o.startswith("global_") or o.startswith("buffer_") for o in ops), pat

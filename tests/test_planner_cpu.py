@@ -57,7 +57,25 @@ def walk_symw(q, n):
     Lu = L * ups
     starts = q["starts"].astype(np.int64)
     order = q["order"].astype(np.int64)
-    assert sorted(order.tolist()) == list(range(W)) and np.array_equal(q["waves"][order, 1], starts[1:])      # a partition, record ends included
+    assert sorted(order.tolist()) == list(range(W))
+    # a record ends where the wave's OWN part ends: at the next range's start, or (whole sweeps, two waves per SIMD) a few sweeps short of
+    # it -- those sweeps are in the queue that every wave draws from when its own part is done, each exactly once
+    own_end = q["waves"][order, 1].astype(np.int64)
+    pieces = q["pieces"].astype(np.int64)
+    tails = starts[1:] - own_end
+    assert np.all(tails >= 0) and np.all(own_end > starts[:-1]) and tails.sum() == (pieces[:, 1] >> 16).sum()
+    if len(pieces):
+        assert ups == 1 and np.all(tails[1::2] == 0)
+        # a piece = (first unit, resident layer | sweeps << 16): whole sweeps inside ONE super-block's list; together the tails, each sweep once
+        plen = pieces[:, 1] >> 16
+        covered = np.concatenate([np.arange(a0, a0 + l0) for a0, l0 in zip(pieces[:, 0], plen)])
+        want_pieces = np.concatenate([np.arange(own_end[pp], starts[pp + 1]) for pp in range(W)])
+        assert sorted(covered.tolist()) == want_pieces.tolist() and plen.min() >= 1
+        assert np.all(g[pieces[:, 0]] == g[pieces[:, 0] + plen - 1])
+        assert plen[0] >= plen[-1] and plen[-1] == 1                                                 # long pieces first, single sweeps last
+        assert 0.02 < tails[0::2].sum() / (starts[1::2] - starts[0:-1:2]).sum() < 0.05          # ~3.5 % of the older waves' ranges
+    else:
+        assert np.all(tails == 0)
     assert len(starts) == W + 1 and starts[0] == 0 and starts[-1] == Lu and W <= Lu and np.diff(starts).min() >= 1
     work = np.repeat(np.where(sym, 8, 7 if ups > 1 else 8).astype(np.int64), ups)              # per unit (whole sweeps: an even cut)
     per_pos = np.add.reduceat(work, starts[:-1])
@@ -75,11 +93,14 @@ def walk_symw(q, n):
         assert per_pos.max() - per_pos.min() <= 16, (per_pos.min(), per_pos.max())
     pos_u = np.searchsorted(starts, np.arange(Lu, dtype=np.int64), side="right") - 1            # the position of every unit
     assert np.all((pos_u >= 0) & (pos_u < W))
-    wu = order[pos_u]                            # ... and its wave
+    wu = order[pos_u]                            # ... and its wave (a queued sweep: the wave whose range it was cut from; any wave may run it)
+    queued = np.zeros(Lu, bool)
+    for a0, l0 in zip(pieces[:, 0], pieces[:, 1] >> 16):
+        queued[a0:a0 + l0] = True
     w = wu[::ups]                                # the wave that starts each sweep (steps from 0): it owns the sweep's traveler layer / z-row
     w_last = wu[ups - 1::ups]                    # ... and the one that ends it
     return dict(S=S, CH=CH, cps=cps, nsb=nsb, blocks=blocks, zc=zc, H=H, n_hi=n_hi, g=g, k=k, sym=sym, ringsw=ringsw, zsw=zsw, d=d, tb=tb, c=c,
-                tstart=tstart, w=w, w_last=w_last, wu=wu, pos_u=pos_u, order=order, starts=starts, ups=ups, pl=pl, tab=tab)
+                tstart=tstart, w=w, w_last=w_last, wu=wu, pos_u=pos_u, order=order, starts=starts, ups=ups, pl=pl, tab=tab, queued=queued, pieces=pieces)
 
 
 def check_spill_lists(q, n, wk):
@@ -144,21 +165,28 @@ def check_whole_plan(q, n):
     #     their table records name; the last position of the list, if its range goes on into b + 1, writes its part to b's last
     #     layer.  The table = {first wave, layer count}: every layer K2 reads is written exactly once
     gu = np.repeat(g, wk["ups"])
-    starts, order, waves = wk["starts"], wk["order"], q["waves"]
+    starts, order, waves, queued = wk["starts"], wk["order"], q["waves"], wk["queued"]
+    piece_layer = {int(u): int(l) & 0xffff for u, l in wk["pieces"]}
     for b in range(blocks):
         units = np.nonzero(gu == b)[0]
-        ps = np.unique(wk["pos_u"][units])
-        assert order[ps[0]] == tab[b, 0] and ps[-1] - ps[0] + 1 == len(ps), b
-        goes_on = starts[ps[-1] + 1] > units[-1] + 1
-        ending = ps[:-1] if goes_on else ps
-        layer_of_wg = {}
-        for pp in ending:
-            wv = int(order[pp])
-            assert layer_of_wg.setdefault(wv // 4, int(waves[wv, 2])) == int(waves[wv, 2]), (b, wv)      # one row set per workgroup
-        written = sorted(layer_of_wg.values())
+        own = units[~queued[units]]              # the units of b's list that belong to a wave's own part
+        written = []
+        goes_on = False
+        if len(own):
+            ps = np.unique(wk["pos_u"][own])
+            assert order[np.unique(wk["pos_u"][units])[0]] == tab[b, 0], b
+            last_end = int(waves[order[ps[-1]], 1])
+            goes_on = last_end > units[-1] + 1       # the last own part runs on into b + 1
+            ending = ps[:-1] if goes_on else ps
+            layer_of_wg = {}
+            for pp in ending:
+                wv = int(order[pp])
+                assert layer_of_wg.setdefault(wv // 4, int(waves[wv, 2])) == int(waves[wv, 2]), (b, wv)      # one row set per workgroup
+            written = sorted(layer_of_wg.values())
+        written += [piece_layer[int(u)] for u in units[queued[units]] if int(u) in piece_layer]      # every queued piece of b's list: a layer of its own
         if goes_on:
             written.append(int(tab[b, 1]) - 1)
-        assert written == list(range(int(tab[b, 1]))), (b, written, tab[b])
+        assert sorted(written) == list(range(int(tab[b, 1]))), (b, written, tab[b])
     assert pl["r_layer0"] == 0 and tab[:, 1].max() == pl["t_layer0"] == q["jsplit"]
     # (5) traveler layers: K2 (nb_integrate_symw) reads layers t_layer0 + [0, H + (n_hi and b >= n_hi)) of every row of a whole
     #     super-block b -- exactly the set written, once each; for the rows of Z it reads the z-rows g * zc + c of all g instead:
@@ -423,7 +451,7 @@ def test_shard_own_splits_lie_inside_the_shard(n, g):
 def test_model_choice_table():
     """The automatic choice at the sizes DESIGN.md quotes (256 CUs, 2.4 GHz): a change of the cost model shows up here."""
     want = {1024: "f32pk_fused_regs1024_ipl2_ls64", 6500: "f32pk_fused_lds2048_ipl2_ls32", 7000: "f32pk_symw_ipl8_j1_w1024_r22t6_u32", 8192: "f32pk_symw_ipl8_j1_w1024_r19t8_u32", 9000: "f32pk_symw_ipl8_j1_w1024_r16t8_u32", 10000: "f32pk_symw_ipl16_j1_w1024_r30t4_u32", 11000: "f32pk_symw_ipl16_j1_w1012_r27t5",
-            13000: "f32pk_symw_ipl16_j1_w1024_r25t6_u32", 16384: "f32pk_symw_ipl16_j1_w1024_r19t8_u32", 20000: "f32pk_symw_ipl16_j1_w2048_r31t9_u32", 40002: "f32pk_symw_ipl16_j1_w2048_r17t19_u8", 65536: "f32pk_symw_ipl16_j1_w2048", 262144: "f32pk_symw_ipl16_j1_w2048_r5t128", 1048576: "f32pk_symw_ipl16_j1_w2048"}
+            13000: "f32pk_symw_ipl16_j1_w1024_r25t6_u32", 16384: "f32pk_symw_ipl16_j1_w1024_r19t8_u32", 20000: "f32pk_symw_ipl16_j1_w2048_r31t9_u32", 40002: "f32pk_symw_ipl16_j1_w2048_r17t19_u8", 65536: "f32pk_symw_ipl16_j1_w2048", 262144: "f32pk_symw_ipl16_j1_w2048_r32t128", 1048576: "f32pk_symw_ipl16_j1_w2048"}
     for n, prefix in want.items():
         assert capi.plan_query(n)["variant"].startswith(prefix), (n, capi.plan_query(n)["variant"])
     assert capi.plan_query(262144, precision="f64")["variant"].startswith("f64_symw_ipl8_j1_w2048")
