@@ -277,6 +277,47 @@ def test_layers_that_do_not_fit_the_free_memory_go_in_passes():
         assert "symwrank" in s.variant and "_p" in s.variant, s.variant
 
 
+@pytest.mark.parametrize("n,precision", [(140001, "f32"), (131072, "f64")])
+def test_queued_ends_of_the_ranges_do_not_show_in_the_results(n, precision):
+    """Whole sweeps and two waves per SIMD (N >~ 130,000): the last 3.5 % of every older wave's range is cut into pieces that whichever
+    wave is done first draws from a queue (nb_plan.cpp::lay_out_symw, kernels/symmetric.hip.h).  Every piece stores its sums in a layer
+    of its own, so WHO ran it must not show: three handles -- the second with other work on the device while it steps, so that its
+    waves reach the queue in another order -- give bit-identical positions, velocities and accelerations over 6 steps (one graph
+    replay among them); sampled rows of the first step against an fp64 direct sum; momentum of the pair sums."""
+    dt_np = np.float64 if precision == "f64" else np.float32
+    b, v = ic.plummer(n, seed=61)
+    b, v = b.astype(dt_np), v.astype(dt_np)
+    q = capi.plan_query(n, precision=precision)
+    assert q["ups"] == 1 and len(q["pieces"]) > 1000 and q["variant"].startswith("f64_symw" if precision == "f64" else "f32pk_symw"), q["variant"]
+    outs = []
+    with Simulation(50000) as other:                            # something else for the device to do meanwhile
+        ob, ov = ic.plummer(50000, seed=62)
+        other.init(ob, ov)
+        for k in range(3):
+            with Simulation(n, precision=precision) as s:
+                s.init(b, v)
+                s.simulate(1, 1e-3, 1.0)
+                first = s.read(bodies=False, vel=False)[2]
+                if k == 1:
+                    other.simulate(64, 1e-3, 1.0)                # (its own stream: runs beside the steps below)
+                s.simulate(5)
+                outs.append((first,) + tuple(s.read()))
+        other.sync()
+    for o in outs[1:]:
+        for x, y in zip(outs[0], o):
+            assert x.tobytes() == y.tobytes()
+    acc = outs[0][0]
+    x = b[:, :3].astype(np.float64)
+    m = b[:, 3].astype(np.float64)
+    for i in (0, 1, n // 2, n - 1):
+        d = x - x[i]
+        r2 = (d * d).sum(1) + 1e-4
+        want = (m[:, None] * d / (r2 * np.sqrt(r2))[:, None]).sum(0)
+        assert np.abs(acc[i, :3] - want).max() <= (1e-12 if precision == "f64" else 2e-5) * np.abs(want).max(), i
+    f = m[:, None] * acc[:, :3].astype(np.float64)
+    assert np.all(np.abs(f.sum(0)) < (1e-13 if precision == "f64" else 1e-6) * np.abs(f).sum(0))
+
+
 def check_sampled_rows(b, acc, n, rows):
     """Sampled rows of a multi-million-body step against an fp64 direct sum.  A row is a sum of millions of binary32 terms and its
     error is all summation ORDER (tests/golden/large_n_row_spread.json, made by measure_large_n_row_spread.py: the terms themselves
