@@ -392,10 +392,10 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, c
         uint32_t* rec = &s->sym_tab_host[waves0 + 4 * (size_t)phys[p]];
         rec[0] = starts[p]; rec[1] = own_end[p];
     }
-    std::vector<uint32_t> piece_at;                            // (sorted: which queued pieces lie in a super-block's list)
-    for (const Piece& pc : pieces) piece_at.push_back(pc.at);
-    std::sort(piece_at.begin(), piece_at.end());
-    std::vector<uint32_t> piece_layer(Lu && !pieces.empty() ? (size_t)Lu : 0, 0);      // first unit of a piece -> its resident layer
+    std::vector<uint32_t> by_place(pieces.size()), piece_layer(pieces.size(), 0);      // the pieces in list order; piece -> its resident layer
+    for (size_t e = 0; e < pieces.size(); ++e) by_place[e] = (uint32_t)e;
+    std::sort(by_place.begin(), by_place.end(), [&](uint32_t x, uint32_t y) { return pieces[x].at < pieces[y].at; });
+    size_t next_piece = 0;                                      // (the super-blocks are walked in list order too)
     uint32_t max_r = 1;
     for (uint32_t g = 0; g < blocks; ++g) {
         const uint64_t off = (uint64_t)offset_of(g) * ups, end = off + (uint64_t)total_of(g) * ups;
@@ -415,14 +415,14 @@ static void lay_out_symw(LaunchPlan* s, const Shape& sh, bool f64, uint32_t n, c
             s->sym_tab_host[waves0 + 4 * (size_t)phys[p] + 2] = (uint32_t)at;
         }
         layers = (uint32_t)wg_seen.size();
-        for (auto it = std::lower_bound(piece_at.begin(), piece_at.end(), (uint32_t)off); it != piece_at.end() && *it < end; ++it) piece_layer[*it] = layers++;
+        for (; next_piece < by_place.size() && pieces[by_place[next_piece]].at < end; ++next_piece) piece_layer[by_place[next_piece]] = layers++;
         layers += goes_on;
         s->sym_tab_host[2 * g] = phys[first]; s->sym_tab_host[2 * g + 1] = layers;
         if (layers > max_r) max_r = layers;
     }
     for (size_t e = 0; e < pieces.size(); ++e) {                // {first unit, resident layer | sweeps << 16}
         s->sym_tab_host[spill0 + 2 * e] = pieces[e].at;
-        s->sym_tab_host[spill0 + 2 * e + 1] = piece_layer[pieces[e].at] | pieces[e].len << 16;
+        s->sym_tab_host[spill0 + 2 * e + 1] = piece_layer[e] | pieces[e].len << 16;
     }
     s->sym_pieces = (uint32_t)pieces.size();
     // The spill buffer: the z-rows (whole super-block g's sums for chunk c of Z: row g * zc + c), then the spill rows of the waves.
