@@ -292,194 +292,194 @@ void nb_force_symw(const uint32_t* __restrict__ gtab, const float4* __restrict__
     // `red` for the workgroup's meeting below, and that super-block is returned; else a piece drawn from the queue (whole sweeps inside ONE
     // super-block's list), whose resident sums go straight to the resident layer the planner gave it.
     auto run = [&](uint32_t u, const uint32_t uend, const uint32_t piece_layer) -> uint32_t {
-    uint32_t gfin = ~0u;                       // the super-block the range ends in
-    while (u < uend) {
-        // which super-block's list the unit lies in, and where
-        const uint32_t p = u >> ush;                                  // the sweep
-        uint32_t g, k, total;
-        if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
-        else if (p < first_z) { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
-        else { g = pl.nsb; k = p - first_z; total = pl.zc; }         // Z over its own chunks
-        const uint32_t ring = g < pl.nsb ? total - CPS - pl.zc : 0u; // sweeps over the chunks of other super-blocks
-        const uint32_t both_end = g < pl.nsb ? ring + pl.zc : 0u;    // ... then over Z's: both keep traveler sums; own chunks follow
-        uint32_t ug_end = (p - k + total) * ups;                     // end of g's list, in units
-        if (ug_end > uend) ug_end = uend;
+        uint32_t gfin = ~0u;                       // the super-block the range ends in
+        while (u < uend) {
+            // which super-block's list the unit lies in, and where
+            const uint32_t p = u >> ush;                                  // the sweep
+            uint32_t g, k, total;
+            if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
+            else if (p < first_z) { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
+            else { g = pl.nsb; k = p - first_z; total = pl.zc; }         // Z over its own chunks
+            const uint32_t ring = g < pl.nsb ? total - CPS - pl.zc : 0u; // sweeps over the chunks of other super-blocks
+            const uint32_t both_end = g < pl.nsb ? ring + pl.zc : 0u;    // ... then over Z's: both keep traveler sums; own chunks follow
+            uint32_t ug_end = (p - k + total) * ups;                     // end of g's list, in units
+            if (ug_end > uend) ug_end = uend;
 
-        nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
-        {
-            const float4* rb = bodies + (size_t)g * S + lane;
+            nb_f2 xi[NG], yi[NG], zi[NG], mi[NG], ax[NG], ay[NG], az[NG];
+            {
+                const float4* rb = bodies + (size_t)g * S + lane;
 #pragma unroll
-            for (int c = 0; c < NG; ++c) {
-                const float4 b0 = ld4(rb + (2 * c) * 64), b1 = ld4(rb + (2 * c + 1) * 64);
-                xi[c] = nb_f2{b0.x, b1.x}; yi[c] = nb_f2{b0.y, b1.y}; zi[c] = nb_f2{b0.z, b1.z}; mi[c] = nb_f2{b0.w, b1.w};
-                ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
-            }
-        }
-        // Two-level resident sums: a wave that stays with one super-block for thousands of sweeps (N = 2,000,000: one wave per
-        // super-block, 15,632 sweeps = 1,000,448 terms per resident) would add terms of ~a / N to a running sum of ~a in ONE
-        // binary32 register -- the stagnation that puts the reference's own ascending-j loop at 1e-5 .. 5e-4 there
-        // (tests/golden/large_n_row_spread.json; this pass sat at 2e-5).  Every kFlushSteps rotation steps the register sums
-        // move on to a second level kept in the wave's own part of `red` (LDS: 48 reads, adds and writes per 4,096 steps), so
-        // no accumulator takes more than 4,096 * J terms in sequence.  A range that never gets that far (every N below ~400,000
-        // on 256 CUs) never touches LDS here and adds exactly what it added before.
-        uint32_t since = 0;
-        bool flushed = false;
-        while (u < ug_end) {
-            // the wave's steps [s0, s1) of sweep k
-            const uint32_t q0 = u & (ups - 1u);
-            uint32_t nun = ups - q0;
-            if (nun > ug_end - u) nun = ug_end - u;
-            const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
-            u += nun;
-            if (since >= kFlushSteps) {
-                flush_resident_sums<NG>(red[wi], lane, flushed, ax, ay, az);
-                flushed = true;
-                since = 0;
-            }
-            since += s1 - s0;
-            const bool sym = k < both_end, zsweep = k >= ring && sym;
-            const uint32_t d = k / CPS;                              // ring distance - 1 (ring sweeps)
-            uint32_t tb = g + 1 + d;
-            if (tb >= pl.nsb) tb -= pl.nsb;
-            const uint32_t tstart = k < ring ? tb * S + (k % CPS) * CH : zsweep ? pl.nsb * S + (k - ring) * CH : g * S + (k - both_end) * CH;
-            const uint32_t zrow = g * pl.zc + (k - ring);            // (z sweeps)
-            ++k;
-            // (Tried in round 5 and dropped: requesting the travelers of sweep k + 1 before the rotation steps of sweep k -- the wait
-            // moved behind the loop, in front of the stores.  0.3-1 % SLOWER from N = 10,000 to 65,536 at one and two waves per SIMD,
-            // profiles/r05/ab_traveler_prefetch_head_vs_tree.txt: this round trip is not what the short lists wait for.)
-            float tx[J], ty[J], tz[J], tm[J];
-            nb_f2 bx[J], by[J], bz[J];
-            const uint32_t src = ((uint32_t)lane - s0) & 63u;        // the traveler this lane holds after s0 rotation steps
-#pragma unroll
-            for (int uu = 0; uu < J; ++uu) {
-                const float4 t = ld4(bodies + tstart + uu * 64 + src);
-                tx[uu] = t.x; ty[uu] = t.y; tz[uu] = t.z; tm[uu] = t.w;
-                bx[uu] = nb_f2{0, 0}; by[uu] = nb_f2{0, 0}; bz[uu] = nb_f2{0, 0};
-            }
-            // (the loop head is 32-byte aligned by -falign-loops=32: a packed instruction that straddles an 8-byte boundary issues
-            // more slowly -- 12 % on this loop at one wave per SIMD, profiles/r04/README.md)
-            // Two forms of the loop: a sweep over one of the super-block's OWN chunks needs no traveler sums (each of its pairs is met
-            // from both sides), so it drops the 4 packed instructions per group and the 6 rotations that keep them: 116 instead of
-            // 154 issue slots per step with 16 residents -- 0.88 of the time at one or two waves per SIMD (the planner counts 7/8).
-            // (Tried in round 5 and dropped -- commit 4c416e1 has the code: a THIRD, triangular form for the own chunks, chunk c against the
-            // resident rows r > c from both sides and row c resident-only, one instantiation per first packed group, traveler sums folded
-            // into the accumulators of row c: every pair inside a super-block once, 21 % fewer instructions over the 16 own chunks.
-            // Correct (216 GPU tests), but the forms with fewer than four packed groups have fewer than four independent chains and wait
-            // on their own results: 3-4 % SLOWER per step at N = 13,000 .. 20,000 with wave ranges weighted by instruction count,
-            // level with this form after re-weighting -- profiles/r05/own_chunk_triangular_*.txt.)
-            auto steps = [&](auto both) {
-                constexpr bool BOTH = decltype(both)::value;
-                for (uint32_t st = s0; st < s1; ++st) {
-#pragma unroll
-                    for (int uu = 0; uu < J; ++uu) {
-                        const nb_f2 px = nb_f2{tx[uu], tx[uu]}, py = nb_f2{ty[uu], ty[uu]}, pz = nb_f2{tz[uu], tz[uu]}, pm = nb_f2{tm[uu], tm[uu]};
-#pragma unroll
-                        for (int c0g = 0; c0g < NG; c0g += GW) {         // stage-major over groups of (up to) four
-                            nb_f2 dx[GW], dy[GW], dz[GW], d2[GW], r[GW], si[GW], sj[GW];
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) dx[c] = px - xi[c0g + c];                                   // :233
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) dy[c] = py - yi[c0g + c];
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) dz[c] = pz - zi[c0g + c];
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) r[c] = d2[c] * d2[c];                                       // :235
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) r[c] = r[c] * d2[c];
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
-                            if constexpr (BOTH) {
-#pragma unroll
-                                for (int c = 0; c < GW; ++c) sj[c] = mi[c0g + c] * r[c];   // (G m_i) inv: traveler side
-                            }
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
-#pragma unroll
-                            for (int c = 0; c < GW; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
-                            if constexpr (BOTH) {
-#pragma unroll
-                                for (int c = 0; c < GW; ++c) bx[uu] = __builtin_elementwise_fma(-sj[c], dx[c], bx[uu]);   // x_i - x_t = -(x_t - x_i), exactly
-#pragma unroll
-                                for (int c = 0; c < GW; ++c) by[uu] = __builtin_elementwise_fma(-sj[c], dy[c], by[uu]);
-#pragma unroll
-                                for (int c = 0; c < GW; ++c) bz[uu] = __builtin_elementwise_fma(-sj[c], dz[c], bz[uu]);
-                            }
-                        }
-                    }
-#pragma unroll
-                    for (int uu = 0; uu < J; ++uu) {                     // the travelers and their sums move on by one lane
-                        tx[uu] = wave_rot1(tx[uu]); ty[uu] = wave_rot1(ty[uu]); tz[uu] = wave_rot1(tz[uu]); tm[uu] = wave_rot1(tm[uu]);
-                        if constexpr (BOTH) {
-                            bx[uu] = nb_f2{wave_rot1(bx[uu].x), wave_rot1(bx[uu].y)};
-                            by[uu] = nb_f2{wave_rot1(by[uu].x), wave_rot1(by[uu].y)};
-                            bz[uu] = nb_f2{wave_rot1(bz[uu].x), wave_rot1(bz[uu].y)};
-                        }
-                    }
+                for (int c = 0; c < NG; ++c) {
+                    const float4 b0 = ld4(rb + (2 * c) * 64), b1 = ld4(rb + (2 * c + 1) * 64);
+                    xi[c] = nb_f2{b0.x, b1.x}; yi[c] = nb_f2{b0.y, b1.y}; zi[c] = nb_f2{b0.z, b1.z}; mi[c] = nb_f2{b0.w, b1.w};
+                    ax[c] = nb_f2{0, 0}; ay[c] = nb_f2{0, 0}; az[c] = nb_f2{0, 0};
                 }
-            };
-            if (first_part) NB_STAMP(2);       // (drains the loads first: residents + first travelers landed)
-            if (sym) steps(std::true_type{}); else steps(std::false_type{});
-            if (first_part) { NB_STAMP_LIGHT(3); first_part = false; }
-            if (sym) {
-                // the sums of steps [s0, s1) sit s1 lanes past their travelers' home lanes.  The part that starts the sweep owns the
-                // sweep's traveler layer; any later part goes to the wave's own spill row (K2 adds it: the spill rows of a chunk are consecutive)
-                SymRow* out = (s0 != 0 ? spill + (size_t)slot * CH : zsweep ? spill + (size_t)zrow * CH : partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart)
-                              + (((uint32_t)lane - s1) & 63u);
-#pragma unroll
-                for (int uu = 0; uu < J; ++uu) out[uu * 64] = SymRow{bx[uu].x + bx[uu].y, by[uu].x + by[uu].y, bz[uu].x + bz[uu].y};
             }
-        }
-        if (u >= uend && piece_layer != ~0u) {
-            SymRow* out = partial + (size_t)(pl.r_layer0 + piece_layer) * pl.np + (size_t)g * S + lane;
+            // Two-level resident sums: a wave that stays with one super-block for thousands of sweeps (N = 2,000,000: one wave per
+            // super-block, 15,632 sweeps = 1,000,448 terms per resident) would add terms of ~a / N to a running sum of ~a in ONE
+            // binary32 register -- the stagnation that puts the reference's own ascending-j loop at 1e-5 .. 5e-4 there
+            // (tests/golden/large_n_row_spread.json; this pass sat at 2e-5).  Every kFlushSteps rotation steps the register sums
+            // move on to a second level kept in the wave's own part of `red` (LDS: 48 reads, adds and writes per 4,096 steps), so
+            // no accumulator takes more than 4,096 * J terms in sequence.  A range that never gets that far (every N below ~400,000
+            // on 256 CUs) never touches LDS here and adds exactly what it added before.
+            uint32_t since = 0;
+            bool flushed = false;
+            while (u < ug_end) {
+                // the wave's steps [s0, s1) of sweep k
+                const uint32_t q0 = u & (ups - 1u);
+                uint32_t nun = ups - q0;
+                if (nun > ug_end - u) nun = ug_end - u;
+                const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
+                u += nun;
+                if (since >= kFlushSteps) {
+                    flush_resident_sums<NG>(red[wi], lane, flushed, ax, ay, az);
+                    flushed = true;
+                    since = 0;
+                }
+                since += s1 - s0;
+                const bool sym = k < both_end, zsweep = k >= ring && sym;
+                const uint32_t d = k / CPS;                              // ring distance - 1 (ring sweeps)
+                uint32_t tb = g + 1 + d;
+                if (tb >= pl.nsb) tb -= pl.nsb;
+                const uint32_t tstart = k < ring ? tb * S + (k % CPS) * CH : zsweep ? pl.nsb * S + (k - ring) * CH : g * S + (k - both_end) * CH;
+                const uint32_t zrow = g * pl.zc + (k - ring);            // (z sweeps)
+                ++k;
+                // (Tried in round 5 and dropped: requesting the travelers of sweep k + 1 before the rotation steps of sweep k -- the wait
+                // moved behind the loop, in front of the stores.  0.3-1 % SLOWER from N = 10,000 to 65,536 at one and two waves per SIMD,
+                // profiles/r05/ab_traveler_prefetch_head_vs_tree.txt: this round trip is not what the short lists wait for.)
+                float tx[J], ty[J], tz[J], tm[J];
+                nb_f2 bx[J], by[J], bz[J];
+                const uint32_t src = ((uint32_t)lane - s0) & 63u;        // the traveler this lane holds after s0 rotation steps
+#pragma unroll
+                for (int uu = 0; uu < J; ++uu) {
+                    const float4 t = ld4(bodies + tstart + uu * 64 + src);
+                    tx[uu] = t.x; ty[uu] = t.y; tz[uu] = t.z; tm[uu] = t.w;
+                    bx[uu] = nb_f2{0, 0}; by[uu] = nb_f2{0, 0}; bz[uu] = nb_f2{0, 0};
+                }
+                // (the loop head is 32-byte aligned by -falign-loops=32: a packed instruction that straddles an 8-byte boundary issues
+                // more slowly -- 12 % on this loop at one wave per SIMD, profiles/r04/README.md)
+                // Two forms of the loop: a sweep over one of the super-block's OWN chunks needs no traveler sums (each of its pairs is met
+                // from both sides), so it drops the 4 packed instructions per group and the 6 rotations that keep them: 116 instead of
+                // 154 issue slots per step with 16 residents -- 0.88 of the time at one or two waves per SIMD (the planner counts 7/8).
+                // (Tried in round 5 and dropped -- commit 4c416e1 has the code: a THIRD, triangular form for the own chunks, chunk c against the
+                // resident rows r > c from both sides and row c resident-only, one instantiation per first packed group, traveler sums folded
+                // into the accumulators of row c: every pair inside a super-block once, 21 % fewer instructions over the 16 own chunks.
+                // Correct (216 GPU tests), but the forms with fewer than four packed groups have fewer than four independent chains and wait
+                // on their own results: 3-4 % SLOWER per step at N = 13,000 .. 20,000 with wave ranges weighted by instruction count,
+                // level with this form after re-weighting -- profiles/r05/own_chunk_triangular_*.txt.)
+                auto steps = [&](auto both) {
+                    constexpr bool BOTH = decltype(both)::value;
+                    for (uint32_t st = s0; st < s1; ++st) {
+#pragma unroll
+                        for (int uu = 0; uu < J; ++uu) {
+                            const nb_f2 px = nb_f2{tx[uu], tx[uu]}, py = nb_f2{ty[uu], ty[uu]}, pz = nb_f2{tz[uu], tz[uu]}, pm = nb_f2{tm[uu], tm[uu]};
+#pragma unroll
+                            for (int c0g = 0; c0g < NG; c0g += GW) {         // stage-major over groups of (up to) four
+                                nb_f2 dx[GW], dy[GW], dz[GW], d2[GW], r[GW], si[GW], sj[GW];
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) dx[c] = px - xi[c0g + c];                                   // :233
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) dy[c] = py - yi[c0g + c];
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) dz[c] = pz - zi[c0g + c];
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dx[c], dx[c], e2);         // :234
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dy[c], dy[c], d2[c]);
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) d2[c] = __builtin_elementwise_fma(dz[c], dz[c], d2[c]);
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) r[c] = d2[c] * d2[c];                                       // :235
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) r[c] = r[c] * d2[c];
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) r[c] = nb_f2{nb_rsq(r[c].x), nb_rsq(r[c].y)};
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) si[c] = pm * r[c];                // (G m_t) inv: resident side, :236
+                                if constexpr (BOTH) {
+#pragma unroll
+                                    for (int c = 0; c < GW; ++c) sj[c] = mi[c0g + c] * r[c];   // (G m_i) inv: traveler side
+                                }
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) ax[c0g + c] = __builtin_elementwise_fma(si[c], dx[c], ax[c0g + c]);
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) ay[c0g + c] = __builtin_elementwise_fma(si[c], dy[c], ay[c0g + c]);
+#pragma unroll
+                                for (int c = 0; c < GW; ++c) az[c0g + c] = __builtin_elementwise_fma(si[c], dz[c], az[c0g + c]);
+                                if constexpr (BOTH) {
+#pragma unroll
+                                    for (int c = 0; c < GW; ++c) bx[uu] = __builtin_elementwise_fma(-sj[c], dx[c], bx[uu]);   // x_i - x_t = -(x_t - x_i), exactly
+#pragma unroll
+                                    for (int c = 0; c < GW; ++c) by[uu] = __builtin_elementwise_fma(-sj[c], dy[c], by[uu]);
+#pragma unroll
+                                    for (int c = 0; c < GW; ++c) bz[uu] = __builtin_elementwise_fma(-sj[c], dz[c], bz[uu]);
+                                }
+                            }
+                        }
+#pragma unroll
+                        for (int uu = 0; uu < J; ++uu) {                     // the travelers and their sums move on by one lane
+                            tx[uu] = wave_rot1(tx[uu]); ty[uu] = wave_rot1(ty[uu]); tz[uu] = wave_rot1(tz[uu]); tm[uu] = wave_rot1(tm[uu]);
+                            if constexpr (BOTH) {
+                                bx[uu] = nb_f2{wave_rot1(bx[uu].x), wave_rot1(bx[uu].y)};
+                                by[uu] = nb_f2{wave_rot1(by[uu].x), wave_rot1(by[uu].y)};
+                                bz[uu] = nb_f2{wave_rot1(bz[uu].x), wave_rot1(bz[uu].y)};
+                            }
+                        }
+                    }
+                };
+                if (first_part) NB_STAMP(2);       // (drains the loads first: residents + first travelers landed)
+                if (sym) steps(std::true_type{}); else steps(std::false_type{});
+                if (first_part) { NB_STAMP_LIGHT(3); first_part = false; }
+                if (sym) {
+                    // the sums of steps [s0, s1) sit s1 lanes past their travelers' home lanes.  The part that starts the sweep owns the
+                    // sweep's traveler layer; any later part goes to the wave's own spill row (K2 adds it: the spill rows of a chunk are consecutive)
+                    SymRow* out = (s0 != 0 ? spill + (size_t)slot * CH : zsweep ? spill + (size_t)zrow * CH : partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart)
+                                  + (((uint32_t)lane - s1) & 63u);
+#pragma unroll
+                    for (int uu = 0; uu < J; ++uu) out[uu * 64] = SymRow{bx[uu].x + bx[uu].y, by[uu].x + by[uu].y, bz[uu].x + bz[uu].y};
+                }
+            }
+            if (u >= uend && piece_layer != ~0u) {
+                SymRow* out = partial + (size_t)(pl.r_layer0 + piece_layer) * pl.np + (size_t)g * S + lane;
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    if (flushed) {         // (a long piece of a very large system: second level + what the registers hold)
+                        ax[c].x += red[wi][6 * c + 0][lane]; ay[c].x += red[wi][6 * c + 1][lane]; az[c].x += red[wi][6 * c + 2][lane];
+                        ax[c].y += red[wi][6 * c + 3][lane]; ay[c].y += red[wi][6 * c + 4][lane]; az[c].y += red[wi][6 * c + 5][lane];
+                    }
+                    out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
+                    out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
+                }
+                return g;
+            }
+            if (u >= uend) {
+                // the range ends here: the sums meet those of the workgroup's other waves in LDS (below)
+                gfin = g;
+#pragma unroll
+                for (int c = 0; c < NG; ++c) {
+                    if (flushed) {         // second level + what the registers hold
+                        ax[c].x += red[wi][6 * c + 0][lane]; ay[c].x += red[wi][6 * c + 1][lane]; az[c].x += red[wi][6 * c + 2][lane];
+                        ax[c].y += red[wi][6 * c + 3][lane]; ay[c].y += red[wi][6 * c + 4][lane]; az[c].y += red[wi][6 * c + 5][lane];
+                    }
+                    red[wi][6 * c + 0][lane] = ax[c].x; red[wi][6 * c + 1][lane] = ay[c].x; red[wi][6 * c + 2][lane] = az[c].x;
+                    red[wi][6 * c + 3][lane] = ax[c].y; red[wi][6 * c + 4][lane] = ay[c].y; red[wi][6 * c + 5][lane] = az[c].y;
+                }
+                break;
+            }
+            // the range goes on into the next super-block: the resident sums of this part go to g's last layer (only the last wave of a
+            // super-block's list can go on)
+            SymRow* out = partial + (size_t)(pl.r_layer0 + gtab[2 * g + 1] - 1u) * pl.np + (size_t)g * S + lane;
 #pragma unroll
             for (int c = 0; c < NG; ++c) {
-                if (flushed) {         // (a long piece of a very large system: second level + what the registers hold)
+                if (flushed) {
                     ax[c].x += red[wi][6 * c + 0][lane]; ay[c].x += red[wi][6 * c + 1][lane]; az[c].x += red[wi][6 * c + 2][lane];
                     ax[c].y += red[wi][6 * c + 3][lane]; ay[c].y += red[wi][6 * c + 4][lane]; az[c].y += red[wi][6 * c + 5][lane];
                 }
                 out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
                 out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
             }
-            return g;
         }
-        if (u >= uend) {
-            // the range ends here: the sums meet those of the workgroup's other waves in LDS (below)
-            gfin = g;
-#pragma unroll
-            for (int c = 0; c < NG; ++c) {
-                if (flushed) {         // second level + what the registers hold
-                    ax[c].x += red[wi][6 * c + 0][lane]; ay[c].x += red[wi][6 * c + 1][lane]; az[c].x += red[wi][6 * c + 2][lane];
-                    ax[c].y += red[wi][6 * c + 3][lane]; ay[c].y += red[wi][6 * c + 4][lane]; az[c].y += red[wi][6 * c + 5][lane];
-                }
-                red[wi][6 * c + 0][lane] = ax[c].x; red[wi][6 * c + 1][lane] = ay[c].x; red[wi][6 * c + 2][lane] = az[c].x;
-                red[wi][6 * c + 3][lane] = ax[c].y; red[wi][6 * c + 4][lane] = ay[c].y; red[wi][6 * c + 5][lane] = az[c].y;
-            }
-            break;
-        }
-        // the range goes on into the next super-block: the resident sums of this part go to g's last layer (only the last wave of a
-        // super-block's list can go on)
-        SymRow* out = partial + (size_t)(pl.r_layer0 + gtab[2 * g + 1] - 1u) * pl.np + (size_t)g * S + lane;
-#pragma unroll
-        for (int c = 0; c < NG; ++c) {
-            if (flushed) {
-                ax[c].x += red[wi][6 * c + 0][lane]; ay[c].x += red[wi][6 * c + 1][lane]; az[c].x += red[wi][6 * c + 2][lane];
-                ax[c].y += red[wi][6 * c + 3][lane]; ay[c].y += red[wi][6 * c + 4][lane]; az[c].y += red[wi][6 * c + 5][lane];
-            }
-            out[(2 * c) * 64] = SymRow{ax[c].x, ay[c].x, az[c].x};
-            out[(2 * c + 1) * 64] = SymRow{ax[c].y, ay[c].y, az[c].y};
-        }
-    }
-    return gfin;
+        return gfin;
     };
     const uint32_t gfin = run(active ? rec.x : 0u, active ? rec.y : 0u, ~0u);
     // The resident sums of the super-block the range ends in: the waves of the workgroup that end in the same one (consecutive
@@ -490,21 +490,21 @@ void nb_force_symw(const uint32_t* __restrict__ gtab, const float4* __restrict__
     __syncthreads();
     NB_STAMP_LIGHT(9);
     if (gfin != ~0u) {
-    int members = 0, mine = 0;
+        int members = 0, mine = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool same = fin[j] == gfin;
-        members += same;
-        mine += same && j < wi;
-    }
-    SymRow* out = partial + (size_t)(pl.r_layer0 + rec.z) * pl.np + (size_t)gfin * S + lane;
-    for (int r = mine; r < 2 * NG; r += members) {       // the members share the rows out
-        float sx = 0.f, sy = 0.f, sz = 0.f;
+        for (int j = 0; j < 4; ++j) {
+            const bool same = fin[j] == gfin;
+            members += same;
+            mine += same && j < wi;
+        }
+        SymRow* out = partial + (size_t)(pl.r_layer0 + rec.z) * pl.np + (size_t)gfin * S + lane;
+        for (int r = mine; r < 2 * NG; r += members) {       // the members share the rows out
+            float sx = 0.f, sy = 0.f, sz = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (fin[j] == gfin) { sx += red[j][3 * r + 0][lane]; sy += red[j][3 * r + 1][lane]; sz += red[j][3 * r + 2][lane]; }
-        out[r * 64] = SymRow{sx, sy, sz};
-    }
+            for (int j = 0; j < 4; ++j)
+                if (fin[j] == gfin) { sx += red[j][3 * r + 0][lane]; sy += red[j][3 * r + 1][lane]; sz += red[j][3 * r + 2][lane]; }
+            out[r * 64] = SymRow{sx, sy, sz};
+        }
     }
     // The queue (two waves per SIMD, whole sweeps; nb_plan.cpp::lay_out_symw): the last sweeps of every older wave's range are nobody's
     // own -- a wave that is done draws them one at a time, so the XCDs that hold a higher clock (or started earlier) take more of them
@@ -564,119 +564,119 @@ void nb_force_symw64(const uint32_t* __restrict__ gtab, const double4* __restric
     const uint32_t first_lo = pl.n_hi * pl.total_hi, first_z = first_lo + (pl.nsb - pl.n_hi) * pl.total_lo;
     const uint32_t slot = rec.w;
     auto run = [&](uint32_t u, const uint32_t uend, const uint32_t piece_layer) -> uint32_t {      // see nb_force_symw: the wave's own range, or a piece drawn from the queue
-    uint32_t gfin = ~0u;
-    while (u < uend) {
-        const uint32_t p = u >> ush;
-        uint32_t g, k, total;
-        if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
-        else if (p < first_z) { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
-        else { g = pl.nsb; k = p - first_z; total = pl.zc; }
-        const uint32_t ring = g < pl.nsb ? total - CPS - pl.zc : 0u, both_end = g < pl.nsb ? ring + pl.zc : 0u;
-        uint32_t ug_end = (p - k + total) * ups;
-        if (ug_end > uend) ug_end = uend;
-        double xi[IPL], yi[IPL], zi[IPL], mi[IPL], ax[IPL], ay[IPL], az[IPL];
+        uint32_t gfin = ~0u;
+        while (u < uend) {
+            const uint32_t p = u >> ush;
+            uint32_t g, k, total;
+            if (p < first_lo) { g = p / pl.total_hi; k = p - g * pl.total_hi; total = pl.total_hi; }
+            else if (p < first_z) { const uint32_t r = p - first_lo; g = pl.n_hi + r / pl.total_lo; k = r - (g - pl.n_hi) * pl.total_lo; total = pl.total_lo; }
+            else { g = pl.nsb; k = p - first_z; total = pl.zc; }
+            const uint32_t ring = g < pl.nsb ? total - CPS - pl.zc : 0u, both_end = g < pl.nsb ? ring + pl.zc : 0u;
+            uint32_t ug_end = (p - k + total) * ups;
+            if (ug_end > uend) ug_end = uend;
+            double xi[IPL], yi[IPL], zi[IPL], mi[IPL], ax[IPL], ay[IPL], az[IPL];
 #pragma unroll
-        for (int c = 0; c < IPL; ++c) {
-            const double4 b = ld4(bodies + (size_t)g * S + c * 64 + lane);
-            xi[c] = b.x; yi[c] = b.y; zi[c] = b.z; mi[c] = b.w * G;
-            ax[c] = 0; ay[c] = 0; az[c] = 0;
-        }
-        while (u < ug_end) {
-            const uint32_t q0 = u & (ups - 1u);
-            uint32_t nun = ups - q0;
-            if (nun > ug_end - u) nun = ug_end - u;
-            const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
-            u += nun;
-            const bool sym = k < both_end, zsweep = k >= ring && sym;
-            const uint32_t d = k / CPS;
-            uint32_t tb = g + 1 + d;
-            if (tb >= pl.nsb) tb -= pl.nsb;
-            const uint32_t tstart = k < ring ? tb * S + (k % CPS) * CH : zsweep ? pl.nsb * S + (k - ring) * CH : g * S + (k - both_end) * CH;
-            const uint32_t zrow = g * pl.zc + (k - ring);
-            ++k;
-            const double4 t = ld4(bodies + tstart + (((uint32_t)lane - s0) & 63u));
-            double tx = t.x, ty = t.y, tz = t.z, tm = t.w * G, bx = 0, by = 0, bz = 0;
-            auto steps = [&](auto both) {                                // see nb_force_symw: a sweep over an own chunk keeps no traveler sums
-                constexpr bool BOTH = decltype(both)::value;
-                for (uint32_t st = s0; st < s1; ++st) {
+            for (int c = 0; c < IPL; ++c) {
+                const double4 b = ld4(bodies + (size_t)g * S + c * 64 + lane);
+                xi[c] = b.x; yi[c] = b.y; zi[c] = b.z; mi[c] = b.w * G;
+                ax[c] = 0; ay[c] = 0; az[c] = 0;
+            }
+            while (u < ug_end) {
+                const uint32_t q0 = u & (ups - 1u);
+                uint32_t nun = ups - q0;
+                if (nun > ug_end - u) nun = ug_end - u;
+                const uint32_t s0 = q0 * ustep, s1 = s0 + nun * ustep;
+                u += nun;
+                const bool sym = k < both_end, zsweep = k >= ring && sym;
+                const uint32_t d = k / CPS;
+                uint32_t tb = g + 1 + d;
+                if (tb >= pl.nsb) tb -= pl.nsb;
+                const uint32_t tstart = k < ring ? tb * S + (k % CPS) * CH : zsweep ? pl.nsb * S + (k - ring) * CH : g * S + (k - both_end) * CH;
+                const uint32_t zrow = g * pl.zc + (k - ring);
+                ++k;
+                const double4 t = ld4(bodies + tstart + (((uint32_t)lane - s0) & 63u));
+                double tx = t.x, ty = t.y, tz = t.z, tm = t.w * G, bx = 0, by = 0, bz = 0;
+                auto steps = [&](auto both) {                                // see nb_force_symw: a sweep over an own chunk keeps no traveler sums
+                    constexpr bool BOTH = decltype(both)::value;
+                    for (uint32_t st = s0; st < s1; ++st) {
 #pragma unroll
-                    for (int c0g = 0; c0g < IPL; c0g += GW) {            // stage-major over four residents
-                        double dx[GW], dy[GW], dz[GW], d2[GW], y[GW], uu[GW];
+                        for (int c0g = 0; c0g < IPL; c0g += GW) {            // stage-major over four residents
+                            double dx[GW], dy[GW], dz[GW], d2[GW], y[GW], uu[GW];
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) dx[c] = tx - xi[c0g + c];
+                            for (int c = 0; c < GW; ++c) dx[c] = tx - xi[c0g + c];
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) dy[c] = ty - yi[c0g + c];
+                            for (int c = 0; c < GW; ++c) dy[c] = ty - yi[c0g + c];
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) dz[c] = tz - zi[c0g + c];
+                            for (int c = 0; c < GW; ++c) dz[c] = tz - zi[c0g + c];
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) d2[c] = nb_fma(dz[c], dz[c], nb_fma(dy[c], dy[c], nb_fma(dx[c], dx[c], eps2)));
+                            for (int c = 0; c < GW; ++c) d2[c] = nb_fma(dz[c], dz[c], nb_fma(dy[c], dy[c], nb_fma(dx[c], dx[c], eps2)));
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) y[c] = __builtin_amdgcn_rsq(d2[c]);
+                            for (int c = 0; c < GW; ++c) y[c] = __builtin_amdgcn_rsq(d2[c]);
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) {
-                            const double y2 = y[c] * y[c];
-                            const double e = nb_fma(-d2[c], y2, 1.0);
-                            const double t3 = y[c] * y2;
-                            uu[c] = nb_fma(t3 * e, 1.5, t3);
-                        }
+                            for (int c = 0; c < GW; ++c) {
+                                const double y2 = y[c] * y[c];
+                                const double e = nb_fma(-d2[c], y2, 1.0);
+                                const double t3 = y[c] * y2;
+                                uu[c] = nb_fma(t3 * e, 1.5, t3);
+                            }
 #pragma unroll
-                        for (int c = 0; c < GW; ++c) {
-                            const double si = tm * uu[c];
-                            ax[c0g + c] = nb_fma(si, dx[c], ax[c0g + c]); ay[c0g + c] = nb_fma(si, dy[c], ay[c0g + c]); az[c0g + c] = nb_fma(si, dz[c], az[c0g + c]);
-                            if constexpr (BOTH) {
-                                const double sj = mi[c0g + c] * uu[c];
-                                bx = nb_fma(-sj, dx[c], bx); by = nb_fma(-sj, dy[c], by); bz = nb_fma(-sj, dz[c], bz);
+                            for (int c = 0; c < GW; ++c) {
+                                const double si = tm * uu[c];
+                                ax[c0g + c] = nb_fma(si, dx[c], ax[c0g + c]); ay[c0g + c] = nb_fma(si, dy[c], ay[c0g + c]); az[c0g + c] = nb_fma(si, dz[c], az[c0g + c]);
+                                if constexpr (BOTH) {
+                                    const double sj = mi[c0g + c] * uu[c];
+                                    bx = nb_fma(-sj, dx[c], bx); by = nb_fma(-sj, dy[c], by); bz = nb_fma(-sj, dz[c], bz);
+                                }
                             }
                         }
+                        tx = wave_rot1(tx); ty = wave_rot1(ty); tz = wave_rot1(tz); tm = wave_rot1(tm);
+                        if constexpr (BOTH) { bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz); }
                     }
-                    tx = wave_rot1(tx); ty = wave_rot1(ty); tz = wave_rot1(tz); tm = wave_rot1(tm);
-                    if constexpr (BOTH) { bx = wave_rot1(bx); by = wave_rot1(by); bz = wave_rot1(bz); }
+                };
+                if (sym) steps(std::true_type{}); else steps(std::false_type{});
+                if (sym) {
+                    SymRowT<double>* out = (s0 != 0 ? spill + (size_t)slot * CH : zsweep ? spill + (size_t)zrow * CH : partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart)
+                                           + (((uint32_t)lane - s1) & 63u);
+                    *out = SymRowT<double>{bx, by, bz};
                 }
-            };
-            if (sym) steps(std::true_type{}); else steps(std::false_type{});
-            if (sym) {
-                SymRowT<double>* out = (s0 != 0 ? spill + (size_t)slot * CH : zsweep ? spill + (size_t)zrow * CH : partial + (size_t)(pl.t_layer0 + d) * pl.np + tstart)
-                                       + (((uint32_t)lane - s1) & 63u);
-                *out = SymRowT<double>{bx, by, bz};
             }
-        }
-        if (u >= uend && piece_layer != ~0u) {
-            SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + piece_layer) * pl.np + (size_t)g * S + lane;
+            if (u >= uend && piece_layer != ~0u) {
+                SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + piece_layer) * pl.np + (size_t)g * S + lane;
+#pragma unroll
+                for (int c = 0; c < IPL; ++c) out[c * 64] = SymRowT<double>{ax[c], ay[c], az[c]};
+                return g;
+            }
+            if (u >= uend) {
+                gfin = g;
+#pragma unroll
+                for (int c = 0; c < IPL; ++c) { red[wi][3 * c + 0][lane] = ax[c]; red[wi][3 * c + 1][lane] = ay[c]; red[wi][3 * c + 2][lane] = az[c]; }
+                break;
+            }
+            SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + gtab[2 * g + 1] - 1u) * pl.np + (size_t)g * S + lane;     // the range goes on: g's last layer
 #pragma unroll
             for (int c = 0; c < IPL; ++c) out[c * 64] = SymRowT<double>{ax[c], ay[c], az[c]};
-            return g;
         }
-        if (u >= uend) {
-            gfin = g;
-#pragma unroll
-            for (int c = 0; c < IPL; ++c) { red[wi][3 * c + 0][lane] = ax[c]; red[wi][3 * c + 1][lane] = ay[c]; red[wi][3 * c + 2][lane] = az[c]; }
-            break;
-        }
-        SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + gtab[2 * g + 1] - 1u) * pl.np + (size_t)g * S + lane;     // the range goes on: g's last layer
-#pragma unroll
-        for (int c = 0; c < IPL; ++c) out[c * 64] = SymRowT<double>{ax[c], ay[c], az[c]};
-    }
-    return gfin;
+        return gfin;
     };
     const uint32_t gfin = run(active ? rec.x : 0u, active ? rec.y : 0u, ~0u);
     if (lane == 0) fin[wi] = gfin;
     __syncthreads();
     if (gfin != ~0u) {
-    int members = 0, mine = 0;
+        int members = 0, mine = 0;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool same = fin[j] == gfin;
-        members += same;
-        mine += same && j < wi;
-    }
-    SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + rec.z) * pl.np + (size_t)gfin * S + lane;
-    for (int r = mine; r < IPL; r += members) {
-        double sx = 0, sy = 0, sz = 0;
+        for (int j = 0; j < 4; ++j) {
+            const bool same = fin[j] == gfin;
+            members += same;
+            mine += same && j < wi;
+        }
+        SymRowT<double>* out = partial + (size_t)(pl.r_layer0 + rec.z) * pl.np + (size_t)gfin * S + lane;
+        for (int r = mine; r < IPL; r += members) {
+            double sx = 0, sy = 0, sz = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (fin[j] == gfin) { sx += red[j][3 * r + 0][lane]; sy += red[j][3 * r + 1][lane]; sz += red[j][3 * r + 2][lane]; }
-        out[r * 64] = SymRowT<double>{sx, sy, sz};
-    }
+            for (int j = 0; j < 4; ++j)
+                if (fin[j] == gfin) { sx += red[j][3 * r + 0][lane]; sy += red[j][3 * r + 1][lane]; sz += red[j][3 * r + 2][lane]; }
+            out[r * 64] = SymRowT<double>{sx, sy, sz};
+        }
     }
     if (npieces) {                             // the queue: see nb_force_symw
         for (;;) {
