@@ -962,34 +962,49 @@ __global__ __launch_bounds__(kBlock) void nb_sym_reduce(const SymRowT<T>* __rest
     const uint32_t b = j / S, g0 = pl.g0, g1 = pl.g1, within = j - b * S;
     const size_t lstride = (size_t)(g1 - g0) * S;                // compact layers: rows filed under the own super-block that wrote them
     T sx = 0, sy = 0, sz = 0;
+    // FOUR rows requested per trip, added in the same fixed order as one by one (round 5: a thread that loaded a row, added it and only
+    // then asked for the next was a chain of dependent round trips -- 61 us per call for a rank of 8 at N = 262,144).  `at(e)` names the
+    // e-th row of a section, or nullptr where the section has none at e: row 0 of `partial` is requested in its place and 0 added.
+    auto add_rows = [&](uint32_t count, auto at) {
+        for (uint32_t e = 0; e < count; e += 4) {
+            const SymRow* q[4];
+            SymRow r[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { q[i] = e + i < count ? at(e + i) : nullptr; r[i] = *(q[i] ? q[i] : partial); }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { sx += q[i] ? r[i].x : T(0); sy += q[i] ? r[i].y : T(0); sz += q[i] ? r[i].z : T(0); }
+        }
+    };
     if (b >= g0 && b < g1) {                                     // resident layers: phase A's waves, then phase B's
         const uint32_t na = tab[4 * b + 1], nb_ = tab[4 * b + 3];
         const size_t row = (size_t)(b - g0) * S + within;
-        for (uint32_t e = 0; e < na; ++e) { const SymRow r = partial[(size_t)(pl.r_layer0 + e) * lstride + row]; sx += r.x; sy += r.y; sz += r.z; }
-        for (uint32_t e = 0; e < nb_; ++e) { const SymRow r = partial[(size_t)(pl.rb_layer0 + e) * lstride + row]; sx += r.x; sy += r.y; sz += r.z; }
+        add_rows(na, [&](uint32_t e) { return partial + (size_t)(pl.r_layer0 + e) * lstride + row; });
+        add_rows(nb_, [&](uint32_t e) { return partial + (size_t)(pl.rb_layer0 + e) * lstride + row; });
     }
     if (g1 - g0 > pl.H) {
-        for (uint32_t d = d0; d <= pl.H && d < d1; ++d) {        // few ring distances, many own super-blocks: ascending distance
+        // few ring distances, many own super-blocks: ascending distance
+        add_rows(pl.H + 1 > d0 ? std::min(pl.H + 1, d1) - d0 : 0u, [&](uint32_t e) -> const SymRow* {
+            const uint32_t d = d0 + e;
             uint32_t g = b + pl.nsb - 1 - d;
             if (g >= pl.nsb) g -= pl.nsb;
-            if (d < d0 || d >= d1 || g < g0 || g >= g1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;       // [d0, d1): the ring distances of this pass
-            const SymRow r = partial[(size_t)(pl.t_layer0 + d - d0) * lstride + (size_t)(g - g0) * S + within];
-            sx += r.x; sy += r.y; sz += r.z;
-        }
+            if (g < g0 || g >= g1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) return nullptr;       // [d0, d1): the ring distances of this pass
+            return partial + (size_t)(pl.t_layer0 + d - d0) * lstride + (size_t)(g - g0) * S + within;
+        });
     } else {
-        for (uint32_t g = g0; g < g1; ++g) {                     // a rank of many: only its own super-blocks can have written a layer of row j
+        // a rank of many: only its own super-blocks can have written a layer of row j
+        add_rows(g1 - g0, [&](uint32_t e) -> const SymRow* {
+            const uint32_t g = g0 + e;
             uint32_t d = b + pl.nsb - 1 - g;
             if (d >= pl.nsb) d -= pl.nsb;
-            if (d < d0 || d >= d1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) continue;
-            const SymRow r = partial[(size_t)(pl.t_layer0 + d - d0) * lstride + (size_t)(g - g0) * S + within];
-            sx += r.x; sy += r.y; sz += r.z;
-        }
+            if (d < d0 || d >= d1 || d >= pl.H + (g < pl.n_hi ? 1u : 0u)) return nullptr;
+            return partial + (size_t)(pl.t_layer0 + d - d0) * lstride + (size_t)(g - g0) * S + within;
+        });
     }
     if (pl.ups > 1) {                                            // later parts of sweeps shared by two waves: the chunk's spill list
         const uint32_t base = 4 * pl.nsb + 2 * (g1 - g0 + 1), ci = j >> 6;
         const uint32_t so = tab[base + 2 * ci], ns = tab[base + 2 * ci + 1];
         const uint32_t* ids = tab + base + 2 * (pl.np >> 6) + so;
-        for (uint32_t e = 0; e < ns; ++e) { const SymRow r = spill[(size_t)ids[e] * 64u + (j & 63u)]; sx += r.x; sy += r.y; sz += r.z; }
+        add_rows(ns, [&](uint32_t e) { return spill + (size_t)ids[e] * 64u + (j & 63u); });
     }
     if (accumulate) { const V4 o = ld4(A + j); sx += o.x; sy += o.y; sz += o.z; }      // a later pass over the ring distances: layers reused, sums carried in A
     A[j] = V4{sx, sy, sz, 0};
